@@ -1,0 +1,330 @@
+/*
+ * trx.h — C-ABI of the MI355X (gfx950) CWBVH traversal backend for tray_racing.
+ *
+ * This is the drop-in boundary for the ONE hot path of DGriffin91/tray_racing:
+ * closest-hit traversal of rays through a CWBVH (80-byte nodes) with
+ * Moeller-Trumbore triangle tests, for primary and AO rays.
+ *
+ * Every entry point names the reference interface it replaces (paths relative
+ * to the tray_racing checkout).  Plain pointers and sizes only; no C++ or
+ * torch types cross this boundary.  All functions return 0 on success or a
+ * negative trx_status; the message is available from trx_last_error()
+ * (thread-local).  Nothing here aborts: the Rust shim `expect()`s on the
+ * status to keep the reference's panic convention (src/main.rs:178-180).
+ *
+ * There is NO CPU fallback behind this ABI: every trace entry point fails
+ * with TRX_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef TRX_H
+#define TRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRX_ABI_VERSION 1
+
+typedef enum trx_status {
+    TRX_OK = 0,
+    TRX_ERR_INVALID = -1,        /* bad argument (null pointer, size mismatch, bad enum) */
+    TRX_ERR_NO_DEVICE = -2,      /* no usable HIP device / HIP call failed               */
+    TRX_ERR_OOM = -3,            /* host or device allocation failed                     */
+    TRX_ERR_STACK_OVERFLOW = -4, /* a ray exceeded the traversal stack (result invalid)  */
+    TRX_ERR_FORMAT = -5,         /* node/triangle buffer fails structural validation     */
+    TRX_ERR_IO = -6              /* scene / model file could not be read                 */
+} trx_status;
+
+/* ---- data formats -------------------------------------------------------- */
+
+/* One CWBVH node = 80 bytes = uint4[5], exactly the layout the reference's
+ * GPU path consumes (src/rt_gpu/rt_gpu_software_query.hlsl:40-43, decode at
+ * :219-224,249,257-264,381-384; size asserts src/rt_gpu/mod.rs:70,105;
+ * writer embree/src/bvh_embree_to_cwbvh.rs:172-185). */
+#define TRX_NODE_BYTES 80u
+
+/* Triangle input formats accepted by trx_scene_create. */
+typedef enum trx_tri_format {
+    /* obvhs RtCompressedTriangle, 24 B: f32 v0[3]; u32 e[3] with
+     * e[k] = f16(e2[k]) | f16(e1[k]) << 16, e1 = v1 - v0, e2 = v2 - v0
+     * (src/rt_gpu/rt_gpu_software_query.hlsl:45-49,75-85; src/rt_gpu/mod.rs:39-43,86). */
+    TRX_TRI_F16_24 = 0,
+    /* Raw obvhs `Triangle`, 36 B: f32 v0[3], v1[3], v2[3] (src/main.rs:515-519,540-544). */
+    TRX_TRI_VERTS_36 = 1,
+    /* f32 {v0[3], e1[3], e2[3]}, 36 B with e1 = v0 - v1, e2 = v2 - v0: the
+     * f32 content of obvhs RtTriangle without padding / ng (src/rt_cpu/mod.rs:38-43). */
+    TRX_TRI_EDGES_36 = 2
+} trx_tri_format;
+
+/* Bytes per triangle for a trx_tri_format (0 for an unknown value). */
+uint32_t trx_tri_format_bytes(uint32_t tri_format);
+
+/* Traversal semantics (bit set).  0 is the literal in-tree HLSL text.  The
+ * reference's --cpu path lives in the un-vendored obvhs crate; the deviations
+ * recalled for it are exposed as bits, and TRX_SEM_CPU is
+ * the preset that combines them.  Every combination has an oracle twin. */
+typedef enum trx_semantics {
+    /* per-node IEEE divides, separate multiply and add for the slab planes,
+     * tt <= t commits (last equal-t triangle wins):
+     * src/rt_gpu/rt_gpu_software_query.hlsl:237-242,285-286,120 */
+    TRX_SEM_HLSL = 0,
+    /* node test multiplies by inv_dir = 1/dir computed once per ray with an IEEE
+     * divide.  2^e * inv_dir is bit-identical to 2^e / dir (power-of-two scale);
+     * (p - origin) * inv_dir may differ from (p - origin) / dir in the last ulp,
+     * which can only change which boxes are culled at razor edges. */
+    TRX_SEM_NODE_RCP = 1u << 0,
+    /* commit a triangle only if tt < t (first equal-t triangle wins) */
+    TRX_SEM_TIE_FIRST = 1u << 1,
+    /* evaluate the slab planes q * adj_inv + adj_origin with one fused
+     * multiply-add (the HLSL leaves contraction to the compiler) */
+    TRX_SEM_NODE_FMA = 1u << 2,
+    /* recalled obvhs CPU path: precomputed inv_direction, strict t < tmax */
+    TRX_SEM_CPU = (1u << 0) | (1u << 1)
+} trx_semantics;
+
+/* ViewUniform mirror (src/main.rs:589-597, HLSL cbuffer
+ * src/rt_gpu/rt_gpu_software.hlsl:30-38).  Matrices are column-major like glam
+ * (m[c*4 + r]).  Filled by trx_view_from_camera or by the caller. */
+typedef struct trx_view {
+    float view_inv[16];
+    float proj_inv[16];
+    float eye[3];
+    float exposure;
+    uint32_t tlas_start; /* unused by the traced path; scene carries it */
+    uint32_t _pad[3];
+} trx_view;
+
+/* Explicit ray, 32 B: mirrors obvhs Ray::new(origin, direction, tmin, tmax)
+ * as used at src/rt_cpu/rt_cpu.rs:50-55,76. */
+typedef struct trx_ray {
+    float origin[3];
+    float tmin;
+    float direction[3];
+    float tmax;
+} trx_ray;
+
+/* Compact hit record written by every kernel: 8 B per ray.
+ * Miss: t = +inf, prim = 0xFFFFFFFF (RayHit::none(), callers test
+ * hit.t < f32::MAX, src/rt_cpu/rt_cpu.rs:61,82).  `prim` indexes the
+ * triangle buffer handed to trx_scene_create (i.e. primitive_indices order,
+ * src/rt_gpu/mod.rs:38-48). */
+typedef struct trx_hit {
+    float t;
+    uint32_t prim;
+} trx_hit;
+
+/* Mirror of obvhs RayHit {primitive_id, geometry_id, instance_id, t}
+ * (fields: embree/src/embree_managed.rs:52-57) for the Traversable shim. */
+typedef struct trx_rayhit {
+    uint32_t primitive_id;
+    uint32_t geometry_id;
+    uint32_t instance_id;
+    float t;
+} trx_rayhit;
+
+/* Which pixels of the w*h image this call (this GPU) traces: 8x8-pixel tiles
+ * are numbered row-major; a call traces tiles with (tile % count) == index.
+ * {0,1} = whole image.  Output buffers are ALWAYS indexed by full-image pixel
+ * id (y*w + x); untouched pixels are left as they were. */
+typedef struct trx_shard {
+    uint32_t index;
+    uint32_t count;
+} trx_shard;
+
+/* Per-call counters (optional; pass NULL).  n_node / n_tri are the PROFILE_RT
+ * counters of the reference (aabb_hit_count/8 and tri_hit_count,
+ * src/rt_gpu/rt_gpu_software_query.hlsl:377-379,407-409), summed over rays. */
+typedef struct trx_stats {
+    uint64_t n_rays;
+    uint64_t n_node;
+    uint64_t n_tri;
+    uint64_t n_hits;
+    uint32_t max_stack;
+    uint32_t overflow; /* number of rays that overflowed the stack */
+    float kernel_ms;   /* hipEvent time of the traversal kernel(s) of this call */
+    float _pad;
+} trx_stats;
+
+typedef struct trx_scene trx_scene; /* opaque: device-resident nodes/tris/instances */
+
+/* ---- errors / device ------------------------------------------------------ */
+
+const char *trx_last_error(void);
+uint32_t trx_abi_version(void);
+/* Number of HIP devices visible (0 when none; never fails). */
+int trx_device_count(void);
+/* gcnArchName of a device into buf (e.g. "gfx950:sramecc+:xnack-"). */
+int trx_device_name(int device, char *buf, size_t buf_len);
+
+/* ---- scene upload ---------------------------------------------------------
+ * Replaces the buffer upload half of rt_gpu_software::start
+ * (src/rt_gpu/rt_gpu_software.rs:24-32 signature; :83-160 buffer creation),
+ * fed by cwbvh_gpu_runner (src/rt_gpu/mod.rs:92-100 TLAS, :108-110 BLAS-only).
+ *
+ *  bvh_bytes        n_nodes * 80 bytes; all BLAS concatenated, TLAS last
+ *  tri_bytes        n_tris * trx_tri_format_bytes(tri_format), in
+ *                   primitive_indices order, primitive_base_idx pre-offset
+ *  instance_offsets u32 BLAS node offset per TLAS primitive, or NULL / 0 when
+ *                   there is no TLAS (the reference passes 16 zero bytes)
+ *  tlas_start       node index of the TLAS root (0 and n_instances == 0 = BLAS only)
+ *  device           HIP device ordinal
+ * The inputs are copied; the caller keeps ownership. */
+int trx_scene_create(const void *bvh_bytes, uint64_t n_nodes,
+                     const void *tri_bytes, uint64_t n_tris, uint32_t tri_format,
+                     const uint32_t *instance_offsets, uint32_t n_instances,
+                     uint32_t tlas_start, int device, trx_scene **out);
+void trx_scene_destroy(trx_scene *scene);
+/* Bytes resident in HBM for this scene (nodes + 48-byte triangles + instances). */
+uint64_t trx_scene_device_bytes(const trx_scene *scene);
+int trx_scene_device(const trx_scene *scene);
+
+/* Optional: first triangle of each BLAS in the global triangle buffer
+ * (n_blas + 1 entries, trx_flat.blas_tri_start) so trx_traverse1 can report
+ * (geometry_id, local primitive_id) like the reference's CPU TLAS path
+ * (src/cwbvh.rs:151-160). */
+int trx_scene_set_geometry_ranges(trx_scene *scene, const uint32_t *blas_tri_start, uint32_t n_blas);
+
+/* ---- camera ---------------------------------------------------------------
+ * ViewUniform::from_camera (src/main.rs:602-616): proj_inv =
+ * inverse(perspective_infinite_reverse_rh(fov_deg->rad, w/h, 0.01)),
+ * view_inv = inverse(look_at_rh(eye, look_at, +Y)). */
+int trx_view_from_camera(const float eye[3], const float look_at[3], float fov_deg,
+                         float width, float height, trx_view *out);
+
+/* ---- tracing: device-resident outputs --------------------------------------
+ * `stream` is a hipStream_t (NULL = the null stream).  d_* pointers are device
+ * memory on the scene's device.  These calls only enqueue work.
+ *
+ * trx_trace_primary_dev replaces the timed dispatch of the reference
+ * (src/rt_gpu/rt_gpu_software.rs:289-302) restricted to the primary ray of
+ * src/rt_gpu/rt_gpu_software.hlsl:69-89: ray-gen in-kernel, closest hit,
+ * one trx_hit per pixel at d_hits[y*w + x]. */
+int trx_trace_primary_dev(trx_scene *scene, const trx_view *view, uint32_t width,
+                          uint32_t height, trx_shard shard, uint32_t semantics,
+                          trx_hit *d_hits, void *stream);
+
+/* AO pass of src/rt_gpu/rt_gpu_software.hlsl:105-128 / src/rt_cpu/rt_cpu.rs:61-80:
+ * for every pixel whose d_primary hit is valid, build the AO ray (normal from
+ * the hit triangle flipped toward the viewer, origin = eye + d*t - d*ao_eps,
+ * cosine-hemisphere direction from hash_noise(px, frame) /
+ * hash_noise(px, frame + 1024)) and trace it (closest hit).  Pixels whose
+ * primary ray missed get a miss record.  ao_eps: 0.0001 (GPU) / 0.01 (CPU). */
+int trx_trace_ao_dev(trx_scene *scene, const trx_view *view, uint32_t width,
+                     uint32_t height, trx_shard shard, uint32_t semantics, uint32_t frame,
+                     float ao_eps, const trx_hit *d_primary, trx_hit *d_ao, void *stream);
+
+/* Batch form of Traversable::traverse (traversable/src/lib.rs:13-28):
+ * n explicit rays -> n hits. */
+int trx_trace_rays_dev(trx_scene *scene, const trx_ray *d_rays, uint64_t n_rays,
+                       uint32_t semantics, trx_hit *d_hits, void *stream);
+
+/* Counting variant (PROFILE_RT): same traversal, also accumulates trx_stats.
+ * Synchronous; d_hits may be NULL. */
+int trx_count_primary(trx_scene *scene, const trx_view *view, uint32_t width,
+                      uint32_t height, trx_shard shard, uint32_t semantics,
+                      trx_hit *d_hits, trx_stats *stats);
+int trx_count_rays(trx_scene *scene, const trx_ray *d_rays, uint64_t n_rays,
+                   uint32_t semantics, trx_hit *d_hits, trx_stats *stats);
+
+/* Status of the most recent trace on this scene (stack overflow is detected
+ * in-kernel and latched in device memory).  Synchronises `stream`. */
+int trx_scene_check(trx_scene *scene, void *stream);
+
+/* ---- tracing: host-buffer convenience (synchronous) --------------------------
+ * What rt_gpu_software::start returns to its caller is a time in ms
+ * (src/rt_gpu/rt_gpu_software.rs:376); out_ms is the hipEvent time of the
+ * kernel(s) (src/timestamp.rs:62-74 equivalent).  out_hits: w*h (or n) host
+ * records, may be NULL for timing only. */
+int trx_trace_primary(trx_scene *scene, const trx_view *view, uint32_t width,
+                      uint32_t height, uint32_t semantics, trx_hit *out_hits,
+                      float *out_ms);
+int trx_trace_primary_ao(trx_scene *scene, const trx_view *view, uint32_t width,
+                         uint32_t height, uint32_t semantics, uint32_t frame, float ao_eps,
+                         trx_hit *out_primary, trx_hit *out_ao, float *out_ms);
+int trx_trace_rays(trx_scene *scene, const trx_ray *rays, uint64_t n_rays,
+                   uint32_t semantics, trx_hit *out_hits, float *out_ms);
+/* Single-ray Traversable::traverse; a batch of one on the device. */
+int trx_traverse1(trx_scene *scene, const trx_ray *ray, uint32_t semantics,
+                  trx_rayhit *out);
+
+/* Benchmark loop of the reference (warm-up dispatch + timestamp pair per
+ * frame, min and mean over frames: src/rt_gpu/rt_gpu_software.rs:289-302,
+ * 339-344,376).  Traces `frames` primary frames after `warmup` untimed ones
+ * into an internal device buffer; returns min / mean kernel ms. */
+int trx_bench_primary(trx_scene *scene, const trx_view *view, uint32_t width,
+                      uint32_t height, uint32_t semantics, uint32_t warmup,
+                      uint32_t frames, float *out_min_ms, float *out_mean_ms);
+
+/* Kernel variant selection (tuning aid; 0 = default).  Returns the previous
+ * value.  Variants compute identical results. */
+uint32_t trx_set_kernel_variant(uint32_t variant);
+
+/* ---- host side: CWBVH construction (CPU) -------------------------------------
+ * Stands in for obvhs build_cwbvh_from_tris / build_cwbvh (called at
+ * src/cwbvh.rs:97,132), which the Rust host keeps doing in a real
+ * integration.  Node encoding follows embree/src/bvh_embree_to_cwbvh.rs:85-186
+ * and child ordering embree/src/bvh_embree.rs:284-349. */
+typedef struct trx_bvh trx_bvh; /* opaque CwBvh {nodes, primitive_indices, total_aabb} */
+
+/* verts: n_tris * 9 floats (v0,v1,v2).  max_prims_per_leaf 1..3
+ * (src/main.rs:176-178).  threads <= 0: all cores. */
+int trx_bvh_build_tris(const float *verts, uint64_t n_tris, uint32_t max_prims_per_leaf,
+                       int threads, trx_bvh **out);
+/* aabbs: n * 6 floats (min xyz, max xyz) — the TLAS build over BLAS AABBs
+ * (src/cwbvh.rs:114,132). */
+int trx_bvh_build_aabbs(const float *aabbs, uint64_t n, uint32_t max_prims_per_leaf,
+                        int threads, trx_bvh **out);
+void trx_bvh_destroy(trx_bvh *bvh);
+uint64_t trx_bvh_node_count(const trx_bvh *bvh);
+uint64_t trx_bvh_prim_count(const trx_bvh *bvh);
+const void *trx_bvh_nodes(const trx_bvh *bvh);                 /* node_count * 80 B */
+const uint32_t *trx_bvh_primitive_indices(const trx_bvh *bvh); /* prim_count u32     */
+void trx_bvh_total_aabb(const trx_bvh *bvh, float out6[6]);
+double trx_bvh_build_seconds(const trx_bvh *bvh);
+
+/* cwbvh_gpu_runner (src/rt_gpu/mod.rs:16-112) as one call: builds one BLAS per
+ * object (or one flattened BLAS when use_tlas == 0, src/main.rs:300-308),
+ * permutes triangles into primitive_indices order, offsets primitive_base_idx,
+ * optionally builds the TLAS and concatenates, and returns the flat buffers
+ * the GPU path consumes.  Output arrays are owned by the trx_flat and freed
+ * with trx_flat_destroy. */
+typedef struct trx_flat {
+    void *bvh_bytes;
+    uint64_t n_nodes;
+    float *tri_verts;        /* n_tris * 9 floats, TRX_TRI_VERTS_36, permuted */
+    uint64_t n_tris;
+    uint32_t *instance_offsets;
+    uint32_t n_instances;
+    uint32_t tlas_start;
+    uint32_t *tri_source;    /* n_tris: index of each permuted triangle in the input */
+    uint32_t *blas_tri_start;/* n_blas + 1: first permuted triangle of each BLAS (geometry_id lookup) */
+    uint32_t n_blas;
+    double blas_build_s;
+    double tlas_build_s;
+} trx_flat;
+int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects,
+                   int use_tlas, uint32_t max_prims_per_leaf, int threads, trx_flat **out);
+void trx_flat_destroy(trx_flat *flat);
+
+/* ---- host side: scenes ----------------------------------------------------
+ * The reference's assets are absent: seeded procedural
+ * stand-ins with the triangle counts of README.md:27-34.  name is one of
+ * "cornell" "demoscene" "kitchen" "bistro" "hairball" "san_miguel" "soup".
+ * Returns a malloc'd vertex array (n_tris*9 floats) and per-object triangle
+ * counts; free with trx_free. */
+int trx_gen_scene(const char *name, uint64_t n_tris_target, uint64_t seed, float **out_verts,
+                  uint64_t *out_n_tris, uint64_t **out_object_counts, uint32_t *out_n_objects);
+/* Camera of assets/scenes/<name>.ron (eye, look_at, fov) for the stand-in. */
+int trx_scene_camera(const char *name, float eye[3], float look_at[3], float *fov_deg);
+/* load_meshs (src/main.rs:494-561): Wavefront OBJ (tri + quad fan, one object
+ * per `o`) or the JSON triangle list. */
+int trx_load_model(const char *path, float **out_verts, uint64_t *out_n_tris,
+                   uint64_t **out_object_counts, uint32_t *out_n_objects);
+void trx_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRX_H */

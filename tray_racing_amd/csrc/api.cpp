@@ -1,0 +1,939 @@
+// api.cpp — implementation of the C-ABI declared in include/trx.h.
+//
+// Host side of the HIP backend: scene upload (replaces the buffer creation of
+// src/rt_gpu/rt_gpu_software.rs:83-160), launch + hipEvent timing (replaces
+// the dispatch and src/timestamp.rs), and the flat-buffer assembly of
+// cwbvh_gpu_runner (src/rt_gpu/mod.rs:16-112).  There is deliberately no CPU
+// traversal in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/trx.h"
+#include "builder.h"
+#include "cwbvh_format.h"
+#include "kernels.h"
+#include "scenes.h"
+
+using namespace trx;
+
+namespace {
+
+thread_local std::string g_err;
+uint32_t g_variant = 0;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? TRX_ERR_OOM : TRX_ERR_NO_DEVICE,       \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                    \
+    } while (0)
+
+constexpr int kSlots = 4;
+
+struct Slot {
+    SlotCounters *ctr = nullptr;
+    uint2 *spill = nullptr;
+    hipEvent_t done = nullptr;
+    bool used = false;
+};
+
+} // namespace
+
+struct trx_scene {
+    int device = 0;
+    uint4 *d_nodes = nullptr;
+    float4 *d_tris = nullptr;
+    uint32_t *d_inst = nullptr;
+    uint64_t n_nodes = 0, n_tris = 0;
+    uint32_t n_inst = 0, tlas_start = 0;
+    bool tlas = false;
+    int grid = 0;
+    Slot slots[kSlots];
+    int next_slot = 0;
+    std::mutex mu;
+    // scratch for the host-buffer convenience entry points
+    trx_hit *d_scratch_a = nullptr, *d_scratch_b = nullptr;
+    trx_ray *d_scratch_rays = nullptr;
+    uint64_t scratch_hits = 0, scratch_rays = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<uint32_t> blas_tri_start; // geometry_id lookup for trx_traverse1
+};
+
+struct trx_bvh {
+    CwBvh bvh;
+};
+
+namespace {
+
+// Structural validation of untrusted node buffers: a kernel that walks a
+// malformed tree would read out of bounds (and can take the GPU down), so
+// every index the kernel can form is range-checked here once.
+int validate_nodes(const CwbvhNode *nodes, uint64_t n_nodes, uint64_t n_tris, const uint32_t *inst,
+                   uint32_t n_inst, uint32_t tlas_start) {
+    std::vector<uint32_t> seg; // BLAS segment starts, sorted
+    const bool tlas = n_inst > 0;
+    if (tlas) {
+        if (tlas_start >= n_nodes) return fail(TRX_ERR_FORMAT, "tlas_start %u >= n_nodes %llu", tlas_start, (unsigned long long)n_nodes);
+        seg.assign(inst, inst + n_inst);
+        for (uint32_t o : seg)
+            if (o >= tlas_start) return fail(TRX_ERR_FORMAT, "instance offset %u not below tlas_start %u", o, tlas_start);
+        std::sort(seg.begin(), seg.end());
+        seg.erase(std::unique(seg.begin(), seg.end()), seg.end());
+    }
+    for (uint64_t i = 0; i < n_nodes; i++) {
+        const CwbvhNode &n = nodes[i];
+        uint64_t seg_begin = 0, seg_end = n_nodes;
+        bool in_tlas = false;
+        if (tlas) {
+            if (i >= tlas_start) {
+                seg_begin = tlas_start;
+                in_tlas = true;
+            } else {
+                auto it = std::upper_bound(seg.begin(), seg.end(), (uint32_t)i);
+                seg_begin = it == seg.begin() ? 0 : *(it - 1);
+                seg_end = it == seg.end() ? tlas_start : *it;
+            }
+        }
+        uint32_t inner = 0, prims = 0;
+        for (int s = 0; s < 8; s++) {
+            uint8_t m = n.child_meta[s];
+            if (m == 0) continue;
+            if ((m & 0x18) == 0x18) {
+                inner++;
+            } else {
+                uint32_t bits = m >> 5, cnt = bits == 1 ? 1 : bits == 3 ? 2 : bits == 7 ? 3 : 0;
+                if (!cnt) return fail(TRX_ERR_FORMAT, "node %llu slot %d: bad leaf meta 0x%02x", (unsigned long long)i, s, m);
+                prims = std::max(prims, (uint32_t)(m & 0x1f) + cnt);
+            }
+        }
+        if (inner != (uint32_t)__builtin_popcount(n.imask))
+            return fail(TRX_ERR_FORMAT, "node %llu: imask 0x%02x disagrees with child_meta", (unsigned long long)i, n.imask);
+        if (inner && (uint64_t)n.child_base_idx + inner > seg_end - seg_begin)
+            return fail(TRX_ERR_FORMAT, "node %llu: children [%u,+%u) leave the BVH segment", (unsigned long long)i, n.child_base_idx, inner);
+        if (prims > 24) return fail(TRX_ERR_FORMAT, "node %llu: more than 24 primitives", (unsigned long long)i);
+        uint64_t limit = in_tlas ? n_inst : n_tris;
+        if (prims && (uint64_t)n.primitive_base_idx + prims > limit)
+            return fail(TRX_ERR_FORMAT, "node %llu: primitives [%u,+%u) out of range %llu", (unsigned long long)i,
+                        n.primitive_base_idx, prims, (unsigned long long)limit);
+    }
+    return TRX_OK;
+}
+
+float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1f, man = h & 0x3ffu, bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else {
+            float f = (float)man * 5.9604644775390625e-8f;
+            return sign ? -f : f;
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 112) << 23) | (man << 13);
+    }
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+// Any accepted input format -> 48-byte device record {v0, e1 = v0 - v1, e2 = v2 - v0}.
+void convert_tris(const void *src, uint64_t n, uint32_t fmt, TriDev *dst) {
+    const uint8_t *b = (const uint8_t *)src;
+    for (uint64_t i = 0; i < n; i++) {
+        TriDev t;
+        std::memset(&t, 0, sizeof(t));
+        if (fmt == TRX_TRI_F16_24) {
+            float v[3];
+            uint32_t e[3];
+            std::memcpy(v, b + 24 * i, 12);
+            std::memcpy(e, b + 24 * i + 12, 12);
+            for (int k = 0; k < 3; k++) {
+                t.v0[k] = v[k];
+                t.e1[k] = -half_to_float((uint16_t)(e[k] >> 16)); // stored e1 = v1 - v0
+                t.e2[k] = half_to_float((uint16_t)(e[k] & 0xffff));
+            }
+        } else {
+            float v[9];
+            std::memcpy(v, b + 36 * i, 36);
+            for (int k = 0; k < 3; k++) {
+                t.v0[k] = v[k];
+                if (fmt == TRX_TRI_VERTS_36) {
+                    t.e1[k] = v[k] - v[3 + k];
+                    t.e2[k] = v[6 + k] - v[k];
+                } else {
+                    t.e1[k] = v[3 + k];
+                    t.e2[k] = v[6 + k];
+                }
+            }
+        }
+        dst[i] = t;
+    }
+}
+
+int ensure_scratch(trx_scene *s, uint64_t hits, uint64_t rays) {
+    if (hits > s->scratch_hits) {
+        if (s->d_scratch_a) (void)hipFree(s->d_scratch_a);
+        if (s->d_scratch_b) (void)hipFree(s->d_scratch_b);
+        s->d_scratch_a = s->d_scratch_b = nullptr;
+        s->scratch_hits = 0;
+        HIP_TRY(hipMalloc(&s->d_scratch_a, hits * sizeof(trx_hit)));
+        HIP_TRY(hipMalloc(&s->d_scratch_b, hits * sizeof(trx_hit)));
+        s->scratch_hits = hits;
+    }
+    if (rays > s->scratch_rays) {
+        if (s->d_scratch_rays) (void)hipFree(s->d_scratch_rays);
+        s->d_scratch_rays = nullptr;
+        s->scratch_rays = 0;
+        HIP_TRY(hipMalloc(&s->d_scratch_rays, rays * sizeof(trx_ray)));
+        s->scratch_rays = rays;
+    }
+    return TRX_OK;
+}
+
+void fill_view(const trx_view *v, ViewDev &out) {
+    std::memcpy(out.view_inv, v->view_inv, 64);
+    std::memcpy(out.proj_inv, v->proj_inv, 64);
+    std::memcpy(out.eye, v->eye, 12);
+    out.pad = 0.f;
+}
+
+// Enqueue one traversal kernel on a launch slot.  Slots make the scene
+// re-entrant (Traversable requires Sync, src/rt_cpu/rt_cpu.rs:17-20): a slot is
+// reused only after the stream has waited for its previous kernel.
+int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hipStream_t stream,
+            SlotCounters **ctr_out) {
+    if (sem & ~7u) return fail(TRX_ERR_INVALID, "unknown semantics bits 0x%x", sem);
+    HIP_TRY(hipSetDevice(s->device));
+    std::lock_guard<std::mutex> lock(s->mu);
+    Slot &slot = s->slots[s->next_slot];
+    s->next_slot = (s->next_slot + 1) % kSlots;
+    if (!slot.ctr) {
+        HIP_TRY(hipMalloc(&slot.ctr, sizeof(SlotCounters)));
+        HIP_TRY(hipMemset(slot.ctr, 0, sizeof(SlotCounters)));
+        HIP_TRY(hipMalloc(&slot.spill, (size_t)s->grid * kSpillStack * kWave * sizeof(uint2)));
+        HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    }
+    if (slot.used) HIP_TRY(hipStreamWaitEvent(stream, slot.done, 0));
+    p.nodes = s->d_nodes;
+    p.tris = s->d_tris;
+    p.inst = s->d_inst;
+    p.tlas_start = s->tlas_start;
+    p.ctr = slot.ctr;
+    p.spill = slot.spill;
+    p.tie_first = (sem & TRX_SEM_TIE_FIRST) ? 1u : 0u;
+    uint32_t refill = g_variant & 0x7fu;
+    p.refill_idle = refill ? std::min(refill, 64u) : 64u;
+    p.variant = g_variant;
+    HIP_TRY(launch_trace(p, mode, s->tlas, sem, count, s->grid, stream));
+    HIP_TRY(hipEventRecord(slot.done, stream));
+    slot.used = true;
+    if (ctr_out) *ctr_out = slot.ctr;
+    return TRX_OK;
+}
+
+int image_params(TraceParams &p, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard) {
+    if (!view) return fail(TRX_ERR_INVALID, "view is null");
+    if (w == 0 || h == 0) return fail(TRX_ERR_INVALID, "empty image %ux%u", w, h);
+    if ((uint64_t)w * h > 0x7fffffffull) return fail(TRX_ERR_INVALID, "image %ux%u too large", w, h);
+    if (shard.count == 0) shard.count = 1;
+    if (shard.index >= shard.count) return fail(TRX_ERR_INVALID, "shard %u of %u", shard.index, shard.count);
+    const uint32_t tx = (w + 7) / 8, ty = (h + 7) / 8;
+    const uint64_t tiles = (uint64_t)tx * ty;
+    const uint64_t local = tiles > shard.index ? (tiles - shard.index + shard.count - 1) / shard.count : 0;
+    p.width = w;
+    p.height = h;
+    p.tiles_x = tx;
+    p.shard_index = shard.index;
+    p.shard_count = shard.count;
+    p.n_items = (uint32_t)(local * 64);
+    fill_view(view, p.view);
+    return TRX_OK;
+}
+
+int read_overflow(trx_scene *s, SlotCounters *ctr) {
+    unsigned int over = 0;
+    HIP_TRY(hipMemcpy(&over, &ctr->overflow, sizeof(over), hipMemcpyDeviceToHost));
+    if (over) {
+        HIP_TRY(hipMemset(&ctr->overflow, 0, sizeof(over)));
+        return fail(TRX_ERR_STACK_OVERFLOW, "%u rays overflowed the %d-entry traversal stack (or the step cap)", over,
+                    kLdsStack + kSpillStack);
+    }
+    (void)s;
+    return TRX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *trx_last_error(void) { return g_err.c_str(); }
+uint32_t trx_abi_version(void) { return TRX_ABI_VERSION; }
+
+int trx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int trx_device_name(int device, char *buf, size_t buf_len) {
+    if (!buf || !buf_len) return fail(TRX_ERR_INVALID, "null buffer");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buf_len, "%s", prop.gcnArchName);
+    return TRX_OK;
+}
+
+uint32_t trx_tri_format_bytes(uint32_t f) {
+    switch (f) {
+    case TRX_TRI_F16_24: return 24;
+    case TRX_TRI_VERTS_36: return 36;
+    case TRX_TRI_EDGES_36: return 36;
+    default: return 0;
+    }
+}
+
+uint32_t trx_set_kernel_variant(uint32_t variant) {
+    uint32_t old = g_variant;
+    g_variant = variant;
+    return old;
+}
+
+int trx_scene_create(const void *bvh_bytes, uint64_t n_nodes, const void *tri_bytes, uint64_t n_tris,
+                     uint32_t tri_format, const uint32_t *instance_offsets, uint32_t n_instances,
+                     uint32_t tlas_start, int device, trx_scene **out) {
+    if (!out) return fail(TRX_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!bvh_bytes || n_nodes == 0) return fail(TRX_ERR_INVALID, "empty node buffer");
+    if (n_tris && !tri_bytes) return fail(TRX_ERR_INVALID, "tri_bytes is null");
+    if (!trx_tri_format_bytes(tri_format)) return fail(TRX_ERR_INVALID, "unknown tri_format %u", tri_format);
+    if (n_nodes >= 0xffffffffull || n_tris >= 0xffffffffull) return fail(TRX_ERR_INVALID, "buffer too large for u32 indices");
+    if (n_instances && !instance_offsets) return fail(TRX_ERR_INVALID, "instance_offsets is null");
+    if (!n_instances && tlas_start != 0) return fail(TRX_ERR_INVALID, "tlas_start without instances");
+    int rc = validate_nodes((const CwbvhNode *)bvh_bytes, n_nodes, n_tris, instance_offsets, n_instances, tlas_start);
+    if (rc) return rc;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(TRX_ERR_NO_DEVICE, "no HIP device (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(TRX_ERR_INVALID, "device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    trx_scene *s = new (std::nothrow) trx_scene();
+    if (!s) return fail(TRX_ERR_OOM, "host allocation failed");
+    s->device = device;
+    s->n_nodes = n_nodes;
+    s->n_tris = n_tris;
+    s->n_inst = n_instances;
+    s->tlas_start = tlas_start;
+    s->tlas = n_instances > 0;
+
+    std::vector<TriDev> tris(std::max<uint64_t>(n_tris, 1));
+    convert_tris(tri_bytes, n_tris, tri_format, tris.data());
+
+    auto cleanup = [&](int code) {
+        trx_scene_destroy(s);
+        return code;
+    };
+#define HIP_TRY_S(expr)                                                                                      \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return cleanup(fail(e_ == hipErrorOutOfMemory ? TRX_ERR_OOM : TRX_ERR_NO_DEVICE, "%s failed: %s", \
+                                #expr, hipGetErrorString(e_)));                                              \
+    } while (0)
+    HIP_TRY_S(hipMalloc(&s->d_nodes, n_nodes * TRX_NODE_BYTES));
+    HIP_TRY_S(hipMemcpy(s->d_nodes, bvh_bytes, n_nodes * TRX_NODE_BYTES, hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_tris, tris.size() * sizeof(TriDev)));
+    HIP_TRY_S(hipMemcpy(s->d_tris, tris.data(), tris.size() * sizeof(TriDev), hipMemcpyHostToDevice));
+    uint32_t zero = 0;
+    HIP_TRY_S(hipMalloc(&s->d_inst, std::max<uint32_t>(n_instances, 4) * sizeof(uint32_t)));
+    HIP_TRY_S(hipMemcpy(s->d_inst, n_instances ? instance_offsets : &zero, (n_instances ? n_instances : 1) * sizeof(uint32_t),
+                        hipMemcpyHostToDevice));
+    HIP_TRY_S(hipEventCreate(&s->ev0));
+    HIP_TRY_S(hipEventCreate(&s->ev1));
+#undef HIP_TRY_S
+    s->grid = trace_grid_size(device, 0, s->tlas, 0, false);
+    if (s->grid <= 0) return cleanup(fail(TRX_ERR_NO_DEVICE, "could not size the persistent grid"));
+    *out = s;
+    return TRX_OK;
+}
+
+void trx_scene_destroy(trx_scene *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    if (s->d_nodes) (void)hipFree(s->d_nodes);
+    if (s->d_tris) (void)hipFree(s->d_tris);
+    if (s->d_inst) (void)hipFree(s->d_inst);
+    if (s->d_scratch_a) (void)hipFree(s->d_scratch_a);
+    if (s->d_scratch_b) (void)hipFree(s->d_scratch_b);
+    if (s->d_scratch_rays) (void)hipFree(s->d_scratch_rays);
+    for (Slot &sl : s->slots) {
+        if (sl.ctr) (void)hipFree(sl.ctr);
+        if (sl.spill) (void)hipFree(sl.spill);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+uint64_t trx_scene_device_bytes(const trx_scene *s) {
+    if (!s) return 0;
+    return s->n_nodes * TRX_NODE_BYTES + s->n_tris * sizeof(TriDev) + (uint64_t)s->n_inst * 4;
+}
+int trx_scene_device(const trx_scene *s) { return s ? s->device : -1; }
+
+int trx_scene_set_geometry_ranges(trx_scene *s, const uint32_t *blas_tri_start, uint32_t n_blas) {
+    if (!s || (!blas_tri_start && n_blas)) return fail(TRX_ERR_INVALID, "null argument");
+    s->blas_tri_start.assign(blas_tri_start, blas_tri_start + n_blas + (n_blas ? 1 : 0));
+    return TRX_OK;
+}
+
+// ---- camera: ViewUniform::from_camera, src/main.rs:602-616 -----------------------------
+static void mat4_inverse_f32(const float m[16], float out[16]) {
+    // cofactor expansion (same scheme as glam's Mat4::inverse), evaluated in f32
+    const float a00 = m[0], a01 = m[1], a02 = m[2], a03 = m[3], a10 = m[4], a11 = m[5], a12 = m[6], a13 = m[7];
+    const float a20 = m[8], a21 = m[9], a22 = m[10], a23 = m[11], a30 = m[12], a31 = m[13], a32 = m[14], a33 = m[15];
+    const float b00 = a00 * a11 - a01 * a10, b01 = a00 * a12 - a02 * a10, b02 = a00 * a13 - a03 * a10;
+    const float b03 = a01 * a12 - a02 * a11, b04 = a01 * a13 - a03 * a11, b05 = a02 * a13 - a03 * a12;
+    const float b06 = a20 * a31 - a21 * a30, b07 = a20 * a32 - a22 * a30, b08 = a20 * a33 - a23 * a30;
+    const float b09 = a21 * a32 - a22 * a31, b10 = a21 * a33 - a23 * a31, b11 = a22 * a33 - a23 * a32;
+    const float det = b00 * b11 - b01 * b10 + b02 * b09 + b03 * b08 - b04 * b07 + b05 * b06;
+    const float r = 1.0f / det;
+    out[0] = (a11 * b11 - a12 * b10 + a13 * b09) * r;
+    out[1] = (a02 * b10 - a01 * b11 - a03 * b09) * r;
+    out[2] = (a31 * b05 - a32 * b04 + a33 * b03) * r;
+    out[3] = (a22 * b04 - a21 * b05 - a23 * b03) * r;
+    out[4] = (a12 * b08 - a10 * b11 - a13 * b07) * r;
+    out[5] = (a00 * b11 - a02 * b08 + a03 * b07) * r;
+    out[6] = (a32 * b02 - a30 * b05 - a33 * b01) * r;
+    out[7] = (a20 * b05 - a22 * b02 + a23 * b01) * r;
+    out[8] = (a10 * b10 - a11 * b08 + a13 * b06) * r;
+    out[9] = (a01 * b08 - a00 * b10 - a03 * b06) * r;
+    out[10] = (a30 * b04 - a31 * b02 + a33 * b00) * r;
+    out[11] = (a21 * b02 - a20 * b04 - a23 * b00) * r;
+    out[12] = (a11 * b07 - a10 * b09 - a12 * b06) * r;
+    out[13] = (a00 * b09 - a01 * b07 + a02 * b06) * r;
+    out[14] = (a31 * b01 - a30 * b03 - a32 * b00) * r;
+    out[15] = (a20 * b03 - a21 * b01 + a22 * b00) * r;
+}
+
+int trx_view_from_camera(const float eye[3], const float look_at[3], float fov_deg, float width, float height,
+                         trx_view *out) {
+    if (!eye || !look_at || !out) return fail(TRX_ERR_INVALID, "null argument");
+    if (!(width > 0.f) || !(height > 0.f)) return fail(TRX_ERR_INVALID, "bad image size");
+    std::memset(out, 0, sizeof(*out));
+    const float aspect = width / height;
+    const float fov = fov_deg * (3.14159265358979323846f / 180.0f);
+    const float f = 1.0f / std::tan(0.5f * fov);
+    float proj[16] = {0};
+    proj[0] = f / aspect;
+    proj[5] = f;
+    proj[11] = -1.0f;
+    proj[14] = 0.01f;
+    mat4_inverse_f32(proj, out->proj_inv);
+    float fw[3] = {look_at[0] - eye[0], look_at[1] - eye[1], look_at[2] - eye[2]};
+    float fl = std::sqrt(fw[0] * fw[0] + fw[1] * fw[1] + fw[2] * fw[2]);
+    if (!(fl > 0.f)) return fail(TRX_ERR_INVALID, "eye == look_at");
+    for (float &x : fw) x /= fl;
+    // s = normalize(f x up), up = +Y
+    float s[3] = {fw[1] * 0.f - fw[2] * 1.f, fw[2] * 0.f - fw[0] * 0.f, fw[0] * 1.f - fw[1] * 0.f};
+    float sl = std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+    if (!(sl > 0.f)) return fail(TRX_ERR_INVALID, "view direction parallel to +Y");
+    for (float &x : s) x /= sl;
+    float u[3] = {s[1] * fw[2] - s[2] * fw[1], s[2] * fw[0] - s[0] * fw[2], s[0] * fw[1] - s[1] * fw[0]};
+    auto dot = [](const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    float view[16] = {s[0], u[0], -fw[0], 0, s[1], u[1], -fw[1], 0, s[2], u[2], -fw[2], 0,
+                      -dot(s, eye), -dot(u, eye), dot(fw, eye), 1};
+    mat4_inverse_f32(view, out->view_inv);
+    std::memcpy(out->eye, eye, 12);
+    return TRX_OK;
+}
+
+// ---- tracing: device-resident -----------------------------------------------------------
+
+int trx_trace_primary_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard,
+                          uint32_t sem, trx_hit *d_hits, void *stream) {
+    if (!s || !d_hits) return fail(TRX_ERR_INVALID, "null argument");
+    TraceParams p;
+    std::memset(&p, 0, sizeof(p));
+    int rc = image_params(p, view, w, h, shard);
+    if (rc) return rc;
+    p.out = d_hits;
+    if (p.n_items == 0) return TRX_OK;
+    return enqueue(s, p, kModePrimary, sem, false, (hipStream_t)stream, nullptr);
+}
+
+int trx_trace_ao_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,
+                     uint32_t frame, float ao_eps, const trx_hit *d_primary, trx_hit *d_ao, void *stream) {
+    if (!s || !d_primary || !d_ao) return fail(TRX_ERR_INVALID, "null argument");
+    TraceParams p;
+    std::memset(&p, 0, sizeof(p));
+    int rc = image_params(p, view, w, h, shard);
+    if (rc) return rc;
+    p.primary = d_primary;
+    p.out = d_ao;
+    p.frame = frame;
+    p.ao_eps = ao_eps;
+    if (p.n_items == 0) return TRX_OK;
+    return enqueue(s, p, kModeAo, sem, false, (hipStream_t)stream, nullptr);
+}
+
+static int trace_rays_impl(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, trx_hit *d_hits,
+                           hipStream_t stream, bool count, SlotCounters **ctr) {
+    // the work queue is 32-bit: split very large batches
+    const uint64_t chunk = 1ull << 30;
+    for (uint64_t off = 0; off < n; off += chunk) {
+        TraceParams p;
+        std::memset(&p, 0, sizeof(p));
+        p.rays = d_rays + off;
+        p.out = d_hits + off;
+        p.n_items = (uint32_t)std::min(chunk, n - off);
+        int rc = enqueue(s, p, kModeRays, sem, count, stream, ctr);
+        if (rc) return rc;
+    }
+    return TRX_OK;
+}
+
+int trx_trace_rays_dev(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, trx_hit *d_hits, void *stream) {
+    if (!s || (n && (!d_rays || !d_hits))) return fail(TRX_ERR_INVALID, "null argument");
+    if (n == 0) return TRX_OK;
+    return trace_rays_impl(s, d_rays, n, sem, d_hits, (hipStream_t)stream, false, nullptr);
+}
+
+static int finish_count(trx_scene *s, SlotCounters *ctr, trx_stats *stats) {
+    HIP_TRY(hipEventRecord(s->ev1, nullptr));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    SlotCounters c;
+    HIP_TRY(hipMemcpy(&c, ctr, sizeof(c), hipMemcpyDeviceToHost));
+    SlotCounters z = c;
+    z.n_rays = z.n_node = z.n_tri = z.n_hits = 0;
+    z.max_stack = 0;
+    z.overflow = 0;
+    HIP_TRY(hipMemcpy(ctr, &z, sizeof(z), hipMemcpyHostToDevice));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    if (stats) {
+        stats->n_rays = c.n_rays;
+        stats->n_node = c.n_node;
+        stats->n_tri = c.n_tri;
+        stats->n_hits = c.n_hits;
+        stats->max_stack = c.max_stack;
+        stats->overflow = c.overflow;
+        stats->kernel_ms = ms;
+        stats->_pad = 0.f;
+    }
+    if (c.overflow) return fail(TRX_ERR_STACK_OVERFLOW, "%u rays overflowed the traversal stack", c.overflow);
+    return TRX_OK;
+}
+
+int trx_count_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,
+                      trx_hit *d_hits, trx_stats *stats) {
+    if (!s) return fail(TRX_ERR_INVALID, "null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    TraceParams p;
+    std::memset(&p, 0, sizeof(p));
+    int rc = image_params(p, view, w, h, shard);
+    if (rc) return rc;
+    if (!d_hits) {
+        rc = ensure_scratch(s, (uint64_t)w * h, 0);
+        if (rc) return rc;
+        d_hits = s->d_scratch_a;
+    }
+    p.out = d_hits;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipEventRecord(s->ev0, nullptr));
+    SlotCounters *ctr = nullptr;
+    rc = enqueue(s, p, kModePrimary, sem, true, nullptr, &ctr);
+    if (rc) return rc;
+    return finish_count(s, ctr, stats);
+}
+
+int trx_count_rays(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, trx_hit *d_hits, trx_stats *stats) {
+    if (!s || !d_rays || n == 0 || n > (1ull << 30)) return fail(TRX_ERR_INVALID, "bad ray batch");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!d_hits) {
+        int rc = ensure_scratch(s, n, 0);
+        if (rc) return rc;
+        d_hits = s->d_scratch_a;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipEventRecord(s->ev0, nullptr));
+    SlotCounters *ctr = nullptr;
+    int rc = trace_rays_impl(s, d_rays, n, sem, d_hits, nullptr, true, &ctr);
+    if (rc) return rc;
+    return finish_count(s, ctr, stats);
+}
+
+int trx_scene_check(trx_scene *s, void *stream) {
+    if (!s) return fail(TRX_ERR_INVALID, "null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (Slot &sl : s->slots) {
+        if (!sl.ctr) continue;
+        int rc = read_overflow(s, sl.ctr);
+        if (rc) return rc;
+    }
+    return TRX_OK;
+}
+
+// ---- tracing: host buffers ------------------------------------------------------------------
+
+int trx_trace_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, trx_hit *out_hits,
+                      float *out_ms) {
+    if (!s) return fail(TRX_ERR_INVALID, "null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = ensure_scratch(s, (uint64_t)w * h, 0);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s->ev0, nullptr));
+    rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1}, sem, s->d_scratch_a, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s->ev1, nullptr));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    if (out_ms) HIP_TRY(hipEventElapsedTime(out_ms, s->ev0, s->ev1));
+    if (out_hits) HIP_TRY(hipMemcpy(out_hits, s->d_scratch_a, (uint64_t)w * h * sizeof(trx_hit), hipMemcpyDeviceToHost));
+    return trx_scene_check(s, nullptr);
+}
+
+int trx_trace_primary_ao(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint32_t frame,
+                         float ao_eps, trx_hit *out_primary, trx_hit *out_ao, float *out_ms) {
+    if (!s) return fail(TRX_ERR_INVALID, "null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = ensure_scratch(s, (uint64_t)w * h, 0);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s->ev0, nullptr));
+    rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1}, sem, s->d_scratch_a, nullptr);
+    if (rc) return rc;
+    rc = trx_trace_ao_dev(s, view, w, h, trx_shard{0, 1}, sem, frame, ao_eps, s->d_scratch_a, s->d_scratch_b, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s->ev1, nullptr));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    if (out_ms) HIP_TRY(hipEventElapsedTime(out_ms, s->ev0, s->ev1));
+    const uint64_t bytes = (uint64_t)w * h * sizeof(trx_hit);
+    if (out_primary) HIP_TRY(hipMemcpy(out_primary, s->d_scratch_a, bytes, hipMemcpyDeviceToHost));
+    if (out_ao) HIP_TRY(hipMemcpy(out_ao, s->d_scratch_b, bytes, hipMemcpyDeviceToHost));
+    return trx_scene_check(s, nullptr);
+}
+
+int trx_trace_rays(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t sem, trx_hit *out_hits, float *out_ms) {
+    if (!s || (n && !rays)) return fail(TRX_ERR_INVALID, "null argument");
+    if (n == 0) return TRX_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = ensure_scratch(s, n, n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(s->d_scratch_rays, rays, n * sizeof(trx_ray), hipMemcpyHostToDevice));
+    HIP_TRY(hipEventRecord(s->ev0, nullptr));
+    rc = trx_trace_rays_dev(s, s->d_scratch_rays, n, sem, s->d_scratch_a, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s->ev1, nullptr));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    if (out_ms) HIP_TRY(hipEventElapsedTime(out_ms, s->ev0, s->ev1));
+    if (out_hits) HIP_TRY(hipMemcpy(out_hits, s->d_scratch_a, n * sizeof(trx_hit), hipMemcpyDeviceToHost));
+    return trx_scene_check(s, nullptr);
+}
+
+int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *out) {
+    if (!s || !ray || !out) return fail(TRX_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    // private buffers so concurrent callers do not share scratch (Traversable: Sync)
+    trx_ray *d_ray = nullptr;
+    trx_hit *d_hit = nullptr;
+    HIP_TRY(hipMalloc(&d_ray, sizeof(trx_ray)));
+    hipError_t e = hipMalloc(&d_hit, sizeof(trx_hit));
+    if (e != hipSuccess) {
+        (void)hipFree(d_ray);
+        return fail(TRX_ERR_OOM, "hipMalloc failed");
+    }
+    hipStream_t st = nullptr;
+    trx_hit h{};
+    int rc = TRX_OK;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "stream create failed");
+    if (!rc && hipMemcpyAsync(d_ray, ray, sizeof(trx_ray), hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "copy failed");
+    if (!rc) rc = trace_rays_impl(s, d_ray, 1, sem, d_hit, st, false, nullptr);
+    if (!rc && hipMemcpyAsync(&h, d_hit, sizeof(trx_hit), hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "copy failed");
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "sync failed");
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(d_ray);
+    (void)hipFree(d_hit);
+    if (rc) return rc;
+    out->t = h.t;
+    out->instance_id = 0xFFFFFFFFu;
+    if (h.prim == 0xFFFFFFFFu) { // RayHit::none()
+        out->primitive_id = out->geometry_id = 0xFFFFFFFFu;
+        return TRX_OK;
+    }
+    out->primitive_id = h.prim;
+    out->geometry_id = 0;
+    if (s->blas_tri_start.size() > 1) { // (geometry_id, local primitive_id) like src/cwbvh.rs:151-160
+        auto it = std::upper_bound(s->blas_tri_start.begin(), s->blas_tri_start.end(), h.prim);
+        uint32_t g = (uint32_t)(it - s->blas_tri_start.begin()) - 1;
+        out->geometry_id = g;
+        out->primitive_id = h.prim - s->blas_tri_start[g];
+        out->instance_id = g;
+    }
+    return TRX_OK;
+}
+
+int trx_bench_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint32_t warmup,
+                      uint32_t frames, float *out_min_ms, float *out_mean_ms) {
+    if (!s || frames == 0) return fail(TRX_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = ensure_scratch(s, (uint64_t)w * h, 0);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < warmup; i++) {
+        rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1}, sem, s->d_scratch_a, nullptr);
+        if (rc) return rc;
+    }
+    float mn = 1e30f;
+    double sum = 0.0;
+    for (uint32_t i = 0; i < frames; i++) {
+        HIP_TRY(hipEventRecord(s->ev0, nullptr));
+        rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1}, sem, s->d_scratch_a, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(s->ev1, nullptr));
+        HIP_TRY(hipEventSynchronize(s->ev1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        mn = std::min(mn, ms);
+        sum += ms;
+    }
+    if (out_min_ms) *out_min_ms = mn;
+    if (out_mean_ms) *out_mean_ms = (float)(sum / frames);
+    return trx_scene_check(s, nullptr);
+}
+
+// ---- host side: builder ----------------------------------------------------------------------
+
+int trx_bvh_build_tris(const float *verts, uint64_t n, uint32_t max_prims, int threads, trx_bvh **out) {
+    if (!out || (n && !verts)) return fail(TRX_ERR_INVALID, "null argument");
+    if (max_prims < 1 || max_prims > 3)
+        return fail(TRX_ERR_INVALID, "CWBVH only supports a maximum of 3 primitives per leaf."); // src/main.rs:176-178
+    if (n >= 0x7fffffffull) return fail(TRX_ERR_INVALID, "too many primitives");
+    trx_bvh *b = new (std::nothrow) trx_bvh();
+    if (!b) return fail(TRX_ERR_OOM, "host allocation failed");
+    BuildParams bp;
+    bp.max_prims_per_leaf = max_prims;
+    bp.threads = threads;
+    try {
+        build_cwbvh_from_tris(verts, n, bp, b->bvh);
+    } catch (const std::bad_alloc &) {
+        delete b;
+        return fail(TRX_ERR_OOM, "out of memory building the BVH");
+    }
+    *out = b;
+    return TRX_OK;
+}
+
+int trx_bvh_build_aabbs(const float *aabbs, uint64_t n, uint32_t max_prims, int threads, trx_bvh **out) {
+    if (!out || (n && !aabbs)) return fail(TRX_ERR_INVALID, "null argument");
+    if (max_prims < 1 || max_prims > 3) return fail(TRX_ERR_INVALID, "CWBVH only supports a maximum of 3 primitives per leaf.");
+    if (n >= 0x7fffffffull) return fail(TRX_ERR_INVALID, "too many primitives");
+    trx_bvh *b = new (std::nothrow) trx_bvh();
+    if (!b) return fail(TRX_ERR_OOM, "host allocation failed");
+    BuildParams bp;
+    bp.max_prims_per_leaf = max_prims;
+    bp.threads = threads;
+    try {
+        build_cwbvh_from_aabbs((const Aabb *)aabbs, n, bp, b->bvh);
+    } catch (const std::bad_alloc &) {
+        delete b;
+        return fail(TRX_ERR_OOM, "out of memory building the BVH");
+    }
+    *out = b;
+    return TRX_OK;
+}
+
+void trx_bvh_destroy(trx_bvh *b) { delete b; }
+uint64_t trx_bvh_node_count(const trx_bvh *b) { return b ? b->bvh.nodes.size() : 0; }
+uint64_t trx_bvh_prim_count(const trx_bvh *b) { return b ? b->bvh.primitive_indices.size() : 0; }
+const void *trx_bvh_nodes(const trx_bvh *b) { return b ? b->bvh.nodes.data() : nullptr; }
+const uint32_t *trx_bvh_primitive_indices(const trx_bvh *b) { return b ? b->bvh.primitive_indices.data() : nullptr; }
+void trx_bvh_total_aabb(const trx_bvh *b, float out6[6]) {
+    if (!b || !out6) return;
+    std::memcpy(out6, b->bvh.total_aabb.mn, 12);
+    std::memcpy(out6 + 3, b->bvh.total_aabb.mx, 12);
+}
+double trx_bvh_build_seconds(const trx_bvh *b) { return b ? b->bvh.build_seconds : 0.0; }
+
+// cwbvh_gpu_runner, src/rt_gpu/mod.rs:16-112
+int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects, int use_tlas,
+                   uint32_t max_prims, int threads, trx_flat **out) {
+    if (!out || !object_tri_counts || n_objects == 0) return fail(TRX_ERR_INVALID, "null argument");
+    if (max_prims < 1 || max_prims > 3) return fail(TRX_ERR_INVALID, "CWBVH only supports a maximum of 3 primitives per leaf.");
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_objects; i++) total += object_tri_counts[i];
+    if (total && !verts) return fail(TRX_ERR_INVALID, "verts is null");
+    if (total >= 0x7fffffffull) return fail(TRX_ERR_INVALID, "too many triangles");
+    BuildParams bp;
+    bp.max_prims_per_leaf = max_prims;
+    bp.threads = threads;
+    try {
+        // without --tlas everything is flattened into the first object (src/main.rs:300-308)
+        std::vector<uint64_t> counts;
+        if (use_tlas) {
+            for (uint32_t i = 0; i < n_objects; i++)
+                if (object_tri_counts[i]) counts.push_back(object_tri_counts[i]);
+            if (counts.empty()) counts.push_back(0);
+        } else {
+            counts.push_back(total);
+        }
+        std::vector<CwbvhNode> nodes;
+        std::vector<uint32_t> blas_offset, blas_tri_start, tri_source;
+        std::vector<Aabb> blas_aabb;
+        std::vector<float> tri_out;
+        tri_out.reserve(total * 9);
+        tri_source.reserve(total);
+        double blas_s = 0.0, tlas_s = 0.0;
+        uint64_t first = 0;
+        for (uint64_t cnt : counts) {
+            CwBvh bvh;
+            build_cwbvh_from_tris(verts + first * 9, cnt, bp, bvh);
+            blas_s += bvh.build_seconds;
+            const uint32_t tri_offset = (uint32_t)(tri_out.size() / 9);
+            blas_tri_start.push_back(tri_offset);
+            // permute triangles into primitive_indices order (mod.rs:38-43)
+            for (uint32_t pi : bvh.primitive_indices) {
+                const float *v = verts + (first + pi) * 9;
+                tri_out.insert(tri_out.end(), v, v + 9);
+                tri_source.push_back((uint32_t)(first + pi));
+            }
+            // global triangle buffer: offset primitive_base_idx (mod.rs:44-48)
+            for (CwbvhNode &n : bvh.nodes) n.primitive_base_idx += tri_offset;
+            blas_offset.push_back((uint32_t)nodes.size());
+            blas_aabb.push_back(bvh.total_aabb);
+            nodes.insert(nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
+            first += cnt;
+        }
+        blas_tri_start.push_back((uint32_t)(tri_out.size() / 9));
+        std::vector<uint32_t> inst;
+        uint32_t tlas_start = 0;
+        if (use_tlas) {
+            // TLAS over the BLAS boxes (src/cwbvh.rs:114,132); instance table in TLAS
+            // primitive order (mod.rs:72-78); TLAS nodes appended last (mod.rs:88-99)
+            CwBvh tlas;
+            build_cwbvh_from_aabbs(blas_aabb.data(), blas_aabb.size(), bp, tlas);
+            tlas_s = tlas.build_seconds;
+            for (uint32_t pi : tlas.primitive_indices) inst.push_back(blas_offset[pi]);
+            tlas_start = (uint32_t)nodes.size();
+            nodes.insert(nodes.end(), tlas.nodes.begin(), tlas.nodes.end());
+        }
+        trx_flat *f = (trx_flat *)std::calloc(1, sizeof(trx_flat));
+        if (!f) return fail(TRX_ERR_OOM, "host allocation failed");
+        auto dup = [](const void *src, size_t bytes) -> void * {
+            void *p = std::malloc(bytes ? bytes : 1);
+            if (p && bytes) std::memcpy(p, src, bytes);
+            return p;
+        };
+        f->n_nodes = nodes.size();
+        f->bvh_bytes = dup(nodes.data(), nodes.size() * sizeof(CwbvhNode));
+        f->n_tris = tri_out.size() / 9;
+        f->tri_verts = (float *)dup(tri_out.data(), tri_out.size() * 4);
+        f->n_instances = (uint32_t)inst.size();
+        f->instance_offsets = (uint32_t *)dup(inst.data(), inst.size() * 4);
+        f->tlas_start = tlas_start;
+        f->tri_source = (uint32_t *)dup(tri_source.data(), tri_source.size() * 4);
+        f->n_blas = (uint32_t)counts.size();
+        f->blas_tri_start = (uint32_t *)dup(blas_tri_start.data(), blas_tri_start.size() * 4);
+        f->blas_build_s = blas_s;
+        f->tlas_build_s = tlas_s;
+        if (!f->bvh_bytes || !f->tri_verts || !f->instance_offsets || !f->tri_source || !f->blas_tri_start) {
+            trx_flat_destroy(f);
+            return fail(TRX_ERR_OOM, "host allocation failed");
+        }
+        *out = f;
+    } catch (const std::bad_alloc &) {
+        return fail(TRX_ERR_OOM, "out of memory building the scene");
+    }
+    return TRX_OK;
+}
+
+void trx_flat_destroy(trx_flat *f) {
+    if (!f) return;
+    std::free(f->bvh_bytes);
+    std::free(f->tri_verts);
+    std::free(f->instance_offsets);
+    std::free(f->tri_source);
+    std::free(f->blas_tri_start);
+    std::free(f);
+}
+
+// ---- host side: scenes ---------------------------------------------------------------------------
+
+static int export_mesh(std::vector<float> &verts, std::vector<uint64_t> &objects, float **out_verts,
+                       uint64_t *out_n, uint64_t **out_counts, uint32_t *out_nobj) {
+    uint64_t n = verts.size() / 9;
+    float *v = (float *)std::malloc(std::max<size_t>(verts.size() * 4, 4));
+    uint64_t *c = (uint64_t *)std::malloc(std::max<size_t>(objects.size() * 8, 8));
+    if (!v || !c) {
+        std::free(v);
+        std::free(c);
+        return fail(TRX_ERR_OOM, "host allocation failed");
+    }
+    if (!verts.empty()) std::memcpy(v, verts.data(), verts.size() * 4);
+    if (!objects.empty()) std::memcpy(c, objects.data(), objects.size() * 8);
+    *out_verts = v;
+    *out_n = n;
+    if (out_counts) *out_counts = c;
+    else std::free(c);
+    if (out_nobj) *out_nobj = (uint32_t)objects.size();
+    return TRX_OK;
+}
+
+int trx_gen_scene(const char *name, uint64_t n_tris, uint64_t seed, float **out_verts, uint64_t *out_n,
+                  uint64_t **out_counts, uint32_t *out_nobj) {
+    if (!name || !out_verts || !out_n) return fail(TRX_ERR_INVALID, "null argument");
+    std::vector<float> verts;
+    std::vector<uint64_t> objects;
+    try {
+        if (!gen_scene(name, n_tris, seed, verts, objects)) return fail(TRX_ERR_INVALID, "unknown scene '%s'", name);
+    } catch (const std::bad_alloc &) {
+        return fail(TRX_ERR_OOM, "out of memory generating '%s'", name);
+    }
+    return export_mesh(verts, objects, out_verts, out_n, out_counts, out_nobj);
+}
+
+int trx_scene_camera(const char *name, float eye[3], float look_at[3], float *fov) {
+    if (!name || !eye || !look_at || !fov) return fail(TRX_ERR_INVALID, "null argument");
+    if (!scene_camera(name, eye, look_at, fov)) return fail(TRX_ERR_INVALID, "unknown scene '%s'", name);
+    return TRX_OK;
+}
+
+int trx_load_model(const char *path, float **out_verts, uint64_t *out_n, uint64_t **out_counts, uint32_t *out_nobj) {
+    if (!path || !out_verts || !out_n) return fail(TRX_ERR_INVALID, "null argument");
+    std::vector<float> verts;
+    std::vector<uint64_t> objects;
+    try {
+        if (!load_model(path, verts, objects)) return fail(TRX_ERR_IO, "Error while loading model file \"%s\"", path);
+    } catch (const std::bad_alloc &) {
+        return fail(TRX_ERR_OOM, "out of memory loading '%s'", path);
+    }
+    return export_mesh(verts, objects, out_verts, out_n, out_counts, out_nobj);
+}
+
+void trx_free(void *p) { std::free(p); }
+
+} // extern "C"

@@ -1,0 +1,513 @@
+// builder.cpp — CPU construction of the 80-byte CWBVH (see builder.h).
+#include "builder.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+
+namespace trx {
+namespace {
+
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
+inline Aabb empty_box() {
+    return Aabb{{kInf, kInf, kInf}, {-kInf, -kInf, -kInf}};
+}
+inline void grow(Aabb &a, const Aabb &b) {
+    for (int k = 0; k < 3; k++) {
+        a.mn[k] = std::min(a.mn[k], b.mn[k]);
+        a.mx[k] = std::max(a.mx[k], b.mx[k]);
+    }
+}
+inline void grow_pt(Aabb &a, const float *p) {
+    for (int k = 0; k < 3; k++) {
+        a.mn[k] = std::min(a.mn[k], p[k]);
+        a.mx[k] = std::max(a.mx[k], p[k]);
+    }
+}
+inline float half_area(const Aabb &b) {
+    float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+    if (!(dx >= 0.f) || !(dy >= 0.f) || !(dz >= 0.f)) return 0.f;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// ---- BVH2 ------------------------------------------------------------------
+// Nodes are laid out in DFS pre-order: a subtree over n primitives owns exactly
+// 2n-1 consecutive nodes, so the layout is independent of the thread schedule.
+struct Node2 {
+    Aabb box;
+    uint32_t left;  // inner: index of left child (== self + 1)
+    uint32_t right; // inner: index of right child
+    uint32_t prim;  // leaf: primitive id
+    uint32_t count; // primitives below this node (1 = leaf)
+};
+
+struct Task {
+    uint32_t node, begin, end;
+};
+
+struct Bvh2Builder {
+    const Aabb *boxes;
+    std::vector<float> cen; // 3 per primitive
+    std::vector<uint32_t> idx;
+    std::vector<Node2> nodes;
+
+    static constexpr int kBins = 16;
+
+    // Splits [begin,end) in place; returns the split position (begin < mid < end).
+    uint32_t split(uint32_t begin, uint32_t end, Aabb &bounds_out) {
+        Aabb bounds = empty_box(), cb = empty_box();
+        for (uint32_t i = begin; i < end; i++) {
+            uint32_t p = idx[i];
+            grow(bounds, boxes[p]);
+            grow_pt(cb, &cen[3 * (size_t)p]);
+        }
+        bounds_out = bounds;
+        uint32_t n = end - begin;
+        if (n == 2) return begin + 1;
+
+        float best_cost = kInf;
+        int best_axis = -1, best_bin = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            float lo = cb.mn[axis], hi = cb.mx[axis];
+            if (!(hi > lo)) continue;
+            float scale = (float)kBins / (hi - lo);
+            Aabb bb[kBins];
+            uint32_t bc[kBins];
+            for (int b = 0; b < kBins; b++) {
+                bb[b] = empty_box();
+                bc[b] = 0;
+            }
+            for (uint32_t i = begin; i < end; i++) {
+                uint32_t p = idx[i];
+                int b = (int)((cen[3 * (size_t)p + axis] - lo) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                grow(bb[b], boxes[p]);
+                bc[b]++;
+            }
+            float right_area[kBins];
+            uint32_t right_cnt[kBins];
+            Aabb acc = empty_box();
+            uint32_t cnt = 0;
+            for (int b = kBins - 1; b > 0; b--) {
+                grow(acc, bb[b]);
+                cnt += bc[b];
+                right_area[b] = half_area(acc);
+                right_cnt[b] = cnt;
+            }
+            acc = empty_box();
+            cnt = 0;
+            for (int b = 0; b < kBins - 1; b++) {
+                grow(acc, bb[b]);
+                cnt += bc[b];
+                if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                float cost = half_area(acc) * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_bin = b;
+                }
+            }
+        }
+        uint32_t mid = begin;
+        if (best_axis >= 0) {
+            float lo = cb.mn[best_axis], hi = cb.mx[best_axis];
+            float scale = (float)kBins / (hi - lo);
+            auto it = std::partition(idx.begin() + begin, idx.begin() + end, [&](uint32_t p) {
+                int b = (int)((cen[3 * (size_t)p + best_axis] - lo) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b <= best_bin;
+            });
+            mid = (uint32_t)(it - idx.begin());
+        }
+        if (mid == begin || mid == end) {
+            // all centroids coincide (or binning degenerated): median split on
+            // the widest axis of the box, ties broken by primitive id.
+            int axis = 0;
+            float ext[3] = {bounds.mx[0] - bounds.mn[0], bounds.mx[1] - bounds.mn[1],
+                            bounds.mx[2] - bounds.mn[2]};
+            if (ext[1] > ext[axis]) axis = 1;
+            if (ext[2] > ext[axis]) axis = 2;
+            mid = begin + n / 2;
+            std::nth_element(idx.begin() + begin, idx.begin() + mid, idx.begin() + end,
+                             [&](uint32_t a, uint32_t b) {
+                                 float ca = cen[3 * (size_t)a + axis], cb2 = cen[3 * (size_t)b + axis];
+                                 return ca < cb2 || (ca == cb2 && a < b);
+                             });
+        }
+        return mid;
+    }
+
+    // Builds one node; returns child tasks through l / r (false for a leaf).
+    bool build_node(const Task &t, Task &l, Task &r) {
+        Node2 &nd = nodes[t.node];
+        uint32_t n = t.end - t.begin;
+        nd.count = n;
+        if (n == 1) {
+            uint32_t p = idx[t.begin];
+            nd.box = boxes[p];
+            nd.left = nd.right = 0;
+            nd.prim = p;
+            return false;
+        }
+        uint32_t mid = split(t.begin, t.end, nd.box);
+        uint32_t nl = mid - t.begin;
+        nd.left = t.node + 1;
+        nd.right = t.node + 2 * nl;
+        nd.prim = 0;
+        l = Task{nd.left, t.begin, mid};
+        r = Task{nd.right, mid, t.end};
+        return true;
+    }
+
+    void build_subtree(Task root) {
+        std::vector<Task> stack;
+        stack.push_back(root);
+        while (!stack.empty()) {
+            Task t = stack.back();
+            stack.pop_back();
+            Task l, r;
+            if (build_node(t, l, r)) {
+                stack.push_back(r);
+                stack.push_back(l);
+            }
+        }
+    }
+
+    void run(uint32_t n, int threads) {
+        nodes.resize(2 * (size_t)n - 1);
+        idx.resize(n);
+        for (uint32_t i = 0; i < n; i++) idx[i] = i;
+        // Serial top: split every range larger than the grain, then hand the
+        // remaining subtrees to the thread pool.
+        uint32_t grain = std::max<uint32_t>(4096, n / (uint32_t)(threads * 16));
+        std::vector<Task> pending{Task{0, 0, n}}, leaves;
+        while (!pending.empty()) {
+            Task t = pending.back();
+            pending.pop_back();
+            if (t.end - t.begin <= grain || threads == 1) {
+                leaves.push_back(t);
+                continue;
+            }
+            Task l, r;
+            if (build_node(t, l, r)) {
+                pending.push_back(r);
+                pending.push_back(l);
+            }
+        }
+        std::sort(leaves.begin(), leaves.end(),
+                  [](const Task &a, const Task &b) { return a.end - a.begin > b.end - b.begin; });
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= leaves.size()) break;
+                build_subtree(leaves[i]);
+            }
+        };
+        if (threads <= 1) {
+            worker();
+        } else {
+            std::vector<std::thread> pool;
+            for (int i = 0; i < threads; i++) pool.emplace_back(worker);
+            for (auto &th : pool) th.join();
+        }
+    }
+};
+
+// ---- BVH2 -> BVH8 collapse (Ylitie et al. 2017, section 4.2) ------------------
+enum : uint8_t { kLeaf = 0, kInternal = 1, kDistribute = 2 };
+struct Decision {
+    float cost;
+    uint8_t type, dl, dr, pad;
+};
+
+struct Collapser {
+    const std::vector<Node2> &n2;
+    std::vector<Decision> dec; // 7 per BVH2 node
+    BuildParams params;
+    CwBvh &out;
+
+    Collapser(const std::vector<Node2> &nodes, const BuildParams &p, CwBvh &o)
+        : n2(nodes), dec(nodes.size() * 7), params(p), out(o) {}
+
+    void compute_costs() {
+        // children have larger indices than their parent (pre-order layout)
+        for (size_t ni = n2.size(); ni-- > 0;) {
+            const Node2 &nd = n2[ni];
+            Decision *d = &dec[ni * 7];
+            float area = half_area(nd.box);
+            if (nd.count == 1) {
+                for (int i = 0; i < 7; i++) d[i] = Decision{area * params.prim_cost, kLeaf, 0xff, 0xff, 0};
+                continue;
+            }
+            const Decision *dl = &dec[(size_t)nd.left * 7], *dr = &dec[(size_t)nd.right * 7];
+            float cost_leaf = nd.count <= params.max_prims_per_leaf
+                                  ? area * (float)nd.count * params.prim_cost
+                                  : kInf;
+            float cost_dist = kInf;
+            uint8_t bl = 0xff, br = 0xff;
+            for (int k = 0; k < 7; k++) {
+                float c = dl[k].cost + dr[6 - k].cost;
+                if (c < cost_dist) {
+                    cost_dist = c;
+                    bl = (uint8_t)k;
+                    br = (uint8_t)(6 - k);
+                }
+            }
+            float cost_internal = cost_dist + area * params.traversal_cost;
+            if (cost_leaf < cost_internal)
+                d[0] = Decision{cost_leaf, kLeaf, bl, br, 0};
+            else
+                d[0] = Decision{cost_internal, kInternal, bl, br, 0};
+            for (int i = 1; i < 7; i++) {
+                float best = d[i - 1].cost;
+                uint8_t l = 0xff, r = 0xff;
+                for (int k = 0; k < i; k++) {
+                    float c = dl[k].cost + dr[i - k - 1].cost;
+                    if (c < best) {
+                        best = c;
+                        l = (uint8_t)k;
+                        r = (uint8_t)(i - k - 1);
+                    }
+                }
+                if (l != 0xff)
+                    d[i] = Decision{best, kDistribute, l, r, 0};
+                else
+                    d[i] = d[i - 1];
+            }
+        }
+    }
+
+    void get_children(uint32_t ni, int i, uint32_t *children, int &count) const {
+        const Node2 &nd = n2[ni];
+        if (nd.count == 1) {
+            children[count++] = ni;
+            return;
+        }
+        const Decision &d = dec[(size_t)ni * 7 + i];
+        if (dec[(size_t)nd.left * 7 + d.dl].type == kDistribute)
+            get_children(nd.left, d.dl, children, count);
+        else
+            children[count++] = nd.left;
+        if (dec[(size_t)nd.right * 7 + d.dr].type == kDistribute)
+            get_children(nd.right, d.dr, children, count);
+        else
+            children[count++] = nd.right;
+    }
+
+    void collect_prims(uint32_t ni, std::vector<uint32_t> &prims) const {
+        // pre-order layout: the leaves below ni are the count==1 nodes of its 2c-1 block
+        const Node2 &nd = n2[ni];
+        size_t last = (size_t)ni + 2 * (size_t)nd.count - 1;
+        for (size_t k = ni; k < last; k++)
+            if (n2[k].count == 1) prims.push_back(n2[k].prim);
+    }
+
+    struct Child {
+        uint32_t n2 = 0;
+        bool used = false;
+        bool inner = false;
+    };
+
+    // Greedy octant-slot assignment, embree/src/bvh_embree.rs:284-349.
+    void order_children(const Aabb &box, const uint32_t *children, int count, Child slots[8]) const {
+        float pc[3] = {0.5f * (box.mn[0] + box.mx[0]), 0.5f * (box.mn[1] + box.mx[1]),
+                       0.5f * (box.mn[2] + box.mx[2])};
+        float cost[8][8];
+        for (int c = 0; c < count; c++) {
+            const Aabb &cb = n2[children[c]].box;
+            float d[3] = {0.5f * (cb.mn[0] + cb.mx[0]) - pc[0], 0.5f * (cb.mn[1] + cb.mx[1]) - pc[1],
+                          0.5f * (cb.mn[2] + cb.mx[2]) - pc[2]};
+            for (int s = 0; s < 8; s++) {
+                float sx = (s & 4) ? -1.f : 1.f, sy = (s & 2) ? -1.f : 1.f, sz = (s & 1) ? -1.f : 1.f;
+                cost[c][s] = d[0] * sx + d[1] * sy + d[2] * sz;
+            }
+        }
+        int assignment[8];
+        bool filled[8] = {false, false, false, false, false, false, false, false};
+        for (int c = 0; c < 8; c++) assignment[c] = -1;
+        for (;;) {
+            float min_cost = std::numeric_limits<float>::max();
+            int min_slot = -1, min_index = -1;
+            for (int c = 0; c < count; c++) {
+                if (assignment[c] != -1) continue;
+                for (int s = 0; s < 8; s++) {
+                    if (!filled[s] && cost[c][s] < min_cost) {
+                        min_cost = cost[c][s];
+                        min_slot = s;
+                        min_index = c;
+                    }
+                }
+            }
+            if (min_slot < 0) break;
+            filled[min_slot] = true;
+            assignment[min_index] = min_slot;
+        }
+        for (int c = 0; c < count; c++) {
+            int s = assignment[c];
+            if (s < 0) { // non-finite centre: first free slot
+                for (s = 0; s < 8 && filled[s]; s++) {}
+                filled[s] = true;
+            }
+            slots[s].n2 = children[c];
+            slots[s].used = true;
+            slots[s].inner = dec[(size_t)children[c] * 7].type == kInternal;
+        }
+    }
+
+    // Node encoding, embree/src/bvh_embree_to_cwbvh.rs:85-186.
+    static float quant_scale(float extent, float lo, float hi_world) {
+        (void)lo;
+        (void)hi_world;
+        float x = std::max(extent, 1e-20f) * (1.0f / 255.0f);
+        int k;
+        float m = std::frexp(x, &k); // x = m * 2^k, m in [0.5, 1)
+        float e = std::ldexp(1.0f, m == 0.5f ? k - 1 : k);
+        return e;
+    }
+
+    void emit(uint32_t out_idx, uint32_t ni) {
+        const Node2 &nd = n2[ni];
+        uint32_t children[8];
+        int count = 0;
+        if (nd.count == 1)
+            children[count++] = ni; // single-primitive scene: root with one leaf child
+        else
+            get_children(ni, 0, children, count);
+        Child slots[8];
+        order_children(nd.box, children, count, slots);
+
+        uint32_t child_base = (uint32_t)out.nodes.size();
+        uint32_t prim_base = (uint32_t)out.primitive_indices.size();
+
+        CwbvhNode node;
+        std::memset(&node, 0, sizeof(node));
+        float e[3];
+        for (int k = 0; k < 3; k++) {
+            node.p[k] = nd.box.mn[k];
+            e[k] = quant_scale(nd.box.mx[k] - nd.box.mn[k], nd.box.mn[k], nd.box.mx[k]);
+            // make sure 255 steps reach the far plane after rounding
+            while (std::ceil(((double)nd.box.mx[k] - (double)nd.box.mn[k]) / (double)e[k]) > 255.0)
+                e[k] *= 2.0f;
+            uint32_t bits;
+            std::memcpy(&bits, &e[k], 4);
+            node.e[k] = (uint8_t)(bits >> 23);
+        }
+        node.child_base_idx = child_base;
+        node.primitive_base_idx = prim_base;
+
+        uint32_t n_inner = 0, total_tris = 0;
+        std::vector<uint32_t> prims;
+        for (int s = 0; s < 8; s++) {
+            if (!slots[s].used) continue;
+            const Aabb &cb = n2[slots[s].n2].box;
+            uint8_t *qmin[3] = {node.child_min_x, node.child_min_y, node.child_min_z};
+            uint8_t *qmax[3] = {node.child_max_x, node.child_max_y, node.child_max_z};
+            for (int k = 0; k < 3; k++) {
+                float rcp = 1.0f / e[k];
+                float lo = std::floor((cb.mn[k] - node.p[k]) * rcp);
+                float hi = std::ceil((cb.mx[k] - node.p[k]) * rcp);
+                lo = std::min(std::max(lo, 0.0f), 255.0f);
+                hi = std::min(std::max(hi, 0.0f), 255.0f);
+                // keep the decoded planes conservative under f32 rounding of (c - p)
+                while (lo > 0.0f && (double)node.p[k] + (double)lo * (double)e[k] > (double)cb.mn[k]) lo -= 1.0f;
+                while (hi < 255.0f && (double)node.p[k] + (double)hi * (double)e[k] < (double)cb.mx[k]) hi += 1.0f;
+                qmin[k][s] = (uint8_t)lo;
+                qmax[k][s] = (uint8_t)hi;
+            }
+            if (slots[s].inner) {
+                node.imask |= (uint8_t)(1u << s);
+                node.child_meta[s] = (uint8_t)((24 + s) | 0x20);
+                n_inner++;
+            } else {
+                prims.clear();
+                collect_prims(slots[s].n2, prims);
+                uint32_t np = (uint32_t)prims.size();
+                static const uint8_t unary[4] = {0, 0x20, 0x60, 0xE0};
+                node.child_meta[s] = (uint8_t)(total_tris | unary[np]);
+                total_tris += np;
+                for (uint32_t p : prims) out.primitive_indices.push_back(p);
+            }
+        }
+        out.nodes[out_idx] = node;
+        // inner children are stored contiguously in slot order
+        out.nodes.resize(out.nodes.size() + n_inner);
+        uint32_t k = 0;
+        for (int s = 0; s < 8; s++) {
+            if (slots[s].used && slots[s].inner) {
+                emit(child_base + k, slots[s].n2);
+                k++;
+            }
+        }
+    }
+};
+
+void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, const BuildParams &params_in,
+                      CwBvh &out) {
+    auto t0 = std::chrono::steady_clock::now();
+    BuildParams params = params_in;
+    if (params.max_prims_per_leaf < 1) params.max_prims_per_leaf = 1;
+    if (params.max_prims_per_leaf > 3) params.max_prims_per_leaf = 3;
+    int threads = params.threads > 0 ? params.threads : (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+
+    out.nodes.clear();
+    out.primitive_indices.clear();
+    out.total_aabb = empty_box();
+    if (n == 0) {
+        // empty scene: one node with no children; every ray misses
+        CwbvhNode node;
+        std::memset(&node, 0, sizeof(node));
+        node.e[0] = node.e[1] = node.e[2] = 127;
+        node.child_base_idx = 1;
+        out.nodes.push_back(node);
+        out.total_aabb = Aabb{{0, 0, 0}, {0, 0, 0}};
+        out.build_seconds = 0.0;
+        return;
+    }
+    Bvh2Builder b2;
+    b2.boxes = boxes;
+    b2.cen.assign(centroids, centroids + 3 * n);
+    b2.run((uint32_t)n, threads);
+    out.total_aabb = b2.nodes[0].box;
+
+    Collapser col(b2.nodes, params, out);
+    col.compute_costs();
+    if (b2.nodes[0].count > 1) col.dec[0].type = kInternal; // the root is always a node
+    out.nodes.reserve(n / 4 + 16);
+    out.primitive_indices.reserve(n);
+    out.nodes.resize(1);
+    col.emit(0, 0);
+    out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+} // namespace
+
+void build_cwbvh_from_aabbs(const Aabb *boxes, uint64_t n, const BuildParams &params, CwBvh &out) {
+    std::vector<float> cen(3 * n);
+    for (uint64_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) cen[3 * i + k] = 0.5f * (boxes[i].mn[k] + boxes[i].mx[k]);
+    build_from_boxes(boxes, cen.data(), n, params, out);
+}
+
+void build_cwbvh_from_tris(const float *verts, uint64_t n, const BuildParams &params, CwBvh &out) {
+    std::vector<Aabb> boxes(n);
+    std::vector<float> cen(3 * n);
+    for (uint64_t i = 0; i < n; i++) {
+        const float *v = verts + 9 * i;
+        Aabb b = empty_box();
+        grow_pt(b, v);
+        grow_pt(b, v + 3);
+        grow_pt(b, v + 6);
+        boxes[i] = b;
+        for (int k = 0; k < 3; k++) cen[3 * i + k] = (v[k] + v[3 + k] + v[6 + k]) * (1.0f / 3.0f);
+    }
+    build_from_boxes(boxes.data(), cen.data(), n, params, out);
+}
+
+} // namespace trx

@@ -1,0 +1,36 @@
+// builder.h — host-side CWBVH construction (CPU).
+//
+// Stands in for obvhs::cwbvh::builder::{build_cwbvh_from_tris, build_cwbvh}
+// (called from src/cwbvh.rs:97,132).  obvhs is an un-vendored dependency, so
+// this is an independent builder: binned-SAH BVH2 -> optimal SAH collapse to
+// 8-wide nodes (Ylitie et al. 2017, the algorithm obvhs/tinybvh also use) ->
+// octant child ordering (embree/src/bvh_embree.rs:284-349) -> 80-byte node
+// encoding (embree/src/bvh_embree_to_cwbvh.rs:85-186).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "cwbvh_format.h"
+
+namespace trx {
+
+struct CwBvh {
+    std::vector<CwbvhNode> nodes;
+    std::vector<uint32_t> primitive_indices;
+    Aabb total_aabb;
+    double build_seconds = 0.0;
+};
+
+struct BuildParams {
+    uint32_t max_prims_per_leaf = 3; // CWBVH limit (src/main.rs:176-178)
+    float traversal_cost = 1.0f;     // collapse_traversal_cost analogue (src/main.rs:158-163)
+    float prim_cost = 0.3f;
+    int threads = 0; // <= 0: hardware_concurrency
+};
+
+// Build over arbitrary primitive boxes (TLAS path, src/cwbvh.rs:114,132).
+void build_cwbvh_from_aabbs(const Aabb *boxes, uint64_t n, const BuildParams &params, CwBvh &out);
+// verts: n * 9 floats (v0, v1, v2).
+void build_cwbvh_from_tris(const float *verts, uint64_t n, const BuildParams &params, CwBvh &out);
+
+} // namespace trx

@@ -1,0 +1,65 @@
+// kernels.h — launch interface between the C-ABI layer (api.cpp) and the
+// gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/trx.h"
+
+namespace trx {
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kLdsStack = 12;      // traversal-stack entries per lane kept in LDS
+constexpr int kSpillStack = 52;    // further entries per lane in HBM (total 64 = oracle's ORC_STACK_SIZE)
+constexpr uint32_t kMaxSteps = 1u << 22; // per-ray iteration cap: every wave reaches an exit
+
+enum TraceMode : int { kModePrimary = 0, kModeAo = 1, kModeRays = 2 };
+
+struct ViewDev {
+    float view_inv[16];
+    float proj_inv[16];
+    float eye[3];
+    float pad;
+};
+
+// Device-side counters of one launch slot.
+struct SlotCounters {
+    unsigned int next_item;  // work queue head (self-resetting)
+    unsigned int waves_done; // exit ticket (self-resetting)
+    unsigned int overflow;   // rays whose stack overflowed or that hit the step cap (sticky)
+    unsigned int pad;
+    unsigned long long n_rays, n_node, n_tri, n_hits; // COUNT kernels only
+    unsigned int max_stack;
+    unsigned int pad2;
+};
+
+struct TraceParams {
+    const uint4 *nodes;
+    const float4 *tris;
+    const uint32_t *inst;
+    const trx_ray *rays;
+    const trx_hit *primary;
+    trx_hit *out;
+    SlotCounters *ctr;
+    uint2 *spill;
+    uint32_t n_items;
+    uint32_t tlas_start;
+    uint32_t width, height, tiles_x;
+    uint32_t shard_index, shard_count;
+    uint32_t frame;
+    float ao_eps;
+    uint32_t tie_first;
+    uint32_t refill_idle; // refill the wave when at least this many lanes are idle (1..64)
+    uint32_t variant;
+    ViewDev view;
+};
+
+// Resident waves the persistent kernel should be launched with on `device`.
+int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count);
+
+// Enqueues one traversal kernel.  sem: trx_semantics bits.
+hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, int grid,
+                        hipStream_t stream);
+
+} // namespace trx

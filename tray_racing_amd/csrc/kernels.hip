@@ -1,0 +1,526 @@
+// kernels.hip — gfx950 (MI355X, wave64) CWBVH closest-hit kernels.
+//
+// One persistent wave = 64 ray slots.  A wave pulls work items (pixels of an
+// 8x8 tile, or explicit rays) from a global queue with one atomic per refill
+// (ballot + mbcnt give every idle lane its item), traverses with a per-lane
+// stack striped through LDS (entry i of lane l at [i*64 + l]: conflict-free
+// ds_write_b64/ds_read_b64) that spills to HBM past kLdsStack entries, and
+// refills idle lanes when enough of them have finished.
+//
+// What each function restates (paths relative to the tray_racing checkout):
+//   node_intersect   src/rt_gpu/rt_gpu_software_query.hlsl:213-303
+//   tri test         src/rt_gpu/rt_gpu_software_query.hlsl:89-129
+//   traversal        src/rt_gpu/rt_gpu_software_query.hlsl:328-438,
+//                    src/rt_gpu/rt_gpu_software_query_tlas.hlsl:333-500
+//   primary ray      src/rt_gpu/rt_gpu_software.hlsl:69-80, src/rt_cpu/rt_cpu.rs:38-55
+//   AO ray           src/rt_gpu/rt_gpu_software.hlsl:105-121, src/rt_cpu/rt_cpu.rs:61-76,
+//                    src/rt_gpu/sampling.hlsl:5-51
+//
+// Arithmetic contract (DESIGN.md "Numerics"): binary32, no contraction
+// (-ffp-contract=off; the only fused op is the explicit fmaf of
+// TRX_SEM_NODE_FMA), IEEE divide and sqrt, dot = (ax*bx + ay*by) + az*bz.
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace trx {
+namespace {
+
+#define TRX_F32_MAX 3.402823466e+38f
+#define TRX_F32_EPSILON 1.1920929e-7f
+#define TRX_INVALID 0xFFFFFFFFu
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+
+struct Ray {
+    float ox, oy, oz;
+    float dx, dy, dz;    // after the zero-direction fix (query.hlsl:334)
+    float ix, iy, iz;    // 1/d, IEEE divide (TRX_SEM_NODE_RCP)
+    float tmin;
+    uint32_t oct_inv4;
+};
+
+// NODE bit0: multiply by precomputed reciprocal, bit1: fused plane evaluation
+template <int NODE>
+__device__ __forceinline__ float plane(float q, float a, float b) {
+    if (NODE & 2) return __builtin_fmaf(q, a, b);
+    return q * a + b;
+}
+
+__device__ __forceinline__ float ubyte(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xffu); }
+
+template <int NODE>
+__device__ __forceinline__ uint32_t node_intersect(const Ray &r, float max_distance, const uint4 n0,
+                                                   const uint4 n1, const uint4 n2, const uint4 n3,
+                                                   const uint4 n4) {
+    const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
+    const uint32_t e_imask = n0.w;
+    const float ex = __uint_as_float((e_imask & 0xffu) << 23);
+    const float ey = __uint_as_float(((e_imask >> 8) & 0xffu) << 23);
+    const float ez = __uint_as_float(((e_imask >> 16) & 0xffu) << 23);
+    float ax, ay, az, bx, by, bz;
+    if (NODE & 1) {
+        ax = ex * r.ix;
+        ay = ey * r.iy;
+        az = ez * r.iz;
+        bx = (px - r.ox) * r.ix;
+        by = (py - r.oy) * r.iy;
+        bz = (pz - r.oz) * r.iz;
+    } else {
+        ax = ex / r.dx;
+        ay = ey / r.dy;
+        az = ez / r.dz;
+        bx = (px - r.ox) / r.dx;
+        by = (py - r.oy) / r.dy;
+        bz = (pz - r.oz) / r.dz;
+    }
+    const bool nx = r.dx < 0.0f, ny = r.dy < 0.0f, nz = r.dz < 0.0f;
+    uint32_t hit_mask = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t meta4 = i == 0 ? n1.z : n1.w;
+        const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+        const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+        const uint32_t bit_index4 = (meta4 ^ (r.oct_inv4 & inner_mask4)) & 0x1f1f1f1fu;
+        const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+        const uint32_t q_lo_x = i == 0 ? n2.x : n2.y, q_hi_x = i == 0 ? n2.z : n2.w;
+        const uint32_t q_lo_y = i == 0 ? n3.x : n3.y, q_hi_y = i == 0 ? n3.z : n3.w;
+        const uint32_t q_lo_z = i == 0 ? n4.x : n4.y, q_hi_z = i == 0 ? n4.z : n4.w;
+        const uint32_t x_min = nx ? q_hi_x : q_lo_x, x_max = nx ? q_lo_x : q_hi_x;
+        const uint32_t y_min = ny ? q_hi_y : q_lo_y, y_max = ny ? q_lo_y : q_hi_y;
+        const uint32_t z_min = nz ? q_hi_z : q_lo_z, z_max = nz ? q_lo_z : q_hi_z;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float tminx = plane<NODE>(ubyte(x_min, j), ax, bx);
+            const float tminy = plane<NODE>(ubyte(y_min, j), ay, by);
+            const float tminz = plane<NODE>(ubyte(z_min, j), az, bz);
+            const float tmaxx = plane<NODE>(ubyte(x_max, j), ax, bx);
+            const float tmaxy = plane<NODE>(ubyte(y_max, j), ay, by);
+            const float tmaxz = plane<NODE>(ubyte(z_max, j), az, bz);
+            const float tmin = fmaxf(fmaxf(fmaxf(tminx, tminy), tminz), 0.0001f);
+            const float tmax = fminf(fminf(fminf(tmaxx, tmaxy), tmaxz), max_distance);
+            if (tmin <= tmax) {
+                const uint32_t child_bits = (child_bits4 >> (8 * j)) & 0xffu;
+                const uint32_t bit_index = (bit_index4 >> (8 * j)) & 0xffu;
+                hit_mask |= child_bits << bit_index;
+            }
+        }
+    }
+    return hit_mask;
+}
+
+// TriDev = {v0, e1 = v0 - v1, e2 = v2 - v0} as three float4.
+__device__ __forceinline__ bool intersect_tri(const Ray &r, const float4 a, const float4 b, const float4 c4,
+                                              float &t, bool tie_first) {
+    const float e1x = b.x, e1y = b.y, e1z = b.z;
+    const float e2x = c4.x, e2y = c4.y, e2z = c4.z;
+    const float ngx = e1y * e2z - e1z * e2y;
+    const float ngy = e1z * e2x - e1x * e2z;
+    const float ngz = e1x * e2y - e1y * e2x;
+    const float cx = a.x - r.ox, cy = a.y - r.oy, cz = a.z - r.oz;
+    const float rx = r.dy * cz - r.dz * cy;
+    const float ry = r.dz * cx - r.dx * cz;
+    const float rz = r.dx * cy - r.dy * cx;
+    const float inv_det = 1.0f / dot3(ngx, ngy, ngz, r.dx, r.dy, r.dz);
+    const float u = dot3(rx, ry, rz, e2x, e2y, e2z) * inv_det;
+    const float v = dot3(rx, ry, rz, e1x, e1y, e1z) * inv_det;
+    const float w = 1.0f - u - v;
+    const uint32_t hit = __float_as_uint(u) | __float_as_uint(v) | __float_as_uint(w);
+    if (inv_det != 0.0f && (hit & 0x80000000u) == 0) {
+        const float tt = dot3(ngx, ngy, ngz, cx, cy, cz) * inv_det;
+        const bool closer = tie_first ? (tt < t) : (tt <= t);
+        if (tt >= r.tmin && closer) {
+            t = tt;
+            return true;
+        }
+    }
+    return false;
+}
+
+__device__ __forceinline__ void finish_ray_dir(Ray &r, float dx, float dy, float dz) {
+    r.dx = dx == 0.0f ? TRX_F32_EPSILON : dx;
+    r.dy = dy == 0.0f ? TRX_F32_EPSILON : dy;
+    r.dz = dz == 0.0f ? TRX_F32_EPSILON : dz;
+    r.ix = 1.0f / r.dx;
+    r.iy = 1.0f / r.dy;
+    r.iz = 1.0f / r.dz;
+    r.oct_inv4 = (r.dx < 0.0f ? 0u : 0x04040404u) | (r.dy < 0.0f ? 0u : 0x02020202u) |
+                 (r.dz < 0.0f ? 0u : 0x01010101u);
+}
+
+__device__ __forceinline__ void mat4_mul(const float *m, float v0, float v1, float v2, float v3, float &r0,
+                                         float &r1, float &r2, float &r3) {
+    r0 = ((m[0] * v0 + m[4] * v1) + m[8] * v2) + m[12] * v3;
+    r1 = ((m[1] * v0 + m[5] * v1) + m[9] * v2) + m[13] * v3;
+    r2 = ((m[2] * v0 + m[6] * v1) + m[10] * v2) + m[14] * v3;
+    r3 = ((m[3] * v0 + m[7] * v1) + m[11] * v2) + m[15] * v3;
+}
+
+__device__ __forceinline__ void primary_dir(const ViewDev &view, uint32_t w, uint32_t h, uint32_t px,
+                                            uint32_t py, float &dx, float &dy, float &dz) {
+    const float u = (float)px / (float)w;
+    float v = (float)py / (float)h;
+    v = 1.0f - v;
+    const float cx = u * 2.0f - 1.0f, cy = v * 2.0f - 1.0f;
+    float vx, vy, vz, vw;
+    mat4_mul(view.proj_inv, cx, cy, 1.0f, 1.0f, vx, vy, vz, vw);
+    const float s = vw;
+    vx = vx / s;
+    vy = vy / s;
+    vz = vz / s;
+    vw = vw / s;
+    float wx, wy, wz, ww;
+    mat4_mul(view.view_inv, vx, vy, vz, vw, wx, wy, wz, ww);
+    dx = wx - view.eye[0];
+    dy = wy - view.eye[1];
+    dz = wz - view.eye[2];
+    const float inv = 1.0f / sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+    dx *= inv;
+    dy *= inv;
+    dz *= inv;
+}
+
+__device__ __forceinline__ uint32_t uhash(uint32_t a, uint32_t b) {
+    uint32_t x = (a * 1597334673u) ^ (b * 3812015801u);
+    x = x ^ (x >> 16);
+    x *= 0x7feb352du;
+    x = x ^ (x >> 15);
+    x *= 0x846ca68bu;
+    x = x ^ (x >> 16);
+    return x;
+}
+__device__ __forceinline__ float hash_noise(uint32_t x, uint32_t y, uint32_t frame) {
+    return (float)uhash(x, (y << 11) + frame) * (1.0f / 4294967296.0f);
+}
+
+// Explicit sin/cos (same evaluation as the oracle's; platform sin/cos are not
+// bit-reproducible): Cody-Waite reduction by pi/2 + cephes minimax polynomials.
+__device__ __forceinline__ void sincos_det(float theta, float &s, float &c) {
+    const float kf = floorf(theta * 0.636619772f + 0.5f);
+    const int k = (int)kf;
+    float r = theta - kf * 1.5703125f;
+    r = r - kf * 4.837512969970703125e-4f;
+    r = r - kf * 7.54978995489188216e-8f;
+    const float z = r * r;
+    const float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    const float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    switch (k & 3) {
+    case 0: s = sp; c = cp; break;
+    case 1: s = cp; c = -sp; break;
+    case 2: s = -sp; c = -cp; break;
+    default: s = -cp; c = sp; break;
+    }
+}
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <int MODE, bool TLAS, int NODE, bool COUNT>
+__global__ void __launch_bounds__(kWave) k_trace(const TraceParams P) {
+    __shared__ uint2 lds_stack[kLdsStack * kWave];
+    const uint32_t lane = threadIdx.x;
+    uint2 *const spill = P.spill + (size_t)blockIdx.x * (kSpillStack * kWave) + lane;
+    const bool tie_first = P.tie_first != 0;
+
+    // per-lane ray slot
+    bool has_ray = false;
+    Ray r;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmin = 0.0f;
+    r.oct_inv4 = 0;
+    float t = 0.0f;
+    uint32_t prim = TRX_INVALID, out_index = 0, sp = 0, steps = 0;
+    uint32_t tlas_sp = TRX_INVALID, bvh_off = 0;
+    uint2 cur = make_uint2(0u, 0u);
+    bool overflow = false;
+    // COUNT only
+    uint32_t c_node = 0, c_tri = 0, c_rays = 0, c_hits = 0, c_maxsp = 0, c_over = 0;
+
+    bool exhausted = false; // wave-uniform
+    for (;;) {
+        // ---- refill idle lanes from the global queue --------------------------------
+        const unsigned long long idle = __ballot(!has_ray);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (!exhausted && n_idle >= P.refill_idle) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&P.ctr->next_item, n_idle);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + n_idle >= P.n_items || base + n_idle < base) exhausted = true;
+            const uint32_t item = base + lane_rank(idle);
+            if (!has_ray && item < P.n_items && base <= item) {
+                bool ok = false;
+                float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+                if (MODE == kModeRays) {
+                    const float4 *rp = reinterpret_cast<const float4 *>(P.rays + item);
+                    const float4 a = rp[0], b = rp[1];
+                    r.ox = a.x; r.oy = a.y; r.oz = a.z; r.tmin = a.w;
+                    dx = b.x; dy = b.y; dz = b.z;
+                    t = fminf(b.w, TRX_F32_MAX);
+                    out_index = item;
+                    ok = true;
+                } else {
+                    const uint32_t tile = (item >> 6) * P.shard_count + P.shard_index;
+                    const uint32_t k = item & 63u;
+                    const uint32_t px = (tile % P.tiles_x) * 8u + (k & 7u);
+                    const uint32_t py = (tile / P.tiles_x) * 8u + (k >> 3);
+                    if (px < P.width && py < P.height) {
+                        out_index = py * P.width + px;
+                        primary_dir(P.view, P.width, P.height, px, py, dx, dy, dz);
+                        if (MODE == kModePrimary) {
+                            r.ox = P.view.eye[0]; r.oy = P.view.eye[1]; r.oz = P.view.eye[2];
+                            ok = true;
+                        } else {
+                            const trx_hit ph = P.primary[out_index];
+                            if (ph.t < TRX_F32_MAX && ph.prim != TRX_INVALID) {
+                                // normal of the hit triangle, flipped toward the viewer
+                                const float4 *tp = P.tris + (size_t)ph.prim * 3;
+                                const float4 b = tp[1], c4 = tp[2];
+                                float nx = b.y * c4.z - b.z * c4.y;
+                                float ny = b.z * c4.x - b.x * c4.z;
+                                float nz = b.x * c4.y - b.y * c4.x;
+                                const float ninv = 1.0f / sqrtf(dot3(nx, ny, nz, nx, ny, nz));
+                                nx *= ninv; ny *= ninv; nz *= ninv;
+                                const float nd = (nx * -dx + ny * -dy) + nz * -dz;
+                                const float sg = copysignf(1.0f, nd);
+                                nx *= sg; ny *= sg; nz *= sg;
+                                r.ox = (P.view.eye[0] + dx * ph.t) - dx * P.ao_eps;
+                                r.oy = (P.view.eye[1] + dy * ph.t) - dy * P.ao_eps;
+                                r.oz = (P.view.eye[2] + dz * ph.t) - dz * P.ao_eps;
+                                const float u1 = hash_noise(px, py, P.frame);
+                                const float u2 = hash_noise(px, py, P.frame + 1024u);
+                                const float rr = sqrtf(u1);
+                                const float theta = u2 * 6.28318530717958647692f;
+                                float sn, cs;
+                                sincos_det(theta, sn, cs);
+                                const float lx = rr * cs, ly = rr * sn, lz = sqrtf(fmaxf(0.0f, 1.0f - u1));
+                                const float sign = nz >= 0.0f ? 1.0f : -1.0f;
+                                const float a = -1.0f / (sign + nz);
+                                const float bb = nx * ny * a;
+                                const float b1x = 1.0f + sign * nx * nx * a, b1y = sign * bb, b1z = -sign * nx;
+                                const float b2x = bb, b2y = sign + ny * ny * a, b2z = -ny;
+                                dx = (b1x * lx + b2x * ly) + nx * lz;
+                                dy = (b1y * lx + b2y * ly) + ny * lz;
+                                dz = (b1z * lx + b2z * ly) + nz * lz;
+                                const float dinv = 1.0f / sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+                                dx *= dinv; dy *= dinv; dz *= dinv;
+                                ok = true;
+                            } else {
+                                trx_hit miss;
+                                miss.t = __builtin_inff();
+                                miss.prim = TRX_INVALID;
+                                P.out[out_index] = miss;
+                            }
+                        }
+                        if (MODE != kModeRays) {
+                            r.tmin = 0.0f;
+                            t = TRX_F32_MAX;
+                        }
+                    }
+                }
+                if (ok) {
+                    finish_ray_dir(r, dx, dy, dz);
+                    prim = TRX_INVALID;
+                    sp = 0;
+                    steps = 0;
+                    overflow = false;
+                    cur = make_uint2(0u, 0x80000000u);
+                    if (TLAS) {
+                        tlas_sp = TRX_INVALID;
+                        bvh_off = P.tlas_start;
+                    }
+                    has_ray = true;
+                }
+            }
+        }
+        if (__ballot(has_ray) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- traverse ------------------------------------------------------------
+        if (has_ray) {
+            const uint32_t keep = kWave - P.refill_idle; // leave when this few lanes remain
+            for (;;) {
+                uint2 tri;
+                if (cur.y & 0xff000000u) {
+                    const uint32_t hits_imask = cur.y;
+                    const uint32_t child_bit = 31u - (uint32_t)__clz((int)hits_imask);
+                    const uint32_t child_base = cur.x;
+                    cur.y &= ~(1u << child_bit);
+                    if (cur.y & 0xff000000u) {
+                        if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = cur;
+                        else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave] = cur;
+                        else overflow = true;
+                        sp++;
+                        if (COUNT) c_maxsp = max(c_maxsp, sp);
+                    }
+                    const uint32_t slot = (child_bit - 24u) ^ (r.oct_inv4 & 0xffu);
+                    const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
+                    uint32_t node_index = child_base + rel;
+                    if (TLAS) node_index += bvh_off;
+                    const uint4 *np = P.nodes + (size_t)node_index * 5;
+                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                    if (COUNT) c_node++;
+                    const uint32_t hitmask = node_intersect<NODE>(r, t, n0, n1, n2, n3, n4);
+                    cur.x = n1.x;
+                    tri.x = n1.y;
+                    cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                    tri.y = hitmask & 0x00ffffffu;
+                } else {
+                    tri = cur;
+                    cur = make_uint2(0u, 0u);
+                }
+
+                while (tri.y != 0u) {
+                    const uint32_t local = 31u - (uint32_t)__clz((int)tri.y);
+                    tri.y &= ~(1u << local);
+                    const uint32_t gidx = tri.x + local;
+                    if (TLAS && tlas_sp == TRX_INVALID) {
+                        // a TLAS primitive is an instance (query_tlas.hlsl:410-446)
+                        if (tri.y != 0u) {
+                            if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = tri;
+                            else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave] = tri;
+                            else overflow = true;
+                            sp++;
+                        }
+                        if (cur.y & 0xff000000u) {
+                            if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = cur;
+                            else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave] = cur;
+                            else overflow = true;
+                            sp++;
+                        }
+                        if (COUNT) c_maxsp = max(c_maxsp, sp);
+                        tlas_sp = sp;
+                        bvh_off = P.inst[gidx];
+                        cur = make_uint2(0u, 0x80000000u);
+                        break;
+                    }
+                    const float4 *tp = P.tris + (size_t)gidx * 3;
+                    const float4 a = tp[0], b = tp[1], c4 = tp[2];
+                    if (COUNT) c_tri++;
+                    if (intersect_tri(r, a, b, c4, t, tie_first)) prim = gidx;
+                }
+
+                bool done = false;
+                if ((cur.y & 0xff000000u) == 0u) {
+                    if (sp == 0u) {
+                        done = true;
+                    } else {
+                        if (TLAS && sp == tlas_sp) { // back to the TLAS (query_tlas.hlsl:480-486)
+                            tlas_sp = TRX_INVALID;
+                            bvh_off = P.tlas_start;
+                        }
+                        sp--;
+                        if (sp < (uint32_t)kLdsStack) cur = lds_stack[sp * kWave + lane];
+                        else if (sp < (uint32_t)(kLdsStack + kSpillStack)) cur = spill[(sp - kLdsStack) * kWave];
+                        else cur = make_uint2(0u, 0u);
+                    }
+                }
+                if (++steps > kMaxSteps) {
+                    overflow = true;
+                    done = true;
+                }
+                if (done) {
+                    trx_hit h;
+                    h.t = prim != TRX_INVALID ? t : __builtin_inff();
+                    h.prim = prim;
+                    P.out[out_index] = h;
+                    if (COUNT) {
+                        c_rays++;
+                        c_hits += prim != TRX_INVALID;
+                    }
+                    c_over += overflow ? 1u : 0u;
+                    has_ray = false;
+                    break;
+                }
+                if (!exhausted && (uint32_t)__popcll(__ballot(1)) <= keep) break;
+            }
+        }
+    }
+
+    // ---- epilogue: flags, counters, queue reset ---------------------------------------
+    if (c_over) atomicAdd(&P.ctr->overflow, c_over);
+    if (COUNT) {
+        atomicAdd(&P.ctr->n_rays, (unsigned long long)c_rays);
+        atomicAdd(&P.ctr->n_node, (unsigned long long)c_node);
+        atomicAdd(&P.ctr->n_tri, (unsigned long long)c_tri);
+        atomicAdd(&P.ctr->n_hits, (unsigned long long)c_hits);
+        atomicMax(&P.ctr->max_stack, c_maxsp);
+    }
+    if (lane == 0) {
+        // the last wave out re-arms the queue for the next launch on this slot
+        const unsigned int ticket = atomicAdd(&P.ctr->waves_done, 1u);
+        if (ticket == gridDim.x - 1u) {
+            atomicExch(&P.ctr->next_item, 0u);
+            atomicExch(&P.ctr->waves_done, 0u);
+        }
+    }
+}
+
+template <int MODE, bool TLAS, int NODE, bool COUNT>
+hipError_t launch_one(const TraceParams &p, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL((k_trace<MODE, TLAS, NODE, COUNT>), dim3(grid), dim3(kWave), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <int MODE, bool TLAS, bool COUNT>
+hipError_t launch_node(const TraceParams &p, int node, int grid, hipStream_t stream) {
+    switch (node) {
+    case 0: return launch_one<MODE, TLAS, 0, COUNT>(p, grid, stream);
+    case 1: return launch_one<MODE, TLAS, 1, COUNT>(p, grid, stream);
+    case 2: return launch_one<MODE, TLAS, 2, COUNT>(p, grid, stream);
+    default: return launch_one<MODE, TLAS, 3, COUNT>(p, grid, stream);
+    }
+}
+
+template <int MODE>
+hipError_t launch_mode(const TraceParams &p, bool tlas, int node, bool count, int grid, hipStream_t stream) {
+    if (tlas) {
+        if (count) return launch_node<MODE, true, true>(p, node, grid, stream);
+        return launch_node<MODE, true, false>(p, node, grid, stream);
+    }
+    if (count) return launch_node<MODE, false, true>(p, node, grid, stream);
+    return launch_node<MODE, false, false>(p, node, grid, stream);
+}
+
+template <int MODE, bool TLAS, int NODE, bool COUNT>
+int occupancy_one() {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace<MODE, TLAS, NODE, COUNT>, kWave, 0) != hipSuccess)
+        return 0;
+    return blocks;
+}
+
+int node_variant(uint32_t sem) {
+    return ((sem & TRX_SEM_NODE_RCP) ? 1 : 0) | ((sem & TRX_SEM_NODE_FMA) ? 2 : 0);
+}
+
+} // namespace
+
+int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count) {
+    (void)mode;
+    (void)sem;
+    (void)count;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+    // occupancy of the variants is within one wave of each other; query one per TLAS flavour
+    int per_cu = tlas ? occupancy_one<kModePrimary, true, 1, false>() : occupancy_one<kModePrimary, false, 1, false>();
+    if (per_cu <= 0) per_cu = 8;
+    if (per_cu > 32) per_cu = 32;
+    return per_cu * prop.multiProcessorCount;
+}
+
+hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, int grid,
+                        hipStream_t stream) {
+    const int node = node_variant(sem);
+    switch (mode) {
+    case kModePrimary: return launch_mode<kModePrimary>(p, tlas, node, count, grid, stream);
+    case kModeAo: return launch_mode<kModeAo>(p, tlas, node, count, grid, stream);
+    case kModeRays: return launch_mode<kModeRays>(p, tlas, node, count, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace trx

@@ -1,0 +1,243 @@
+"""Host-side mirror of the reference's CWBVH GPU path over the C-ABI.
+
+Names follow the reference: `cwbvh_gpu_runner` (src/rt_gpu/mod.rs:16-112)
+assembles the flat node / triangle / instance buffers, `Scene` owns what
+rt_gpu_software::start uploaded (src/rt_gpu/rt_gpu_software.rs:24-32,83-160),
+and `Scene.start` returns the frame time in ms like the reference does (:376).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+HIT_DTYPE = np.dtype([("t", "<f4"), ("prim", "<u4")])
+RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("tmin", "<f4"), ("direction", "<f4", 3), ("tmax", "<f4")])
+MISS_PRIM = 0xFFFFFFFF
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- scenes / models ----------------------------------------------------------
+
+def _take_mesh(verts_p, n, counts_p, nobj):
+    lib = L.load()
+    verts = np.ctypeslib.as_array(verts_p, shape=(max(n.value, 1), 9))[: n.value].copy()
+    counts = np.ctypeslib.as_array(counts_p, shape=(max(nobj.value, 1),))[: nobj.value].copy()
+    lib.trx_free(C.cast(verts_p, C.c_void_p))
+    lib.trx_free(C.cast(counts_p, C.c_void_p))
+    return verts, counts.astype(np.uint64)
+
+
+def gen_scene(name, n_tris=0, seed=1):
+    """Seeded procedural stand-in for one of the reference's absent assets."""
+    lib = L.load()
+    vp, cp = C.POINTER(C.c_float)(), C.POINTER(C.c_uint64)()
+    n, nobj = C.c_uint64(), C.c_uint32()
+    L.check(lib.trx_gen_scene(name.encode(), n_tris, seed, C.byref(vp), C.byref(n), C.byref(cp), C.byref(nobj)))
+    return _take_mesh(vp, n, cp, nobj)
+
+
+def load_meshs(path):
+    """load_meshs (src/main.rs:494-561): OBJ or JSON -> (verts [n,9], triangles per object)."""
+    lib = L.load()
+    vp, cp = C.POINTER(C.c_float)(), C.POINTER(C.c_uint64)()
+    n, nobj = C.c_uint64(), C.c_uint32()
+    L.check(lib.trx_load_model(str(path).encode(), C.byref(vp), C.byref(n), C.byref(cp), C.byref(nobj)))
+    return _take_mesh(vp, n, cp, nobj)
+
+
+def scene_camera(name):
+    lib = L.load()
+    eye, look, fov = (C.c_float * 3)(), (C.c_float * 3)(), C.c_float()
+    L.check(lib.trx_scene_camera(name.encode(), eye, look, C.byref(fov)))
+    return list(eye), list(look), fov.value
+
+
+def view_from_camera(eye, look_at, fov_deg, width, height):
+    """ViewUniform::from_camera (src/main.rs:602-616)."""
+    lib = L.load()
+    v = L.View()
+    L.check(lib.trx_view_from_camera((C.c_float * 3)(*eye), (C.c_float * 3)(*look_at), fov_deg, float(width),
+                                     float(height), C.byref(v)))
+    return v
+
+
+# ---- flat buffers (cwbvh_gpu_runner's assembly half) -----------------------------
+
+class FlatScene:
+    """The buffers rt_gpu_software::start receives: bvh_bytes, tri_bytes, instance_bytes, tlas_start."""
+
+    def __init__(self, nodes, tri_verts, instance_offsets, tlas_start, tri_source, blas_tri_start,
+                 blas_build_s=0.0, tlas_build_s=0.0):
+        self.nodes = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 20)
+        self.tri_verts = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
+        self.instance_offsets = np.ascontiguousarray(instance_offsets, dtype=np.uint32)
+        self.tlas_start = int(tlas_start)
+        self.tri_source = np.ascontiguousarray(tri_source, dtype=np.uint32)
+        self.blas_tri_start = np.ascontiguousarray(blas_tri_start, dtype=np.uint32)
+        self.blas_build_s = blas_build_s
+        self.tlas_build_s = tlas_build_s
+
+    @property
+    def n_nodes(self):
+        return self.nodes.shape[0]
+
+    @property
+    def n_tris(self):
+        return self.tri_verts.shape[0]
+
+    @property
+    def has_tlas(self):
+        return self.instance_offsets.size > 0
+
+
+def flat_build(verts, object_counts=None, use_tlas=False, max_prims_per_leaf=3, threads=0):
+    lib = L.load()
+    verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
+    if object_counts is None:
+        object_counts = [verts.shape[0]]
+    counts = np.ascontiguousarray(object_counts, dtype=np.uint64)
+    if int(counts.sum()) != verts.shape[0]:
+        raise L.TrxError(L.TRX_ERR_INVALID, "object counts do not add up to the triangle count")
+    fp = C.POINTER(L.Flat)()
+    L.check(lib.trx_flat_build(_ptr(verts), _ptr(counts), counts.size, 1 if use_tlas else 0, max_prims_per_leaf,
+                               threads, C.byref(fp)))
+    f = fp.contents
+    try:
+        nodes = np.frombuffer((C.c_uint8 * (f.n_nodes * 80)).from_address(f.bvh_bytes), dtype=np.uint32).copy()
+        tris = np.ctypeslib.as_array(f.tri_verts, shape=(max(f.n_tris, 1), 9))[: f.n_tris].copy()
+        inst = np.ctypeslib.as_array(f.instance_offsets, shape=(max(f.n_instances, 1),))[: f.n_instances].copy()
+        src = np.ctypeslib.as_array(f.tri_source, shape=(max(f.n_tris, 1),))[: f.n_tris].copy()
+        bts = np.ctypeslib.as_array(f.blas_tri_start, shape=(f.n_blas + 1,)).copy()
+        return FlatScene(nodes, tris, inst, f.tlas_start, src, bts, f.blas_build_s, f.tlas_build_s)
+    finally:
+        lib.trx_flat_destroy(fp)
+
+
+def pack_tris_f16(tri_verts):
+    """obvhs RtCompressedTriangle (24 B): v0 f32x3 + f16 edges, e2 in the low half (query.hlsl:75-85)."""
+    v = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
+    e1 = (v[:, 3:6] - v[:, 0:3]).astype(np.float16).view(np.uint16).astype(np.uint32)
+    e2 = (v[:, 6:9] - v[:, 0:3]).astype(np.float16).view(np.uint16).astype(np.uint32)
+    out = np.empty((v.shape[0], 6), dtype=np.uint32)
+    out[:, 0:3] = v[:, 0:3].view(np.uint32)
+    out[:, 3:6] = e2 | (e1 << 16)
+    return out
+
+
+# ---- device scene ---------------------------------------------------------------------
+
+class Scene:
+    """Device-resident CWBVH scene (what rt_gpu_software::start uploads)."""
+
+    def __init__(self, flat, device=0, tri_format=L.TRI_VERTS_36, tri_bytes=None):
+        lib = L.load()
+        self._lib = lib
+        self._h = C.c_void_p()
+        self.flat = flat
+        nodes = flat.nodes
+        if tri_bytes is None:
+            tri_bytes = flat.tri_verts
+        tri_bytes = np.ascontiguousarray(tri_bytes)
+        inst = flat.instance_offsets
+        L.check(lib.trx_scene_create(_ptr(nodes), flat.n_nodes, _ptr(tri_bytes), flat.n_tris, tri_format,
+                                     _ptr(inst) if inst.size else None, inst.size, flat.tlas_start, device,
+                                     C.byref(self._h)))
+        if flat.blas_tri_start.size > 1:
+            L.check(lib.trx_scene_set_geometry_ranges(self._h, _ptr(flat.blas_tri_start),
+                                                      flat.blas_tri_start.size - 1))
+
+    def close(self):
+        if self._h:
+            self._lib.trx_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def device_bytes(self):
+        return self._lib.trx_scene_device_bytes(self._h)
+
+    # host-buffer entry points -------------------------------------------------------
+    def trace_primary(self, view, width, height, sem=L.SEM_HLSL):
+        hits = np.empty(width * height, dtype=HIT_DTYPE)
+        ms = C.c_float()
+        L.check(self._lib.trx_trace_primary(self._h, C.byref(view), width, height, sem, _ptr(hits), C.byref(ms)))
+        return hits, ms.value
+
+    def trace_primary_ao(self, view, width, height, sem=L.SEM_HLSL, frame=0, ao_eps=0.01):
+        prim = np.empty(width * height, dtype=HIT_DTYPE)
+        ao = np.empty(width * height, dtype=HIT_DTYPE)
+        ms = C.c_float()
+        L.check(self._lib.trx_trace_primary_ao(self._h, C.byref(view), width, height, sem, frame, ao_eps, _ptr(prim),
+                                               _ptr(ao), C.byref(ms)))
+        return prim, ao, ms.value
+
+    def trace_rays(self, rays, sem=L.SEM_HLSL):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.empty(rays.shape[0], dtype=HIT_DTYPE)
+        ms = C.c_float()
+        L.check(self._lib.trx_trace_rays(self._h, _ptr(rays), rays.shape[0], sem, _ptr(hits), C.byref(ms)))
+        return hits, ms.value
+
+    def traverse(self, origin, direction, tmin=0.0, tmax=3.4028234663852886e38, sem=L.SEM_HLSL):
+        """Traversable::traverse (traversable/src/lib.rs:17-21) for one ray."""
+        ray = L.Ray((C.c_float * 3)(*origin), tmin, (C.c_float * 3)(*direction), tmax)
+        out = L.RayHit()
+        L.check(self._lib.trx_traverse1(self._h, C.byref(ray), sem, C.byref(out)))
+        return out
+
+    def count_primary(self, view, width, height, sem=L.SEM_HLSL, shard=(0, 1)):
+        st = L.Stats()
+        L.check(self._lib.trx_count_primary(self._h, C.byref(view), width, height, L.Shard(*shard), sem, None,
+                                            C.byref(st)))
+        return st
+
+    def bench_primary(self, view, width, height, sem=L.SEM_HLSL, warmup=1, frames=20):
+        mn, mean = C.c_float(), C.c_float()
+        L.check(self._lib.trx_bench_primary(self._h, C.byref(view), width, height, sem, warmup, frames, C.byref(mn),
+                                            C.byref(mean)))
+        return mn.value, mean.value
+
+    # device-resident entry points (pointers are ints: tensor.data_ptr(), stream.cuda_stream) ----
+    def trace_primary_dev(self, view, width, height, d_hits, sem=L.SEM_HLSL, shard=(0, 1), stream=0):
+        L.check(self._lib.trx_trace_primary_dev(self._h, C.byref(view), width, height, L.Shard(*shard), sem,
+                                                C.c_void_p(d_hits), C.c_void_p(stream)))
+
+    def trace_ao_dev(self, view, width, height, d_primary, d_ao, sem=L.SEM_HLSL, frame=0, ao_eps=0.01,
+                     shard=(0, 1), stream=0):
+        L.check(self._lib.trx_trace_ao_dev(self._h, C.byref(view), width, height, L.Shard(*shard), sem, frame, ao_eps,
+                                           C.c_void_p(d_primary), C.c_void_p(d_ao), C.c_void_p(stream)))
+
+    def trace_rays_dev(self, d_rays, n, d_hits, sem=L.SEM_HLSL, stream=0):
+        L.check(self._lib.trx_trace_rays_dev(self._h, C.c_void_p(d_rays), n, sem, C.c_void_p(d_hits),
+                                             C.c_void_p(stream)))
+
+    def check(self, stream=0):
+        L.check(self._lib.trx_scene_check(self._h, C.c_void_p(stream)))
+
+
+def cwbvh_gpu_runner(verts, object_counts, width, height, camera, tlas=False, max_prims_per_leaf=3, benchmark=True,
+                     frames=20, sem=L.SEM_HLSL, device=0, threads=0):
+    """cwbvh_gpu_runner (src/rt_gpu/mod.rs:16-112) on the HIP backend: build the BLAS/TLAS,
+    assemble the flat buffers, upload, trace, return (frame_ms, blas_build_s, tlas_build_ms)."""
+    flat = flat_build(verts, object_counts, use_tlas=tlas, max_prims_per_leaf=max_prims_per_leaf, threads=threads)
+    scene = Scene(flat, device=device)
+    try:
+        eye, look_at, fov = camera
+        view = view_from_camera(eye, look_at, fov, width, height)
+        mn, _mean = scene.bench_primary(view, width, height, sem=sem, warmup=1 if benchmark else 0, frames=frames)
+        return mn, flat.blas_build_s, flat.tlas_build_s * 1000.0
+    finally:
+        scene.close()
