@@ -740,7 +740,7 @@ int trx_bvh_build_tris(const float *verts, uint64_t n, uint32_t max_prims, int t
     bp.threads = threads;
     try {
         build_cwbvh_from_tris(verts, n, bp, b->bvh);
-    } catch (const std::bad_alloc &) {
+    } catch (const std::exception &) {
         delete b;
         return fail(TRX_ERR_OOM, "out of memory building the BVH");
     }
@@ -759,7 +759,7 @@ int trx_bvh_build_aabbs(const float *aabbs, uint64_t n, uint32_t max_prims, int 
     bp.threads = threads;
     try {
         build_cwbvh_from_aabbs((const Aabb *)aabbs, n, bp, b->bvh);
-    } catch (const std::bad_alloc &) {
+    } catch (const std::exception &) {
         delete b;
         return fail(TRX_ERR_OOM, "out of memory building the BVH");
     }
@@ -865,7 +865,7 @@ int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32
             return fail(TRX_ERR_OOM, "host allocation failed");
         }
         *out = f;
-    } catch (const std::bad_alloc &) {
+    } catch (const std::exception &) {
         return fail(TRX_ERR_OOM, "out of memory building the scene");
     }
     return TRX_OK;
@@ -910,7 +910,7 @@ int trx_gen_scene(const char *name, uint64_t n_tris, uint64_t seed, float **out_
     std::vector<uint64_t> objects;
     try {
         if (!gen_scene(name, n_tris, seed, verts, objects)) return fail(TRX_ERR_INVALID, "unknown scene '%s'", name);
-    } catch (const std::bad_alloc &) {
+    } catch (const std::exception &) {
         return fail(TRX_ERR_OOM, "out of memory generating '%s'", name);
     }
     return export_mesh(verts, objects, out_verts, out_n, out_counts, out_nobj);
@@ -928,7 +928,7 @@ int trx_load_model(const char *path, float **out_verts, uint64_t *out_n, uint64_
     std::vector<uint64_t> objects;
     try {
         if (!load_model(path, verts, objects)) return fail(TRX_ERR_IO, "Error while loading model file \"%s\"", path);
-    } catch (const std::bad_alloc &) {
+    } catch (const std::exception &) {
         return fail(TRX_ERR_OOM, "out of memory loading '%s'", path);
     }
     return export_mesh(verts, objects, out_verts, out_n, out_counts, out_nobj);

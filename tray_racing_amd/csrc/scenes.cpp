@@ -311,7 +311,17 @@ void pad_with_leaves(Mesh &m, Pcg32 &rng, uint64_t target, const std::vector<V3>
     }
 }
 void truncate(Mesh &m, uint64_t target) {
-    if (m.tris() > target) m.v.resize(target * 9);
+    if (m.tris() <= target) return;
+    m.v.resize(target * 9);
+    // drop / trim objects that were already closed beyond the cut
+    uint64_t sum = 0;
+    size_t keep = 0;
+    for (; keep < m.objects.size(); keep++) {
+        if (sum + m.objects[keep] > target) break;
+        sum += m.objects[keep];
+    }
+    m.objects.resize(keep);
+    m.open_start = sum;
 }
 
 // ---- scenes ---------------------------------------------------------------------
