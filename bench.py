@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s, primary rays, bistro-class scene, 1920x1080, CWBVH, N x MI355X.
+
+A step is one pass of the hot path over one 1920x1080 frame of primary rays
+(2,073,600 rays generated in-kernel; scene resident in HBM before the timed
+region).  With N > 1 (one process per GPU under torch.distributed.run) the
+frame's 8x8 tiles are dealt round-robin to the ranks (tile % N == rank), each
+rank traces its tiles into a compact shard buffer and ONE all-gather (RCCL)
+assembles the frame on every rank; step k's gather overlaps step k+1's kernel.
+Total work is fixed as N grows: "scaling": "strong".
+
+The reference's Bistro asset is absent (assets/large_obj is git-ignored), so
+the workload is the seeded procedural bistro-class stand-in with Bistro's
+triangle count (3,872,303) and the camera of assets/scenes/bistro.ron; pass
+--model / --scene-ron style inputs through tools/ when the real OBJ is present.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+TRI_BYTES = 48         # device triangle record actually fetched per test
+NODE_BYTES = 80
+HIT_BYTES = 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scene", default="bistro")
+    ap.add_argument("--tris", type=int, default=0, help="0 = the scene's reference triangle count")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sem", type=int, default=3, help="trx_semantics bits (3 = TRX_SEM_CPU)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import tray_racing_amd as T
+    from tray_racing_amd import dist as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    lib = T.load()
+    if lib.trx_device_count() <= local_rank:
+        raise SystemExit("no HIP device %d (libtrx.so has no CPU fallback)" % local_rank)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w, h = args.width, args.height
+    threads = max(1, (os.cpu_count() or 8) // world)
+    verts, counts = T.gen_scene(args.scene, args.tris, 1)
+    t0 = time.time()
+    flat = T.flat_build(verts, counts, use_tlas=False, threads=threads)
+    build_s = time.time() - t0
+    eye, look, fov = T.scene_camera(args.scene)
+    view = T.view_from_camera(eye, look, fov, w, h)
+    scene = T.Scene(flat, device=local_rank)
+    stream = torch.cuda.current_stream()
+    sp = stream.cuda_stream
+
+    shard_img = (rank, world, 0)
+    shard_cmp = (rank, world, 1)
+    n_rays_total = w * h
+    fg = D.FrameGather(w, h, rank, world, "cuda")
+    locals_ = [fg.new_local(), fg.new_local()]
+    frame = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
+
+    # algorithmic bytes of ONE launch on this rank (counting kernel = the reference's PROFILE_RT counters)
+    st = scene.count_primary(view, w, h, sem=args.sem, shard=shard_img)
+    launch_bytes = NODE_BYTES * st.n_node + TRI_BYTES * st.n_tri + HIT_BYTES * st.n_rays
+
+    def step(k, works):
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        if world == 1:
+            # one GPU owns every tile: the kernel writes the row-major frame directly
+            ev0.record(stream)
+            scene.trace_primary_dev(view, w, h, frame.data_ptr(), sem=args.sem, shard=shard_img, stream=sp)
+            ev1.record(stream)
+            return ev0, ev1
+        buf = locals_[k & 1]
+        ev0.record(stream)
+        scene.trace_primary_dev(view, w, h, buf.data_ptr(), sem=args.sem, shard=shard_cmp, stream=sp)
+        ev1.record(stream)
+        if k > 0:
+            works[(k - 1) & 1].wait()
+            fg.assemble(frame)
+        works[k & 1] = fg.gather(buf, async_op=True)
+        return ev0, ev1
+
+    def finish(k_last, works):
+        if world > 1:
+            works[k_last & 1].wait()
+            fg.assemble(frame)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    works = [None, None]
+    for k in range(args.warmup):
+        step(k, works)
+    if args.warmup:
+        finish(args.warmup - 1, works)
+    sync_all()
+    t0 = time.perf_counter()
+    events = []
+    for k in range(args.steps):
+        events.append(step(k, works))
+    finish(args.steps - 1, works)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    scene.check(sp)
+
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+    t = torch.tensor([elapsed, kernel_ms * 1e-3, float(launch_bytes)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+    value = n_rays_total * args.steps / elapsed / 1e6
+
+    out = None
+    if rank == 0:
+        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "Mrays/s primary rays, Bistro 1920x1080 CWBVH, 1/2/4/8 MI355X",
+            "value": round(value, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s-class procedural stand-in, %d tris, %d CWBVH nodes, primary rays %dx%d "
+                            "(BASELINE.json configs[2])" % (args.scene, flat.n_tris, flat.n_nodes, w, h),
+                "semantics": "TRX_SEM_CPU" if args.sem == 3 else "bits=%d" % args.sem,
+                "builder": "binned-SAH BVH2 -> SAH-optimal BVH8 collapse (stands in for obvhs ploc_cwbvh)",
+                "parallelism": "8x8 tiles round-robin over %d rank(s), one all_gather of 8 B/ray per frame" % world,
+                "build_seconds": round(build_s, 2),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "kernel_ms": round(kernel_ms, 4),
+                "bytes_per_launch": int(launch_bytes),
+                "nodes_per_ray": round(st.n_node / max(st.n_rays, 1), 3),
+                "tris_per_ray": round(st.n_tri / max(st.n_rays, 1), 3),
+            },
+        }
+
+    # CPU baseline: the oracle (a port, not the reference binary) on the host cores, rank 0 at N=1 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import binding as O
+        osc = O.Scene.from_flat(flat)
+        ov = O.view_from_bytes(view)
+        cores = os.cpu_count() or 1
+        hits, ost = osc.trace_primary(ov, w, h, sem=args.sem, threads=cores)  # one full frame
+        frames, secs = 1, ost.seconds
+        while secs < args.cpu_seconds and frames < 64:
+            _, s2 = osc.trace_primary(ov, w, h, sem=args.sem, threads=cores, out=hits)
+            frames += 1
+            secs += s2.seconds
+        gpu = D.int64_to_hits(frame)
+        parity = bool((gpu["t"].view(np.uint32) == hits["t"].view(np.uint32)).all() and
+                      (gpu["prim"] == hits["prim"]).all())
+        out["cpu_baseline"] = {
+            "value": round(n_rays_total * frames / secs / 1e6, 3),
+            "unit": "Mrays/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": "%d full %dx%d frame(s) of the same workload, %.1f s, OpenMP over 8x8 tiles" % (frames, w, h, secs),
+        }
+        out["parity_vs_oracle_full_frame"] = parity
+        if not parity:
+            print("WARNING: GPU frame differs from the oracle frame", file=sys.stderr)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -126,12 +126,23 @@ typedef struct trx_rayhit {
 
 /* Which pixels of the w*h image this call (this GPU) traces: 8x8-pixel tiles
  * are numbered row-major; a call traces tiles with (tile % count) == index.
- * {0,1} = whole image.  Output buffers are ALWAYS indexed by full-image pixel
- * id (y*w + x); untouched pixels are left as they were. */
+ * {0,1,0,0} = whole image.
+ * layout 0 (TRX_LAYOUT_IMAGE): hit buffers are indexed by full-image pixel id
+ * (y*w + x); pixels of other shards are left as they were.
+ * layout 1 (TRX_LAYOUT_SHARD): hit buffers are compact, indexed by
+ * local_tile*64 + (y&7)*8 + (x&7) with local_tile = tile / count; they hold
+ * trx_shard_tiles() * 64 records (records of pixels outside the image are not
+ * written).  This is the buffer a rank hands to the end-of-frame gather. */
+#define TRX_LAYOUT_IMAGE 0u
+#define TRX_LAYOUT_SHARD 1u
 typedef struct trx_shard {
     uint32_t index;
     uint32_t count;
+    uint32_t layout;
+    uint32_t _pad;
 } trx_shard;
+/* Number of 8x8 tiles of a width x height image that belong to `shard`. */
+uint32_t trx_shard_tiles(uint32_t width, uint32_t height, trx_shard shard);
 
 /* Per-call counters (optional; pass NULL).  n_node / n_tri are the PROFILE_RT
  * counters of the reference (aabb_hit_count/8 and tri_hit_count,

@@ -1,0 +1,107 @@
+"""Generates the committed golden fixtures in this directory.
+
+PARITY UNPINNED: the reference holds no golden vectors for this path and cannot
+be executed, so these fixtures are produced by this repo's own
+CPU oracle: `bf_*` arrays come from the BVH-independent brute-force query
+(every ray against every triangle), `orc_*` arrays from the CWBVH restatement.
+Each .npz carries its INPUTS (80-byte nodes, triangles, instance table, view)
+and the expected outputs, so the tests do not depend on the builder or on
+/root/reference being present.
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import tray_racing_amd as T  # noqa: E402
+from oracle import binding as O  # noqa: E402
+
+SEMS = (0, 3)  # TRX_SEM_HLSL, TRX_SEM_CPU
+
+
+def view_bytes(view):
+    import ctypes
+    return np.frombuffer(ctypes.string_at(ctypes.byref(view), ctypes.sizeof(view)), dtype=np.uint8).copy()
+
+
+def tie_scene():
+    """Axis-aligned unit-quad grids: rays through grid vertices / along edges hit
+    up to six triangles at exactly the same t (and have zero direction components)."""
+    tris = []
+    for z in (0.0, -1.5):
+        for i in range(-4, 4):
+            for j in range(-4, 4):
+                a, b, c, d = (i, j, z), (i + 1, j, z), (i + 1, j + 1, z), (i, j + 1, z)
+                tris.append(a + b + c)
+                tris.append(a + c + d)
+    verts = np.array(tris, dtype=np.float32)
+    rays = []
+    for x in np.arange(-4, 4.5, 0.5):
+        for y in np.arange(-4, 4.5, 0.5):
+            rays.append(((x, y, 3.0), (0.0, 0.0, -1.0)))       # straight down: two zero components
+            rays.append(((x, y, 3.0), (0.0, 0.6, -0.8)))       # one zero component, crosses edges
+    rays.append(((0.25, 0.25, -0.75), (0.0, 0.0, 1.0)))        # from between the sheets, upwards
+    r = np.zeros(len(rays), dtype=T.RAY_DTYPE)
+    r["origin"] = np.array([o for o, _ in rays], dtype=np.float32)
+    r["direction"] = np.array([d for _, d in rays], dtype=np.float32)
+    r["tmin"] = 0.0
+    r["tmax"] = O.F32_MAX
+    return verts, r
+
+
+def save(name, flat, view, w, h, extra):
+    osc = O.Scene.from_flat(flat)
+    out = dict(nodes=flat.nodes, tri_verts=flat.tri_verts, instance_offsets=flat.instance_offsets,
+               tlas_start=np.uint32(flat.tlas_start), width=np.uint32(w), height=np.uint32(h))
+    if view is not None:
+        ov = O.view_from_bytes(view)
+        out["view"] = view_bytes(view)
+        for sem in SEMS:
+            prim, st = osc.trace_primary(ov, w, h, sem=sem)
+            out["orc_primary_sem%d" % sem] = prim
+            out["orc_counts_sem%d" % sem] = np.array([st.n_node, st.n_tri, st.n_hits, st.max_stack], dtype=np.uint64)
+            out["bf_primary_sem%d" % sem] = osc.brute_primary(ov, w, h, sem=sem)
+            ao, _ = osc.trace_ao(ov, w, h, prim, sem=sem, frame=2, ao_eps=0.01)
+            out["orc_ao_sem%d" % sem] = ao
+    out.update(extra(osc) if extra else {})
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()}, os.path.getsize(path), "bytes")
+
+
+def main():
+    # 1. Cornell-class box (5 objects), camera of assets/scenes/cornell_box.ron
+    verts, counts = T.gen_scene("cornell", 0, 1)
+    eye, look, fov = T.scene_camera("cornell")
+    flat = T.flat_build(verts, counts, use_tlas=False)
+    save("cornell_64", flat, T.view_from_camera(eye, look, fov, 64, 64), 64, 64, None)
+    # 2. same geometry, one BLAS per object + TLAS
+    flat = T.flat_build(verts, counts, use_tlas=True)
+    save("cornell_tlas_48", flat, T.view_from_camera(eye, look, fov, 48, 48), 48, 48, None)
+    # 3. random triangle soup, image size not a multiple of 8
+    verts, counts = T.gen_scene("soup", 1500, 7)
+    eye, look, fov = T.scene_camera("soup")
+    flat = T.flat_build(verts, counts)
+    save("soup_52x44", flat, T.view_from_camera(eye, look, fov, 52, 44), 52, 44, None)
+    # 4. exact ties and zero direction components, explicit rays
+    verts, rays = tie_scene()
+    flat = T.flat_build(verts)
+
+    def tie_extra(osc):
+        e = {"rays": rays}
+        for sem in SEMS:
+            e["orc_rays_sem%d" % sem] = osc.trace_rays(rays, sem=sem)[0]
+            e["bf_rays_sem%d" % sem] = osc.brute_rays(rays, sem=sem)
+        return e
+
+    save("ties_rays", flat, None, 0, 0, tie_extra)
+
+
+if __name__ == "__main__":
+    main()

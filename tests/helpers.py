@@ -1,0 +1,126 @@
+"""Shared helpers for the test-suite (scene construction, comparisons)."""
+import numpy as np
+
+F32_MAX = 3.4028234663852886e38
+ALL_SEMS = (0, 1, 2, 3, 4, 5, 6, 7)
+
+
+def make_scene(T, O, name, n, w, h, tlas=False, seed=1):
+    verts, counts = T.gen_scene(name, n, seed)
+    flat = T.flat_build(verts, counts, use_tlas=tlas)
+    eye, look, fov = T.scene_camera(name)
+    view = T.view_from_camera(eye, look, fov, w, h)
+    osc = O.Scene.from_flat(flat)
+    return flat, view, osc, O.view_from_bytes(view)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def assert_hits_equal(got, want, what=""):
+    """Bit-exact on t (covers +inf) and exact on prim."""
+    bt = np.flatnonzero(bits(got["t"]) != bits(want["t"]))
+    bp = np.flatnonzero(got["prim"] != want["prim"])
+    assert bt.size == 0 and bp.size == 0, "%s: %d t mismatches (first %s), %d prim mismatches (first %s)" % (
+        what, bt.size, bt[:5], bp.size, bp[:5])
+
+
+def random_rays(T, flat, n, seed, zero_dirs=True):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, dtype=T.RAY_DTYPE)
+    pts = flat.tri_verts.reshape(-1, 3)
+    lo, hi = pts.min(0), pts.max(0)
+    pad = 0.1 * (hi - lo) + 1e-3
+    rays["origin"] = rng.uniform(lo - pad, hi + pad, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    if zero_dirs and n >= 64:
+        d[0:8, 0] = 0.0
+        d[8:16, 1] = 0.0
+        d[16:24, 2] = 0.0
+        d[24:28, 0:2] = 0.0
+        d[28:32] = np.array([[1, 0, 0], [0, -1, 0], [0, 0, 1], [-1, 0, 0]], dtype=np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays["direction"] = d
+    rays["tmin"] = 0.0
+    rays["tmax"] = F32_MAX
+    rays["tmax"][::7] = np.float32(0.5 * float(np.linalg.norm(hi - lo)))
+    rays["tmin"][::11] = np.float32(0.05 * float(np.linalg.norm(hi - lo)))
+    return rays
+
+
+# ---- hand-made CWBVH nodes (an independent restatement of the encoder,
+# embree/src/bvh_embree_to_cwbvh.rs:85-186, used to craft adversarial trees) -------------
+
+def encode_node(box_min, box_max, children, child_base, prim_base):
+    """children: list of 8 entries, each None | ("inner", lo, hi) | ("leaf", lo, hi, n_tris)."""
+    import math
+    node = np.zeros(20, dtype=np.uint32)
+    b = node.view(np.uint8)
+    p = np.asarray(box_min, dtype=np.float32)
+    node[:3] = p.view(np.uint32)
+    e = np.zeros(3)
+    for k in range(3):
+        ext = max(float(box_max[k]) - float(box_min[k]), 1e-20) / 255.0
+        ex = math.ceil(math.log2(ext))
+        while math.ceil((float(box_max[k]) - float(p[k])) / 2.0 ** ex) > 255:
+            ex += 1
+        e[k] = 2.0 ** ex
+        b[12 + k] = ex + 127
+    imask, tri_total = 0, 0
+    for s, c in enumerate(children):
+        if c is None:
+            continue
+        lo, hi = np.asarray(c[1], float), np.asarray(c[2], float)
+        for k in range(3):
+            b[32 + 16 * k + s] = int(min(max(math.floor((lo[k] - float(p[k])) / e[k]), 0), 255))
+            b[32 + 16 * k + 8 + s] = int(min(max(math.ceil((hi[k] - float(p[k])) / e[k]), 0), 255))
+        if c[0] == "inner":
+            imask |= 1 << s
+            b[24 + s] = 0x20 | (24 + s)
+        else:
+            b[24 + s] = tri_total | {1: 0x20, 2: 0x60, 3: 0xE0}[c[3]]
+            tri_total += c[3]
+    b[15] = imask
+    node[4] = child_base
+    node[5] = prim_base
+    return node
+
+
+def deep_chain_scene(depth):
+    """A CWBVH whose traversal stack reaches `depth` entries for the ray (0.3,0.3,1)->(0,0,-1):
+    node k has two inner children, the rest of the chain (visited first) and a terminal node
+    holding triangle k at z = -k (left pending on the stack).  The closest hit is triangle 0 at t = 1."""
+    tris, nodes = [], []
+    lo_xy, hi_xy = (0.0, 0.0), (1.0, 1.0)
+    # the fixed-up direction (eps, eps, -1) has oct_inv = 6: slot s goes to bit 24 + (s ^ 6), the
+    # highest bit is visited first, so slot 1 (bit 31) holds the chain and slot 0 (bit 30) the terminal
+    for k in range(depth):
+        tris.append([0, 0, -k, 1, 0, -k, 0, 1, -k])
+    # layout: node 2k = chain node k, node 2k+1 = terminal node k; last chain node is a plain leaf node
+    for k in range(depth):
+        zt = -float(k)
+        term_box = ((*lo_xy, zt), (*hi_xy, zt))
+        if k < depth - 1:
+            chain_box = ((*lo_xy, -float(depth - 1)), (*hi_xy, zt - 1.0))
+            kids = [None] * 8
+            kids[1] = ("inner", *chain_box)
+            kids[0] = ("inner", *term_box)
+            # children stored in slot order: slot 0 (terminal) first, then slot 1 (chain)
+            nodes.append(("chain", k, (*lo_xy, -float(depth - 1)), (*hi_xy, zt), kids))
+        else:
+            nodes.append(("last", k, (*lo_xy, zt), (*hi_xy, zt), None))
+    out = []
+    # index plan: chain node k at index 2k, its terminal at 2k+1, next chain node at 2k+2;
+    # child_base of chain node k = 2k+1 (slot 0 -> 2k+1, slot 1 -> 2k+2)
+    for kind, k, bmin, bmax, kids in nodes:
+        if kind == "chain":
+            out.append(encode_node(bmin, bmax, kids, 2 * k + 1, 0))
+            leaf = [None] * 8
+            leaf[0] = ("leaf", (*lo_xy, -float(k)), (*hi_xy, -float(k)), 1)
+            out.append(encode_node((*lo_xy, -float(k)), (*hi_xy, -float(k)), leaf, 0, k))
+        else:
+            leaf = [None] * 8
+            leaf[0] = ("leaf", bmin, bmax, 1)
+            out.append(encode_node(bmin, bmax, leaf, 0, k))
+    return np.array(out, dtype=np.uint32), np.array(tris, dtype=np.float32)

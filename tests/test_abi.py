@@ -1,0 +1,117 @@
+"""The C-ABI library: loads without a GPU, exports every symbol include/trx.h
+declares, and fails loudly (never falls back to a CPU path)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "trx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(trx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(trx):
+    from tray_racing_amd import _lib
+    declared = declared_symbols()
+    assert len(declared) >= 35
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (trx_[a-z0-9_]+)", out))
+    assert set(declared) <= exported, sorted(set(declared) - exported)
+    assert set(declared) == set(_lib.SIGNATURES), sorted(set(declared) ^ set(_lib.SIGNATURES))
+    lib = trx.load()
+    assert lib.trx_abi_version() == 1
+    assert [lib.trx_tri_format_bytes(f) for f in (0, 1, 2, 3)] == [24, 36, 36, 0]
+
+
+def test_struct_sizes_match_the_header(trx):
+    from tray_racing_amd import _lib
+    assert C.sizeof(_lib.View) == 160 and C.sizeof(_lib.Ray) == 32 and C.sizeof(_lib.Hit) == 8
+    assert C.sizeof(_lib.RayHit) == 16 and C.sizeof(_lib.Shard) == 16 and C.sizeof(_lib.Stats) == 48
+    assert trx.HIT_DTYPE.itemsize == 8 and trx.RAY_DTYPE.itemsize == 32
+
+
+def test_product_never_references_the_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "tray_racing_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.replace("oracle's", "").replace("the oracle", "").replace("an oracle", ""), \
+                    os.path.join(dirpath, f)
+    from tray_racing_amd import _lib
+    needed = subprocess.check_output(["readelf", "-d", _lib.LIB_PATH]).decode()
+    assert "liboracle" not in needed
+    syms = subprocess.check_output(["nm", "-D", _lib.LIB_PATH]).decode()
+    assert "orc_" not in syms
+
+
+def test_shard_tiles(trx):
+    from tray_racing_amd import _lib, dist
+    lib = trx.load()
+    for w, h in [(1920, 1080), (52, 44), (8, 8), (3, 3)]:
+        for world in (1, 2, 3, 8):
+            got = [lib.trx_shard_tiles(w, h, _lib.Shard(r, world, 0, 0)) for r in range(world)]
+            assert got == [dist.shard_tiles(w, h, r, world) for r in range(world)]
+            assert sum(got) == ((w + 7) // 8) * ((h + 7) // 8)
+
+
+def test_invalid_arguments_are_reported_not_fatal(trx):
+    lib = trx.load()
+    from tray_racing_amd import _lib
+    flat = trx.flat_build(trx.gen_scene("soup", 50, 1)[0])
+    h = C.c_void_p()
+    P = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = lib.trx_scene_create(None, 0, None, 0, 1, None, 0, 0, 0, C.byref(h))
+    assert rc == _lib.TRX_ERR_INVALID and b"empty node buffer" in lib.trx_last_error()
+    rc = lib.trx_scene_create(P(flat.nodes), flat.n_nodes, P(flat.tri_verts), flat.n_tris, 9, None, 0, 0, 0, C.byref(h))
+    assert rc == _lib.TRX_ERR_INVALID and b"tri_format" in lib.trx_last_error()
+    v = _lib.View()
+    rc = lib.trx_view_from_camera((C.c_float * 3)(0, 0, 0), (C.c_float * 3)(0, 0, 0), 90.0, 8.0, 8.0, C.byref(v))
+    assert rc == _lib.TRX_ERR_INVALID
+    with pytest.raises(trx.TrxError, match="unknown scene"):
+        trx.gen_scene("no_such_scene")
+    with pytest.raises(trx.TrxError, match="Error while loading"):
+        trx.load_meshs("/nonexistent/model.obj")
+
+
+def test_malformed_nodes_are_rejected_before_any_kernel_runs(trx):
+    """Structural validation happens on the host: an out-of-range child or primitive
+    index would make a kernel read out of bounds."""
+    lib = trx.load()
+    from tray_racing_amd import _lib
+    flat = trx.flat_build(trx.gen_scene("soup", 400, 1)[0])
+    P = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+
+    def create(nodes, n_tris=flat.n_tris):
+        h = C.c_void_p()
+        return lib.trx_scene_create(P(nodes), nodes.shape[0], P(flat.tri_verts), n_tris, 1, None, 0, 0, 0, C.byref(h))
+
+    bad = flat.nodes.copy()
+    bad[0, 4] = 10**9                                   # child_base_idx far outside
+    assert create(bad) == _lib.TRX_ERR_FORMAT and b"children" in lib.trx_last_error()
+    assert create(flat.nodes, n_tris=flat.n_tris - 10) == _lib.TRX_ERR_FORMAT   # primitives out of range
+    bad = flat.nodes.copy()
+    bad.view(np.uint8).reshape(-1, 80)[0, 15] ^= 0xFF   # imask disagrees with child_meta
+    assert create(bad) == _lib.TRX_ERR_FORMAT and b"imask" in lib.trx_last_error()
+    bad = flat.nodes.copy()
+    meta = bad.view(np.uint8).reshape(-1, 80)[:, 24:32]
+    i, s = np.argwhere((meta != 0) & ((meta & 0x18) != 0x18))[0]
+    meta[i, s] = 0xA0 | (meta[i, s] & 0x1F)             # 0b101 is not a unary count
+    assert create(bad) == _lib.TRX_ERR_FORMAT and b"leaf meta" in lib.trx_last_error()
+
+
+def test_no_cpu_fallback_without_a_device(trx, has_gpu):
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    flat = trx.flat_build(trx.gen_scene("soup", 50, 1)[0])
+    with pytest.raises(trx.TrxError) as e:
+        trx.Scene(flat)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)

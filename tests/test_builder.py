@@ -1,0 +1,99 @@
+"""Host-side CWBVH construction: structure of the 80-byte nodes and of the flat
+buffers cwbvh_gpu_runner assembles (src/rt_gpu/mod.rs:16-112)."""
+import numpy as np
+import pytest
+
+from helpers import make_scene
+
+
+def node_fields(nodes):
+    b = nodes.view(np.uint8).reshape(-1, 80)
+    return dict(e=b[:, 12:15], imask=b[:, 15], child_base=nodes[:, 4], prim_base=nodes[:, 5], meta=b[:, 24:32])
+
+
+@pytest.mark.parametrize("name,n,tlas", [("cornell", 0, False), ("cornell", 0, True), ("kitchen", 9000, False),
+                                          ("kitchen", 9000, True), ("bistro", 40000, False), ("hairball", 8000, False),
+                                          ("san_miguel", 40000, True), ("demoscene", 20000, False), ("soup", 3000, False)])
+def test_built_bvh_is_structurally_sound(trx, orc, name, n, tlas):
+    flat, _v, osc, _ov = make_scene(trx, orc, name, n, 8, 8, tlas=tlas)
+    assert osc.validate() == (0, "")
+    f = node_fields(flat.nodes)
+    meta = f["meta"]
+    inner = (meta & 0x18) == 0x18
+    # imask mirrors the inner slots; inner meta is 0b001_11sss (embree/src/bvh_embree_to_cwbvh.rs:153-154)
+    assert (np.packbits(inner[:, ::-1], axis=1)[:, 0] == f["imask"]).all()
+    slots = np.arange(8, dtype=np.uint8)[None, :]
+    assert (meta[inner] == ((0x20 | (24 + slots)) * np.ones_like(meta))[inner]).all()
+    # leaves: unary count in the top 3 bits, running offset below, at most 24 per node (:159-167)
+    leaf = (meta != 0) & ~inner
+    cnt = np.select([(meta >> 5) == 1, (meta >> 5) == 3, (meta >> 5) == 7], [1, 2, 3], 0) * leaf
+    assert (cnt[leaf] > 0).all() and cnt.sum(1).max() <= 24
+    # exponent bytes are biased IEEE exponents of a positive power of two (:104-110)
+    assert (f["e"] > 0).all() and (f["e"] < 255).all()
+    # triangles were permuted into primitive_indices order; tri_source is that permutation
+    assert sorted(flat.tri_source.tolist()) == list(range(flat.n_tris))
+    verts, _ = trx.gen_scene(name, n, 1)
+    assert (flat.tri_verts == verts[flat.tri_source]).all()
+    if tlas:
+        assert flat.has_tlas and flat.tlas_start > 0
+        assert (flat.instance_offsets < flat.tlas_start).all()
+        assert len(set(flat.instance_offsets.tolist())) == flat.instance_offsets.size
+        assert flat.blas_tri_start[0] == 0 and flat.blas_tri_start[-1] == flat.n_tris
+        assert (np.diff(flat.blas_tri_start.astype(np.int64)) > 0).all()
+    else:
+        assert not flat.has_tlas and flat.tlas_start == 0
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 9, 25])
+def test_tiny_inputs(trx, orc, n):
+    verts, _ = trx.gen_scene("soup", max(n, 1), 5)
+    verts = verts[:n]
+    flat = trx.flat_build(verts)
+    assert flat.n_tris == n and flat.n_nodes >= 1
+    osc = orc.Scene.from_flat(flat) if n else None
+    if n:
+        assert osc.validate() == (0, "")
+        eye, look, fov = trx.scene_camera("soup")
+        ov = orc.view_from_bytes(trx.view_from_camera(eye, look, fov, 24, 24))
+        got, _ = osc.trace_primary(ov, 24, 24)
+        bf = osc.brute_primary(ov, 24, 24)
+        assert (got["t"].view(np.uint32) == bf["t"].view(np.uint32)).all()
+    else:
+        f = node_fields(flat.nodes)
+        assert (f["meta"] == 0).all() and f["imask"][0] == 0
+
+
+def test_duplicate_and_degenerate_triangles(trx, orc):
+    one = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], dtype=np.float32)
+    verts = np.concatenate([np.repeat(one, 40, axis=0),            # 40 identical triangles (identical centroids)
+                            np.zeros((5, 9), np.float32),          # zero-area triangles at the origin
+                            one + np.float32(2.0)])
+    flat = trx.flat_build(verts)
+    osc = orc.Scene.from_flat(flat)
+    assert osc.validate() == (0, "")
+    rays = np.zeros(2, dtype=orc.RAY_DTYPE)
+    rays["origin"] = [(0.25, 0.25, 5), (2.25, 2.25, 5)]
+    rays["direction"] = [(0, 0, -1), (0, 0, -1)]
+    rays["tmax"] = 3.4e38
+    got, _ = osc.trace_rays(rays)
+    assert got["t"][0] == 5.0 and got["t"][1] == 3.0
+    assert flat.tri_source[got["prim"][0]] < 40 and flat.tri_source[got["prim"][1]] == 45
+
+
+@pytest.mark.parametrize("max_prims", [1, 2, 3])
+def test_max_prims_per_leaf(trx, max_prims):
+    verts, _ = trx.gen_scene("soup", 2000, 2)
+    flat = trx.flat_build(verts, max_prims_per_leaf=max_prims)
+    meta = node_fields(flat.nodes)["meta"]
+    leaf = (meta != 0) & ((meta & 0x18) != 0x18)
+    cnt = np.select([(meta >> 5) == 1, (meta >> 5) == 3, (meta >> 5) == 7], [1, 2, 3], 0)[leaf]
+    assert cnt.max() <= max_prims and cnt.sum() == 2000
+    with pytest.raises(trx.TrxError, match="maximum of 3 primitives"):  # src/main.rs:176-178
+        trx.flat_build(verts, max_prims_per_leaf=4)
+
+
+def test_build_is_deterministic_across_thread_counts(trx):
+    verts, counts = trx.gen_scene("kitchen", 30000, 1)
+    a = trx.flat_build(verts, counts, threads=1)
+    b = trx.flat_build(verts, counts, threads=4)
+    assert (a.nodes == b.nodes).all() and (a.tri_source == b.tri_source).all()

@@ -1,0 +1,103 @@
+"""world_size-2 coverage of the multi-GPU path on CPU (gloo): tile sharding, the one
+all-gather of compact hit shards, and re-assembly into the row-major frame.  The shards
+are produced by the oracle here (no GPU); on the GPU box the same FrameGather code moves
+device tensors over RCCL (tests/test_gpu_parity.py checks the kernel's shard layout)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H = 52, 44  # not multiples of 8: edge tiles are partial
+
+
+def oracle_compact_shard(osc, ov, w, h, rank, world, records):
+    """What trx_trace_primary_dev writes with TRX_LAYOUT_SHARD, computed by the oracle."""
+    from oracle import binding as O
+    full = np.zeros(w * h, dtype=O.HIT_DTYPE)
+    osc.trace_primary(ov, w, h, sem=3, shard=(rank, world), out=full)
+    out = np.zeros(records, dtype=O.HIT_DTYPE)
+    out["t"] = np.inf
+    out["prim"] = 0xFFFFFFFF
+    tx = (w + 7) // 8
+    n_tiles = tx * ((h + 7) // 8)
+    for lt in range(records // 64):
+        tile = lt * world + rank
+        if tile >= n_tiles:
+            break
+        for k in range(64):
+            px, py = (tile % tx) * 8 + (k & 7), (tile // tx) * 8 + (k >> 3)
+            if px < w and py < h:
+                out[lt * 64 + k] = full[py * w + px]
+    return out
+
+
+def worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import tray_racing_amd as T
+        from oracle import binding as O
+        from tray_racing_amd import dist as D
+        from helpers import make_scene
+        _flat, _v, osc, ov = make_scene(T, O, "cornell", 0, W, H)
+        fg = D.FrameGather(W, H, rank, world, "cpu")
+        local = fg.new_local()
+        shard = oracle_compact_shard(osc, ov, W, H, rank, world, fg.records)
+        local.copy_(D.hits_to_int64(shard))
+        work = fg.gather(local, async_op=True)
+        work.wait()
+        frame = D.int64_to_hits(fg.assemble())
+        want, _ = osc.trace_primary(ov, W, H, sem=3)
+        ok = bool((frame["t"].view(np.uint32) == want["t"].view(np.uint32)).all() and
+                  (frame["prim"] == want["prim"]).all())
+        # timing reduce used by bench.py: max over ranks
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        q.put((rank, ok, float(t[0]), D.shard_tiles(W, H, rank, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_tile_sharding_and_gather():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in results] == [True, True]
+    assert [r[2] for r in results] == [2.0, 2.0]
+    assert sum(r[3] for r in results) == ((W + 7) // 8) * ((H + 7) // 8)
+
+
+def test_record_index_table_covers_every_pixel_once():
+    sys.path.insert(0, ROOT)
+    from tray_racing_amd import dist as D
+    for w, h, world in [(52, 44, 2), (1920, 1080, 8), (64, 64, 3), (8, 8, 4)]:
+        idx = D.pixel_index_of_records(w, h, world).view(-1)
+        valid = idx[idx >= 0]
+        assert valid.numel() == w * h and torch.unique(valid).numel() == w * h
+        assert idx.numel() == world * D.max_shard_tiles(w, h, world) * 64

@@ -1,0 +1,395 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the oracle.
+
+Bar: bit-exact t (IEEE-754 binary32, same operation order on both sides) and
+exact primitive indices.  Run with `-m gpu` on an MI355X."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import (ALL_SEMS, F32_MAX, assert_hits_equal, bits, deep_chain_scene, make_scene, random_rays)
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu(trx):
+    lib = trx.load()  # raises if libtrx.so is missing: the HIP extension is mandatory here
+    assert lib.trx_device_count() > 0, "no HIP device visible to libtrx.so"
+    buf = C.create_string_buffer(64)
+    lib.trx_device_name(0, buf, 64)
+    assert buf.value.startswith(b"gfx950"), buf.value
+
+
+class GoldenFlat:
+    def __init__(self, trx, g):
+        self.flat = trx.FlatScene(g["nodes"], g["tri_verts"], g["instance_offsets"], int(g["tlas_start"]),
+                                  np.arange(g["tri_verts"].shape[0]), [0, g["tri_verts"].shape[0]])
+
+
+def load_view(trx, raw):
+    from tray_racing_amd import _lib
+    v = _lib.View()
+    C.memmove(C.byref(v), raw.tobytes(), C.sizeof(v))
+    return v
+
+
+# ---- golden fixtures -----------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["cornell_64", "cornell_tlas_48", "soup_52x44"])
+def test_golden_images(trx, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sc = trx.Scene(GoldenFlat(trx, g).flat)
+    w, h = int(g["width"]), int(g["height"])
+    view = load_view(trx, g["view"])
+    for sem in (0, 3):
+        prim, ao, ms = sc.trace_primary_ao(view, w, h, sem=sem, frame=2, ao_eps=0.01)
+        assert ms > 0
+        assert_hits_equal(prim, g["orc_primary_sem%d" % sem], "%s sem %d primary" % (name, sem))
+        assert_hits_equal(ao, g["orc_ao_sem%d" % sem], "%s sem %d ao" % (name, sem))
+        st = sc.count_primary(view, w, h, sem=sem)
+        assert [st.n_node, st.n_tri, st.n_hits, st.max_stack] == list(g["orc_counts_sem%d" % sem])
+        assert st.n_rays == w * h and st.overflow == 0
+        # against the BVH-independent brute force: t is bit-equal everywhere
+        assert (bits(prim["t"]) == bits(g["bf_primary_sem%d" % sem]["t"])).all()
+    sc.close()
+
+
+def test_golden_ties_and_zero_directions(trx):
+    g = np.load(os.path.join(GOLDEN, "ties_rays.npz"))
+    sc = trx.Scene(GoldenFlat(trx, g).flat)
+    for sem in (0, 3):
+        hits, _ = sc.trace_rays(g["rays"], sem=sem)
+        assert_hits_equal(hits, g["orc_rays_sem%d" % sem], "ties sem %d" % sem)
+        assert (bits(hits["t"]) == bits(g["bf_rays_sem%d" % sem]["t"])).all()
+    sc.close()
+
+
+# ---- live comparison on seeded scenes, every semantics combination ------------------------------
+
+@pytest.mark.parametrize("name,n,w,h,tlas", [("cornell", 0, 96, 64, False), ("kitchen", 20000, 120, 72, False),
+                                              ("kitchen", 20000, 72, 48, True), ("bistro", 150000, 160, 90, False),
+                                              ("hairball", 120000, 96, 96, False), ("san_miguel", 120000, 120, 68, True),
+                                              ("demoscene", 60000, 64, 136, False), ("soup", 2500, 52, 44, False)])
+def test_scenes_all_semantics(trx, orc, name, n, w, h, tlas):
+    flat, view, osc, ov = make_scene(trx, orc, name, n, w, h, tlas=tlas)
+    sc = trx.Scene(flat)
+    rays = random_rays(trx, flat, 5000, 11)
+    for sem in ALL_SEMS:
+        gp, gao, _ = sc.trace_primary_ao(view, w, h, sem=sem, frame=1, ao_eps=0.01)
+        op, ost = osc.trace_primary(ov, w, h, sem=sem)
+        oao, _ = osc.trace_ao(ov, w, h, op, sem=sem, frame=1, ao_eps=0.01)
+        assert_hits_equal(gp, op, "%s sem %d primary" % (name, sem))
+        assert_hits_equal(gao, oao, "%s sem %d ao" % (name, sem))
+        gr, _ = sc.trace_rays(rays, sem=sem)
+        orr, _ = osc.trace_rays(rays, sem=sem)
+        assert_hits_equal(gr, orr, "%s sem %d rays" % (name, sem))
+        st = sc.count_primary(view, w, h, sem=sem)
+        assert (st.n_node, st.n_tri, st.n_hits, st.max_stack) == (ost.n_node, ost.n_tri, ost.n_hits, ost.max_stack)
+    # GPU AO epsilon (rt_gpu_software.hlsl:115) and a different frame seed
+    gp, gao, _ = sc.trace_primary_ao(view, w, h, sem=0, frame=7, ao_eps=0.0001)
+    oao, _ = osc.trace_ao(ov, w, h, gp, sem=0, frame=7, ao_eps=0.0001)
+    assert_hits_equal(gao, oao, "%s ao eps 1e-4" % name)
+    sc.close()
+
+
+def test_triangle_formats(trx, orc):
+    flat, view, osc, ov = make_scene(trx, orc, "kitchen", 12000, 96, 64)
+    want, _ = osc.trace_primary(ov, 96, 64, sem=0)
+    # f32 {v0,e1,e2} handed over directly
+    edges = osc.tris.copy()
+    sc = trx.Scene(flat, tri_format=trx.TRI_EDGES_36, tri_bytes=edges)
+    assert_hits_equal(sc.trace_primary(view, 96, 64, sem=0)[0], want, "TRI_EDGES_36")
+    sc.close()
+    # the reference's 24-byte f16 triangles (RtCompressedTriangle): parity against the oracle
+    # decoding the same bytes; against f32 geometry t moves by ~1e-3 relative (f16 edges)
+    packed = trx.pack_tris_f16(flat.tri_verts)
+    osc16 = orc.Scene(flat.nodes, tri_f16=packed)
+    sc = trx.Scene(flat, tri_format=trx.TRI_F16_24, tri_bytes=packed)
+    got, _ = sc.trace_primary(view, 96, 64, sem=0)
+    assert_hits_equal(got, osc16.trace_primary(ov, 96, 64, sem=0)[0], "TRI_F16_24")
+    both = np.isfinite(got["t"]) & np.isfinite(want["t"])
+    assert both.mean() > 0.9 and np.median(np.abs(got["t"][both] - want["t"][both]) / want["t"][both]) < 5e-3
+    sc.close()
+
+
+# ---- shards, layouts, odd sizes ------------------------------------------------------------------
+
+def test_shards_and_layouts(trx, orc):
+    import torch
+    from tray_racing_amd import dist as D
+    w, h = 100, 52
+    flat, view, osc, ov = make_scene(trx, orc, "cornell", 0, w, h)
+    want, _ = osc.trace_primary(ov, w, h, sem=3)
+    sc = trx.Scene(flat)
+    for world in (1, 2, 3, 8):
+        img = torch.full((w * h,), -1, dtype=torch.int64, device="cuda")
+        gathered = []
+        for r in range(world):
+            sc.trace_primary_dev(view, w, h, img.data_ptr(), sem=3, shard=(r, world, 0))
+            fgr = D.FrameGather(w, h, r, world, "cuda")
+            local = fgr.new_local()
+            sc.trace_primary_dev(view, w, h, local.data_ptr(), sem=3, shard=(r, world, 1))
+            torch.cuda.synchronize()
+            assert local.numel() == D.max_shard_tiles(w, h, world) * 64
+            gathered.append(local)
+        sc.check()
+        assert_hits_equal(D.int64_to_hits(img), want, "image layout, %d shards" % world)
+        fgr.gathered.copy_(torch.stack(gathered))       # what the all-gather would deliver
+        assert_hits_equal(D.int64_to_hits(fgr.assemble()), want, "shard layout, %d shards" % world)
+    sc.close()
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (9, 8), (64, 1), (33, 47)])
+def test_image_sizes_not_multiple_of_8(trx, orc, w, h):
+    flat, view, osc, ov = make_scene(trx, orc, "cornell", 0, w, h)
+    sc = trx.Scene(flat)
+    gp, gao, _ = sc.trace_primary_ao(view, w, h, sem=3)
+    op, _ = osc.trace_primary(ov, w, h, sem=3)
+    assert_hits_equal(gp, op, "%dx%d" % (w, h))
+    assert_hits_equal(gao, osc.trace_ao(ov, w, h, op, sem=3)[0], "%dx%d ao" % (w, h))
+    sc.close()
+
+
+# ---- edge cases -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5])
+def test_tiny_and_empty_scenes(trx, orc, n):
+    verts = trx.gen_scene("soup", max(n, 1), 5)[0][:n]
+    flat = trx.flat_build(verts)
+    eye, look, fov = trx.scene_camera("soup")
+    view = trx.view_from_camera(eye, look, fov, 40, 40)
+    sc = trx.Scene(flat)
+    got, _ = sc.trace_primary(view, 40, 40)
+    if n == 0:
+        assert np.isinf(got["t"]).all() and (got["prim"] == 0xFFFFFFFF).all()
+    else:
+        osc = orc.Scene.from_flat(flat)
+        assert_hits_equal(got, osc.trace_primary(orc.view_from_bytes(view), 40, 40)[0], "%d tris" % n)
+    sc.close()
+
+
+def test_degenerate_triangles_and_ray_ranges(trx, orc):
+    one = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], dtype=np.float32)
+    verts = np.concatenate([np.repeat(one, 30, axis=0), np.zeros((6, 9), np.float32), one + np.float32(2.0),
+                            np.array([[0, 0, -1, 1, 0, -1, 2, 0, -1]], dtype=np.float32)])  # collinear
+    flat = trx.flat_build(verts)
+    osc = orc.Scene.from_flat(flat)
+    rays = np.zeros(9, dtype=trx.RAY_DTYPE)
+    rays["origin"] = [(0.25, 0.25, 5)] * 5 + [(2.25, 2.25, 5), (0.25, 0.25, -3), (0.5, 0, 5), (5, 5, 5)]
+    rays["direction"] = [(0, 0, -1)] * 6 + [(0, 0, 1), (0, 0, -1), (0, 0, -1)]
+    rays["tmin"] = [0, 5.0, 5.5, 0, 0, 0, 0, 0, 0]
+    rays["tmax"] = [F32_MAX, F32_MAX, F32_MAX, 4.9, np.inf, F32_MAX, F32_MAX, F32_MAX, F32_MAX]
+    sc = trx.Scene(flat)
+    for sem in (0, 3):
+        got, _ = sc.trace_rays(rays, sem=sem)
+        assert_hits_equal(got, osc.trace_rays(rays, sem=sem)[0], "degenerate sem %d" % sem)
+    assert got["t"][0] == 5.0 and got["t"][1] == 5.0 and np.isinf(got["t"][2]) and np.isinf(got["t"][3])
+    assert np.isinf(got["t"][8]) and got["prim"][8] == 0xFFFFFFFF
+    sc.close()
+
+
+def test_stack_spill_to_hbm_and_overflow_detection(trx, orc):
+    """A hand-made tree drives the per-lane stack past the LDS part (12 entries) into the
+    HBM spill; past 64 entries the kernel must flag the ray instead of corrupting memory."""
+    rays = np.zeros(70, dtype=trx.RAY_DTYPE)
+    rays["origin"] = (0.3, 0.3, 1)
+    rays["direction"] = (0, 0, -1)
+    rays["origin"][1::2] = (0.3, 0.3, -100)   # half the wave looks the other way: mixed stack depths
+    rays["direction"][1::2] = (0, 0, 1)
+    rays["tmax"] = F32_MAX
+    for depth in (10, 13, 40, 64):
+        nodes, tris = deep_chain_scene(depth)
+        flat = trx.FlatScene(nodes, tris, [], 0, np.arange(depth), [0, depth])
+        osc = orc.Scene(nodes, tris)
+        want, ost = osc.trace_rays(rays, sem=0)
+        assert ost.overflow == 0 and ost.max_stack == depth - 1
+        sc = trx.Scene(flat)
+        got, _ = sc.trace_rays(rays, sem=0)
+        assert_hits_equal(got, want, "depth %d" % depth)
+        assert got["t"][0] == 1.0 and got["prim"][0] == 0
+        sc.close()
+    nodes, tris = deep_chain_scene(70)
+    sc = trx.Scene(trx.FlatScene(nodes, tris, [], 0, np.arange(70), [0, 70]))
+    with pytest.raises(trx.TrxError) as e:
+        sc.trace_rays(rays, sem=0)
+    assert e.value.code == -4 and "overflowed" in str(e.value)
+    got, _ = sc.trace_rays(rays[1:2], sem=0)  # the scene stays usable; the flag was cleared
+    sc.close()
+
+
+# ---- the Traversable surface ---------------------------------------------------------------------
+
+def test_traverse_single_ray_and_concurrent_callers(trx, orc):
+    flat, view, osc, ov = make_scene(trx, orc, "kitchen", 8000, 32, 32, tlas=True)
+    sc = trx.Scene(flat)
+    rays = osc.primary_rays(ov, 32, 32)
+    want, _ = osc.trace_rays(rays, sem=3)
+    errors = []
+
+    def work(ids):
+        try:
+            for i in ids:
+                h = sc.traverse(rays["origin"][i], rays["direction"][i], sem=3)
+                if np.isinf(want["t"][i]):
+                    ok = h.primitive_id == 0xFFFFFFFF and np.isinf(h.t)
+                else:
+                    g = int(np.searchsorted(flat.blas_tri_start, want["prim"][i], side="right") - 1)
+                    ok = (np.float32(h.t) == want["t"][i] and h.geometry_id == g and
+                          h.primitive_id == want["prim"][i] - flat.blas_tri_start[g])
+                if not ok:
+                    errors.append(i)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(range(k, 1024, 64),)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []
+    sc.close()
+
+
+def test_device_pointers_streams_and_runner(trx, orc):
+    import torch
+    w, h = 128, 72
+    flat, view, osc, ov = make_scene(trx, orc, "bistro", 60000, w, h)
+    want, _ = osc.trace_primary(ov, w, h, sem=3)
+    sc = trx.Scene(flat)
+    stream = torch.cuda.Stream()
+    out = torch.zeros(w * h, dtype=torch.int64, device="cuda")
+    ao = torch.zeros(w * h, dtype=torch.int64, device="cuda")
+    with torch.cuda.stream(stream):
+        for _ in range(6):  # more launches than launch slots: slot reuse is stream-ordered
+            sc.trace_primary_dev(view, w, h, out.data_ptr(), sem=3, stream=stream.cuda_stream)
+        sc.trace_ao_dev(view, w, h, out.data_ptr(), ao.data_ptr(), sem=3, frame=0, ao_eps=0.01,
+                        stream=stream.cuda_stream)
+    sc.check(stream.cuda_stream)
+    from tray_racing_amd import dist as D
+    assert_hits_equal(D.int64_to_hits(out), want, "torch stream + tensor")
+    assert_hits_equal(D.int64_to_hits(ao), osc.trace_ao(ov, w, h, want, sem=3, frame=0, ao_eps=0.01)[0], "ao dev")
+    rays = random_rays(trx, flat, 3000, 2)
+    d_rays = torch.from_numpy(rays.view(np.uint8).reshape(-1, 32).copy()).cuda()
+    d_hits = torch.zeros(rays.shape[0], dtype=torch.int64, device="cuda")
+    sc.trace_rays_dev(d_rays.data_ptr(), rays.shape[0], d_hits.data_ptr(), sem=0)
+    torch.cuda.synchronize()
+    assert_hits_equal(D.int64_to_hits(d_hits), osc.trace_rays(rays, sem=0)[0], "rays dev")
+    mn, mean = sc.bench_primary(view, w, h, sem=3, warmup=1, frames=5)
+    assert 0 < mn <= mean
+    sc.close()
+    verts, counts = trx.gen_scene("cornell", 0, 1)
+    ms, blas_s, tlas_ms = trx.cwbvh_gpu_runner(verts, counts, 64, 64, trx.scene_camera("cornell"), tlas=True, frames=3)
+    assert ms > 0 and blas_s >= 0 and tlas_ms >= 0
+
+
+# ---- BASELINE.json sizes ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name,w,h,tlas", [("kitchen", 1920, 1080, False), ("bistro", 1920, 1080, False)])
+def test_full_size_config(trx, orc, name, w, h, tlas):
+    """BASELINE.json configs[1] / configs[2] at full size: the whole 1920x1080 frame against the
+    oracle, plus size-independent properties (variant idempotence, exact scale covariance)."""
+    verts, counts = trx.gen_scene(name, 0, 1)
+    flat = trx.flat_build(verts, counts, use_tlas=tlas)
+    eye, look, fov = trx.scene_camera(name)
+    view = trx.view_from_camera(eye, look, fov, w, h)
+    sc = trx.Scene(flat)
+    got, _ = sc.trace_primary(view, w, h, sem=3)
+    osc = orc.Scene.from_flat(flat)
+    want, ost = osc.trace_primary(orc.view_from_bytes(view), w, h, sem=3)
+    assert_hits_equal(got, want, "%s %dx%d" % (name, w, h))
+    st = sc.count_primary(view, w, h, sem=3)
+    assert (st.n_node, st.n_tri, st.n_hits) == (ost.n_node, ost.n_tri, ost.n_hits)
+    # idempotence: every kernel variant (refill threshold) writes the same frame
+    lib = trx.load()
+    for variant in (8, 32):
+        lib.trx_set_kernel_variant(variant)
+        again, _ = sc.trace_primary(view, w, h, sem=3)
+        assert_hits_equal(again, got, "variant %d" % variant)
+    lib.trx_set_kernel_variant(0)
+    sc.close()
+    # covariance: scaling the scene and the ray origins by a power of two is exact in binary
+    # floating point for the triangle test, so t scales exactly (bit for bit) wherever the same
+    # triangle is found; the node test's absolute 1e-4 clamp is not scale-free, hence "wherever"
+    s = 4.0
+    rays = random_rays(trx, flat, 200000, 9, zero_dirs=False)
+    rays["tmin"] = 0.0
+    rays["tmax"] = F32_MAX
+    sc = trx.Scene(flat)
+    base, _ = sc.trace_rays(rays, sem=3)
+    sc.close()
+    flat2 = trx.flat_build((verts * np.float32(s)).astype(np.float32), counts, use_tlas=tlas)
+    rays2 = rays.copy()
+    rays2["origin"] = rays["origin"] * np.float32(s)
+    sc2 = trx.Scene(flat2)
+    scaled, _ = sc2.trace_rays(rays2, sem=3)
+    sc2.close()
+    hit = np.isfinite(base["t"]) & np.isfinite(scaled["t"])
+    same = hit & (flat.tri_source[np.where(hit, base["prim"], 0)] == flat2.tri_source[np.where(hit, scaled["prim"], 0)])
+    assert hit.sum() > 10000 and same.sum() > 0.999 * hit.sum()
+    assert (bits(scaled["t"][same]) == bits(base["t"][same] * np.float32(s))).all()
+
+
+def test_full_size_hairball_ao_and_tlas_4k_sample(trx, orc):
+    """configs[3] (hairball-class, incoherent AO rays) on a 1/16 tile sample at 1920x1080, and
+    configs[4] (san-miguel-class TLAS, 3840x2160 tiled over 8 ranks) on one rank's shard sample."""
+    verts, counts = trx.gen_scene("hairball", 0, 1)
+    flat = trx.flat_build(verts, counts)
+    eye, look, fov = trx.scene_camera("hairball")
+    w, h = 1920, 1080
+    view = trx.view_from_camera(eye, look, fov, w, h)
+    sc = trx.Scene(flat)
+    osc = orc.Scene.from_flat(flat)
+    ov = orc.view_from_bytes(view)
+    for frame in range(4):  # "4 spp" = frames 0..3 of the AO seed
+        gp, gao, _ = sc.trace_primary_ao(view, w, h, sem=3, frame=frame, ao_eps=0.01)
+        op = np.zeros(w * h, dtype=orc.HIT_DTYPE)
+        op["prim"] = 0xFFFFFFFF
+        op["t"] = np.inf
+        osc.trace_primary(ov, w, h, sem=3, shard=(frame, 16), out=op)
+        mask = np.zeros(w * h, dtype=bool)
+        tiles = np.arange(((w + 7) // 8) * ((h + 7) // 8))
+        tsel = tiles[tiles % 16 == frame]
+        ys, xs = np.divmod(np.arange(64), 8)
+        px = (tsel[:, None] % ((w + 7) // 8)) * 8 + xs[None, :]
+        py = (tsel[:, None] // ((w + 7) // 8)) * 8 + ys[None, :]
+        ok = (px < w) & (py < h)
+        mask[(py * w + px)[ok]] = True
+        assert_hits_equal(gp[mask], op[mask], "hairball primary sample")
+        oao, _ = osc.trace_ao(ov, w, h, op, sem=3, frame=frame, ao_eps=0.01, shard=(frame, 16))
+        assert_hits_equal(gao[mask], oao[mask], "hairball ao sample frame %d" % frame)
+    sc.close()
+    verts, counts = trx.gen_scene("san_miguel", 0, 1)
+    flat = trx.flat_build(verts, counts, use_tlas=True)
+    assert flat.has_tlas and flat.instance_offsets.size > 500
+    eye, look, fov = trx.scene_camera("san_miguel")
+    w, h = 3840, 2160
+    view = trx.view_from_camera(eye, look, fov, w, h)
+    sc = trx.Scene(flat)
+    import torch
+    from tray_racing_amd import dist as D
+    rank, world = 5, 8
+    fg = D.FrameGather(w, h, rank, world, "cuda")
+    local = fg.new_local()
+    sc.trace_primary_dev(view, w, h, local.data_ptr(), sem=3, shard=(rank, world, 1))
+    sc.check()
+    got = D.int64_to_hits(local)
+    # oracle on every 16th tile of this rank's shard
+    osc = orc.Scene.from_flat(flat)
+    ov = orc.view_from_bytes(view)
+    full = np.zeros(w * h, dtype=orc.HIT_DTYPE)
+    osc.trace_primary(ov, w, h, sem=3, shard=(rank, world * 16), out=full)
+    tx = (w + 7) // 8
+    lt = np.arange(0, fg.records // 64)
+    tile = lt * world + rank
+    sel = lt[(tile % (world * 16)) == rank]
+    ys, xs = np.divmod(np.arange(64), 8)
+    px = ((sel * world + rank)[:, None] % tx) * 8 + xs[None, :]
+    py = ((sel * world + rank)[:, None] // tx) * 8 + ys[None, :]
+    rec = sel[:, None] * 64 + np.arange(64)[None, :]
+    assert_hits_equal(got[rec.ravel()], full[(py * w + px).ravel()], "san_miguel tlas 4k shard sample")
+    sc.close()

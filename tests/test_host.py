@@ -1,0 +1,92 @@
+"""Host logic around the path: model loading (src/main.rs:494-561), cameras, scene
+stand-ins, triangle formats."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+def test_obj_loader_matches_reference_rules(trx, tmp_path):
+    p = tmp_path / "m.obj"
+    p.write_text("""# comment
+o first
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+vn 0 0 1
+f 1/1/1 2/2/1 3/3/1
+f 1//1 2//1 3//1 4//1
+o second
+v 0 0 1
+v 1 0 1
+v 0 1 1
+f -3 -2 -1
+f 5 6 7 1 2
+""")
+    verts, counts = trx.load_meshs(p)
+    # a quad is fanned into (0,1,2),(0,2,3); polygons with more than 4 vertices contribute
+    # their first triangle only (the reference reads poly.0[0..2], src/main.rs:536-553)
+    assert counts.tolist() == [3, 2]
+    assert verts.shape == (5, 9)
+    assert verts[1].tolist() == [0, 0, 0, 1, 0, 0, 1, 1, 0] and verts[2].tolist() == [0, 0, 0, 1, 1, 0, 0, 1, 0]
+    assert verts[3].tolist() == [0, 0, 1, 1, 0, 1, 0, 1, 1]
+
+
+def test_json_loader(trx, tmp_path):
+    tris = [{"v0": [-72.0, 3.2, 57.3], "v1": [-79.4, 3.2, 56.7], "v2": [-79.4, 11.9, 56.7]},
+            {"v0": [0, 0, 0], "v1": [1e-3, 0, 0], "v2": [0, 2.5e2, 0]}]
+    p = tmp_path / "m.json"
+    p.write_text(json.dumps(tris))
+    verts, counts = trx.load_meshs(p)
+    assert counts.tolist() == [2]
+    want = np.array([t["v0"] + t["v1"] + t["v2"] for t in tris], dtype=np.float32)
+    assert (verts == want).all()
+
+
+def test_scene_cameras_are_the_reference_ron_files(trx):
+    assert trx.scene_camera("bistro") == ([-10.5, pytest.approx(1.7), -1.0], [12.5, pytest.approx(1.7), -2.0], 100.0)
+    assert trx.scene_camera("kitchen")[2] == 90.0 and trx.scene_camera("demoscene")[2] == 17.0
+    if os.path.exists("/root/reference/assets/scenes"):
+        import re
+        for ours, ron in [("bistro", "bistro"), ("kitchen", "kitchen"), ("hairball", "hairball"),
+                          ("san_miguel", "san-miguel"), ("cornell", "cornell_box")]:
+            text = open("/root/reference/assets/scenes/%s.ron" % ron).read()
+            eye = [float(x) for x in re.search(r"eye:\s*\(([^)]*)\)", text).group(1).split(",")]
+            look = [float(x) for x in re.search(r"look_at:\s*\(([^)]*)\)", text).group(1).split(",")]
+            fov = float(re.search(r"fov:\s*([0-9.]+)", text).group(1))
+            e, l, f = trx.scene_camera(ours)
+            assert np.allclose(e, eye) and np.allclose(l, look) and f == fov
+
+
+@pytest.mark.parametrize("name,n", [("kitchen", 56939), ("bistro", 120000), ("hairball", 50000),
+                                    ("san_miguel", 90000), ("demoscene", 30000), ("soup", 777)])
+def test_stand_in_scenes_hit_their_triangle_count_and_are_seeded(trx, name, n):
+    a, ca = trx.gen_scene(name, n, 1)
+    b, cb = trx.gen_scene(name, n, 1)
+    assert a.shape == (n, 9) and int(ca.sum()) == n
+    assert (a == b).all() and (ca == cb).all()
+    assert np.isfinite(a).all()
+    if name in ("hairball", "soup", "bistro"):
+        c, _ = trx.gen_scene(name, n, 2)
+        assert (a != c).any()
+
+
+def test_f16_pack_layout(trx):
+    v = np.array([[1, 2, 3, 1.5, 2, 3, 1, 2.25, 3]], dtype=np.float32)
+    p = trx.pack_tris_f16(v)
+    assert p.shape == (1, 6) and p[0, :3].view(np.float32).tolist() == [1, 2, 3]
+    # e[k] low half = e2[k] = (v2 - v0)[k], high half = e1[k] = (v1 - v0)[k]  (query.hlsl:75-85)
+    lo = (p[0, 3:] & 0xFFFF).astype(np.uint16).view(np.float16)
+    hi = (p[0, 3:] >> 16).astype(np.uint16).view(np.float16)
+    assert lo.tolist() == [0, 0.25, 0] and hi.tolist() == [0.5, 0, 0]
+
+
+def test_view_uniform_layout(trx):
+    v = trx.view_from_camera([0, 0, 5], [0, 0, 0], 90.0, 16, 16)
+    vi = np.array(v.view_inv).reshape(4, 4).T  # column-major storage
+    assert np.allclose(vi[:3, 3], [0, 0, 5])   # camera-to-world translation = eye
+    assert list(v.eye) == [0, 0, 5]
+    pi = np.array(v.proj_inv).reshape(4, 4).T
+    assert np.allclose(pi @ np.array([0, 0, 1, 1.0]) / (pi @ np.array([0, 0, 1, 1.0]))[3], [0, 0, -0.01, 1], atol=1e-6)

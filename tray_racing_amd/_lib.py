@@ -54,7 +54,7 @@ class RayHit(C.Structure):
 
 
 class Shard(C.Structure):
-    _fields_ = [("index", C.c_uint32), ("count", C.c_uint32)]
+    _fields_ = [("index", C.c_uint32), ("count", C.c_uint32), ("layout", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -98,6 +98,7 @@ SIGNATURES = {
     "trx_traverse1": (_i, [_P, C.POINTER(Ray), _u32, C.POINTER(RayHit)]),
     "trx_bench_primary": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _u32, _u32, C.POINTER(_f), C.POINTER(_f)]),
     "trx_set_kernel_variant": (_u32, [_u32]),
+    "trx_shard_tiles": (_u32, [_u32, _u32, Shard]),
     "trx_bvh_build_tris": (_i, [_P, _u64, _u32, _i, C.POINTER(_P)]),
     "trx_bvh_build_aabbs": (_i, [_P, _u64, _u32, _i, C.POINTER(_P)]),
     "trx_bvh_destroy": (None, [_P]),

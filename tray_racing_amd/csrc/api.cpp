@@ -260,6 +260,7 @@ int image_params(TraceParams &p, const trx_view *view, uint32_t w, uint32_t h, t
     if ((uint64_t)w * h > 0x7fffffffull) return fail(TRX_ERR_INVALID, "image %ux%u too large", w, h);
     if (shard.count == 0) shard.count = 1;
     if (shard.index >= shard.count) return fail(TRX_ERR_INVALID, "shard %u of %u", shard.index, shard.count);
+    if (shard.layout > TRX_LAYOUT_SHARD) return fail(TRX_ERR_INVALID, "unknown shard layout %u", shard.layout);
     const uint32_t tx = (w + 7) / 8, ty = (h + 7) / 8;
     const uint64_t tiles = (uint64_t)tx * ty;
     const uint64_t local = tiles > shard.index ? (tiles - shard.index + shard.count - 1) / shard.count : 0;
@@ -268,6 +269,7 @@ int image_params(TraceParams &p, const trx_view *view, uint32_t w, uint32_t h, t
     p.tiles_x = tx;
     p.shard_index = shard.index;
     p.shard_count = shard.count;
+    p.compact = shard.layout == TRX_LAYOUT_SHARD ? 1u : 0u;
     p.n_items = (uint32_t)(local * 64);
     fill_view(view, p.view);
     return TRX_OK;
@@ -313,6 +315,13 @@ uint32_t trx_tri_format_bytes(uint32_t f) {
     case TRX_TRI_EDGES_36: return 36;
     default: return 0;
     }
+}
+
+uint32_t trx_shard_tiles(uint32_t w, uint32_t h, trx_shard shard) {
+    if (shard.count == 0) shard.count = 1;
+    const uint64_t tiles = (uint64_t)((w + 7) / 8) * ((h + 7) / 8);
+    if (shard.index >= shard.count || tiles <= shard.index) return 0;
+    return (uint32_t)((tiles - shard.index + shard.count - 1) / shard.count);
 }
 
 uint32_t trx_set_kernel_variant(uint32_t variant) {
@@ -610,7 +619,7 @@ int trx_trace_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h
     int rc = ensure_scratch(s, (uint64_t)w * h, 0);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev0, nullptr));
-    rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1}, sem, s->d_scratch_a, nullptr);
+    rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, nullptr);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev1, nullptr));
     HIP_TRY(hipEventSynchronize(s->ev1));
@@ -626,9 +635,9 @@ int trx_trace_primary_ao(trx_scene *s, const trx_view *view, uint32_t w, uint32_
     int rc = ensure_scratch(s, (uint64_t)w * h, 0);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev0, nullptr));
-    rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1}, sem, s->d_scratch_a, nullptr);
+    rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, nullptr);
     if (rc) return rc;
-    rc = trx_trace_ao_dev(s, view, w, h, trx_shard{0, 1}, sem, frame, ao_eps, s->d_scratch_a, s->d_scratch_b, nullptr);
+    rc = trx_trace_ao_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, frame, ao_eps, s->d_scratch_a, s->d_scratch_b, nullptr);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev1, nullptr));
     HIP_TRY(hipEventSynchronize(s->ev1));
@@ -705,14 +714,14 @@ int trx_bench_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h
     int rc = ensure_scratch(s, (uint64_t)w * h, 0);
     if (rc) return rc;
     for (uint32_t i = 0; i < warmup; i++) {
-        rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1}, sem, s->d_scratch_a, nullptr);
+        rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, nullptr);
         if (rc) return rc;
     }
     float mn = 1e30f;
     double sum = 0.0;
     for (uint32_t i = 0; i < frames; i++) {
         HIP_TRY(hipEventRecord(s->ev0, nullptr));
-        rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1}, sem, s->d_scratch_a, nullptr);
+        rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, nullptr);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(s->ev1, nullptr));
         HIP_TRY(hipEventSynchronize(s->ev1));

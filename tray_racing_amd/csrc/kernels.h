@@ -47,6 +47,7 @@ struct TraceParams {
     uint32_t tlas_start;
     uint32_t width, height, tiles_x;
     uint32_t shard_index, shard_count;
+    uint32_t compact; // TRX_LAYOUT_SHARD: hit buffers indexed by work item
     uint32_t frame;
     float ao_eps;
     uint32_t tie_first;

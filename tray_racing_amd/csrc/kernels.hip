@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceParams P) {
                     const uint32_t px = (tile % P.tiles_x) * 8u + (k & 7u);
                     const uint32_t py = (tile / P.tiles_x) * 8u + (k >> 3);
                     if (px < P.width && py < P.height) {
-                        out_index = py * P.width + px;
+                        out_index = P.compact ? item : py * P.width + px;
                         primary_dir(P.view, P.width, P.height, px, py, dx, dy, dz);
                         if (MODE == kModePrimary) {
                             r.ox = P.view.eye[0]; r.oy = P.view.eye[1]; r.oz = P.view.eye[2];

@@ -689,14 +689,15 @@ bool load_obj(const std::string &path, std::vector<float> &verts, std::vector<ui
             long idx[4];
             int n = 0;
             char *p = line + 2;
-            while (n < 4) {
+            for (;;) { // n counts every vertex of the polygon; the first four are kept
                 while (*p == ' ' || *p == '\t') p++;
                 if (*p == 0 || *p == '\n' || *p == '\r') break;
                 char *end;
                 long v = std::strtol(p, &end, 10);
                 if (end == p) break;
                 if (v < 0) v = (long)(pos.size() / 3) + v + 1; // relative index
-                idx[n++] = v - 1;
+                if (n < 4) idx[n] = v - 1;
+                n++;
                 p = end;
                 while (*p && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r') p++; // skip /vt/vn
             }
