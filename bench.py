@@ -70,7 +70,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     w, h = args.width, args.height
-    threads = max(1, (os.cpu_count() or 8) // world)
+    threads = max(1, len(os.sched_getaffinity(0)) // world)
     verts, counts = T.gen_scene(args.scene, args.tris, 1)
     t0 = time.time()
     flat = T.flat_build(verts, counts, use_tlas=False, threads=threads)
@@ -195,7 +195,7 @@ def main():
         from oracle import binding as O
         osc = O.Scene.from_flat(flat)
         ov = O.view_from_bytes(view)
-        cores = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0))  # the cores this process may run on
         hits, ost = osc.trace_primary(ov, w, h, sem=args.sem, threads=cores)  # one full frame
         frames, secs = 1, ost.seconds
         while secs < args.cpu_seconds and frames < 64:
