@@ -156,6 +156,10 @@ typedef struct trx_stats {
     uint32_t overflow; /* number of rays that overflowed the stack */
     float kernel_ms;   /* hipEvent time of the traversal kernel(s) of this call */
     float _pad;
+    /* wave-level executions of the node step / triangle test: n_node / (64 * n_wave_node)
+     * is the SIMD efficiency of the node phase, likewise for triangles */
+    uint64_t n_wave_node;
+    uint64_t n_wave_tri;
 } trx_stats;
 
 typedef struct trx_scene trx_scene; /* opaque: device-resident nodes/tris/instances */
@@ -267,6 +271,12 @@ int trx_traverse1(trx_scene *scene, const trx_ray *ray, uint32_t semantics,
 int trx_bench_primary(trx_scene *scene, const trx_view *view, uint32_t width,
                       uint32_t height, uint32_t semantics, uint32_t warmup,
                       uint32_t frames, float *out_min_ms, float *out_mean_ms);
+
+/* Diagnostics: start / end wall-clock stamps (100 MHz ticks) of every persistent wave of one
+ * primary frame: out_times[2*i], out_times[2*i+1].  Shows residency and the frame's tail. */
+int trx_debug_wave_timeline(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                            uint32_t semantics, uint64_t *out_times, uint32_t max_waves,
+                            uint32_t *out_waves);
 
 /* Kernel variant selection (tuning aid; 0 = default).  Returns the previous
  * value.  Variants compute identical results. */

@@ -75,6 +75,7 @@ def load():
         "orc_brute_rays": (None, [P, u64, P, u64, u32, i, P]),
         "orc_brute_primary": (None, [P, u64, VP, u32, u32, u32, i, P]),
         "orc_validate": (i, [SP, P, C.c_char_p, i]),
+        "orc_count_primary_per_ray": (None, [SP, VP, u32, u32, u32, i, P, P]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -147,6 +148,12 @@ class Scene:
         st = Stats()
         load().orc_trace_rays(C.byref(self.c), _ptr(rays), rays.shape[0], sem, threads, _ptr(hits), C.byref(st))
         return hits, st
+
+    def count_per_ray(self, view, w, h, sem=SEM_HLSL, threads=0):
+        nn = np.zeros(w * h, dtype=np.uint16)
+        nt = np.zeros(w * h, dtype=np.uint16)
+        load().orc_count_primary_per_ray(C.byref(self.c), C.byref(view), w, h, sem, threads, _ptr(nn), _ptr(nt))
+        return nn, nt
 
     def render_frame(self, view, w, h, sem=SEM_HLSL, frame=0, ao_eps=0.01, threads=0):
         return load().orc_render_frame(C.byref(self.c), C.byref(view), w, h, sem, frame, ao_eps, threads, None)

@@ -803,3 +803,21 @@ int orc_validate(const orc_scene *s, const float *verts, char *err, int err_len)
     free(c.node_seen);
     return c.failed ? -1 : 0;
 }
+
+/* per-ray PROFILE_RT counters of a primary frame (the heat-map of
+ * src/rt_gpu/rt_gpu_software.hlsl:93-102 as numbers) */
+void orc_count_primary_per_ray(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h, uint32_t sem,
+                               int threads, uint16_t *n_node, uint16_t *n_tri) {
+    threads = pick_threads(threads);
+    const int64_t n = (int64_t)w * h;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(threads)
+    for (int64_t i = 0; i < n; i++) {
+        float o[3], d[3];
+        orc_stats st;
+        memset(&st, 0, sizeof(st));
+        orc_primary_ray(view, w, h, (uint32_t)(i % w), (uint32_t)(i / w), o, d);
+        orc_traverse(s, o, d, 0.0f, F32_MAX, sem, &st);
+        n_node[i] = (uint16_t)(st.n_node > 65535 ? 65535 : st.n_node);
+        n_tri[i] = (uint16_t)(st.n_tri > 65535 ? 65535 : st.n_tri);
+    }
+}

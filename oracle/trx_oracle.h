@@ -113,6 +113,10 @@ void orc_trace_rays(const orc_scene *s, const orc_ray *rays, uint64_t n, uint32_
 double orc_render_frame(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h, uint32_t sem,
                         uint32_t frame, float ao_eps, int threads, float *rgb);
 
+/* per-ray node / triangle test counts of a primary frame */
+void orc_count_primary_per_ray(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h, uint32_t sem,
+                               int threads, uint16_t *n_node, uint16_t *n_tri);
+
 /* BVH-independent ground truth: every ray against every triangle in index
  * order with the same triangle test and tie rule. */
 void orc_brute_rays(const float *tris9, uint64_t n_tris, const orc_ray *rays, uint64_t n, uint32_t sem,

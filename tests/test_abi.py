@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(trx):
 def test_struct_sizes_match_the_header(trx):
     from tray_racing_amd import _lib
     assert C.sizeof(_lib.View) == 160 and C.sizeof(_lib.Ray) == 32 and C.sizeof(_lib.Hit) == 8
-    assert C.sizeof(_lib.RayHit) == 16 and C.sizeof(_lib.Shard) == 16 and C.sizeof(_lib.Stats) == 48
+    assert C.sizeof(_lib.RayHit) == 16 and C.sizeof(_lib.Shard) == 16 and C.sizeof(_lib.Stats) == 64
     assert trx.HIT_DTYPE.itemsize == 8 and trx.RAY_DTYPE.itemsize == 32
 
 

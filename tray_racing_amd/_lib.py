@@ -59,7 +59,8 @@ class Shard(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_rays", C.c_uint64), ("n_node", C.c_uint64), ("n_tri", C.c_uint64), ("n_hits", C.c_uint64),
-                ("max_stack", C.c_uint32), ("overflow", C.c_uint32), ("kernel_ms", C.c_float), ("_pad", C.c_float)]
+                ("max_stack", C.c_uint32), ("overflow", C.c_uint32), ("kernel_ms", C.c_float), ("_pad", C.c_float),
+                ("n_wave_node", C.c_uint64), ("n_wave_tri", C.c_uint64)]
 
 
 class Flat(C.Structure):
@@ -98,6 +99,7 @@ SIGNATURES = {
     "trx_traverse1": (_i, [_P, C.POINTER(Ray), _u32, C.POINTER(RayHit)]),
     "trx_bench_primary": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _u32, _u32, C.POINTER(_f), C.POINTER(_f)]),
     "trx_set_kernel_variant": (_u32, [_u32]),
+    "trx_debug_wave_timeline": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, _u32, C.POINTER(_u32)]),
     "trx_shard_tiles": (_u32, [_u32, _u32, Shard]),
     "trx_bvh_build_tris": (_i, [_P, _u64, _u32, _i, C.POINTER(_P)]),
     "trx_bvh_build_aabbs": (_i, [_P, _u64, _u32, _i, C.POINTER(_P)]),

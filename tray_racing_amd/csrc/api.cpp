@@ -50,6 +50,7 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 constexpr int kSlots = 4;
+constexpr uint32_t kDefaultWavesPerBlock = 1;
 
 struct Slot {
     SlotCounters *ctr = nullptr;
@@ -68,7 +69,9 @@ struct trx_scene {
     uint64_t n_nodes = 0, n_tris = 0;
     uint32_t n_inst = 0, tlas_start = 0;
     bool tlas = false;
-    int grid = 0;
+    int grid = 0;      // default number of persistent waves
+    int cu_count = 0;
+    unsigned long long *d_wave_times = nullptr; // diagnostics only (trx_debug_wave_timeline)
     Slot slots[kSlots];
     int next_slot = 0;
     std::mutex mu;
@@ -233,7 +236,8 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     if (!slot.ctr) {
         HIP_TRY(hipMalloc(&slot.ctr, sizeof(SlotCounters)));
         HIP_TRY(hipMemset(slot.ctr, 0, sizeof(SlotCounters)));
-        HIP_TRY(hipMalloc(&slot.spill, (size_t)s->grid * kSpillStack * kWave * sizeof(uint2)));
+        // sized for the largest grid a tuning override can ask for (32 waves per CU)
+        HIP_TRY(hipMalloc(&slot.spill, (size_t)s->cu_count * 32 * kSpillStack * kWave * sizeof(uint2)));
         HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     }
     if (slot.used) HIP_TRY(hipStreamWaitEvent(stream, slot.done, 0));
@@ -247,7 +251,15 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     uint32_t refill = g_variant & 0x7fu;
     p.refill_idle = refill ? std::min(refill, 64u) : 64u;
     p.variant = g_variant;
-    HIP_TRY(launch_trace(p, mode, s->tlas, sem, count, s->grid, stream));
+    // tuning overrides (trx_set_kernel_variant): bits 8..15 waves per CU, bits 16..19 waves per workgroup
+    uint32_t wpb = (g_variant >> 16) & 0xfu;
+    if (wpb != 1 && wpb != 2 && wpb != 4) wpb = kDefaultWavesPerBlock;
+    uint32_t per_cu = (g_variant >> 8) & 0xffu;
+    int grid = per_cu ? (int)(std::min(per_cu, 32u) * (uint32_t)s->cu_count) : s->grid;
+    grid = std::max((int)wpb, grid / (int)wpb * (int)wpb);
+    p.waves_per_block = wpb;
+    p.wave_times = s->d_wave_times;
+    HIP_TRY(launch_trace(p, mode, s->tlas, sem, count, grid, stream));
     HIP_TRY(hipEventRecord(slot.done, stream));
     slot.used = true;
     if (ctr_out) *ctr_out = slot.ctr;
@@ -384,6 +396,11 @@ int trx_scene_create(const void *bvh_bytes, uint64_t n_nodes, const void *tri_by
     HIP_TRY_S(hipEventCreate(&s->ev0));
     HIP_TRY_S(hipEventCreate(&s->ev1));
 #undef HIP_TRY_S
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return cleanup(fail(TRX_ERR_NO_DEVICE, "hipGetDeviceProperties failed"));
+        s->cu_count = prop.multiProcessorCount;
+    }
     s->grid = trace_grid_size(device, 0, s->tlas, 0, false);
     if (s->grid <= 0) return cleanup(fail(TRX_ERR_NO_DEVICE, "could not size the persistent grid"));
     *out = s;
@@ -400,6 +417,7 @@ void trx_scene_destroy(trx_scene *s) {
     if (s->d_scratch_a) (void)hipFree(s->d_scratch_a);
     if (s->d_scratch_b) (void)hipFree(s->d_scratch_b);
     if (s->d_scratch_rays) (void)hipFree(s->d_scratch_rays);
+    if (s->d_wave_times) (void)hipFree(s->d_wave_times);
     for (Slot &sl : s->slots) {
         if (sl.ctr) (void)hipFree(sl.ctr);
         if (sl.spill) (void)hipFree(sl.spill);
@@ -541,6 +559,7 @@ static int finish_count(trx_scene *s, SlotCounters *ctr, trx_stats *stats) {
     HIP_TRY(hipMemcpy(&c, ctr, sizeof(c), hipMemcpyDeviceToHost));
     SlotCounters z = c;
     z.n_rays = z.n_node = z.n_tri = z.n_hits = 0;
+    z.n_wave_node = z.n_wave_tri = 0;
     z.max_stack = 0;
     z.overflow = 0;
     HIP_TRY(hipMemcpy(ctr, &z, sizeof(z), hipMemcpyHostToDevice));
@@ -555,6 +574,8 @@ static int finish_count(trx_scene *s, SlotCounters *ctr, trx_stats *stats) {
         stats->overflow = c.overflow;
         stats->kernel_ms = ms;
         stats->_pad = 0.f;
+        stats->n_wave_node = c.n_wave_node;
+        stats->n_wave_tri = c.n_wave_tri;
     }
     if (c.overflow) return fail(TRX_ERR_STACK_OVERFLOW, "%u rays overflowed the traversal stack", c.overflow);
     return TRX_OK;
@@ -733,6 +754,36 @@ int trx_bench_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h
     if (out_min_ms) *out_min_ms = mn;
     if (out_mean_ms) *out_mean_ms = (float)(sum / frames);
     return trx_scene_check(s, nullptr);
+}
+
+// Diagnostics: per-wave [start, end] wall-clock stamps (100 MHz ticks) of one primary frame.
+int trx_debug_wave_timeline(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem,
+                            uint64_t *out_times, uint32_t max_waves, uint32_t *out_waves) {
+    if (!s || !out_times || !out_waves) return fail(TRX_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = ensure_scratch(s, (uint64_t)w * h, 0);
+    if (rc) return rc;
+    const size_t n = (size_t)s->cu_count * 32;
+    HIP_TRY(hipDeviceSynchronize());
+    if (!s->d_wave_times) HIP_TRY(hipMalloc(&s->d_wave_times, n * 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(s->d_wave_times, 0, n * 2 * sizeof(unsigned long long)));
+    rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    std::vector<unsigned long long> host(n * 2);
+    if (e == hipSuccess) e = hipMemcpy(host.data(), s->d_wave_times, n * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(s->d_wave_times);
+    s->d_wave_times = nullptr;
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(TRX_ERR_NO_DEVICE, "timeline read-back failed: %s", hipGetErrorString(e));
+    uint32_t k = 0;
+    for (size_t i = 0; i < n && k < max_waves; i++)
+        if (host[2 * i]) {
+            out_times[2 * k] = host[2 * i];
+            out_times[2 * k + 1] = host[2 * i + 1];
+            k++;
+        }
+    *out_waves = k;
+    return TRX_OK;
 }
 
 // ---- host side: builder ----------------------------------------------------------------------

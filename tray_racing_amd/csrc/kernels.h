@@ -10,6 +10,7 @@
 namespace trx {
 
 constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kMaxBlock = 256;     // up to 4 waves per workgroup
 constexpr int kLdsStack = 12;      // traversal-stack entries per lane kept in LDS
 constexpr int kSpillStack = 52;    // further entries per lane in HBM (total 64 = oracle's ORC_STACK_SIZE)
 constexpr uint32_t kMaxSteps = 1u << 22; // per-ray iteration cap: every wave reaches an exit
@@ -32,6 +33,7 @@ struct SlotCounters {
     unsigned long long n_rays, n_node, n_tri, n_hits; // COUNT kernels only
     unsigned int max_stack;
     unsigned int pad2;
+    unsigned long long n_wave_node, n_wave_tri; // wave-level node / triangle step executions
 };
 
 struct TraceParams {
@@ -53,6 +55,8 @@ struct TraceParams {
     uint32_t tie_first;
     uint32_t refill_idle; // refill the wave when at least this many lanes are idle (1..64)
     uint32_t variant;
+    uint32_t waves_per_block;        // 1, 2 or 4
+    unsigned long long *wave_times;  // diagnostics: [2*wave] start, [2*wave+1] end (wall_clock64), or null
     ViewDev view;
 };
 

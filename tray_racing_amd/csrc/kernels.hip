@@ -219,11 +219,16 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 }
 
 template <int MODE, bool TLAS, int NODE, bool COUNT>
-__global__ void __launch_bounds__(kWave) k_trace(const TraceParams P) {
-    __shared__ uint2 lds_stack[kLdsStack * kWave];
-    const uint32_t lane = threadIdx.x;
-    uint2 *const spill = P.spill + (size_t)blockIdx.x * (kSpillStack * kWave) + lane;
+__global__ void __launch_bounds__(kMaxBlock) k_trace(const TraceParams P) {
+    // one stack region per wave of the workgroup; waves never synchronise with each other
+    extern __shared__ uint2 lds_dyn[];
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave_in_block = threadIdx.x / kWave;
+    const uint32_t wave_global = blockIdx.x * (blockDim.x / kWave) + wave_in_block;
+    uint2 *const lds_stack = lds_dyn + wave_in_block * (kLdsStack * kWave);
+    uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave) + lane;
     const bool tie_first = P.tie_first != 0;
+    if (P.wave_times && lane == 0) P.wave_times[2 * wave_global] = wall_clock64();
 
     // per-lane ray slot
     bool has_ray = false;
@@ -237,6 +242,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceParams P) {
     bool overflow = false;
     // COUNT only
     uint32_t c_node = 0, c_tri = 0, c_rays = 0, c_hits = 0, c_maxsp = 0, c_over = 0;
+    uint32_t c_wnode = 0, c_wtri = 0; // wave-level executions (leader lane only): SIMD-efficiency denominators
 
     bool exhausted = false; // wave-uniform
     for (;;) {
@@ -362,7 +368,10 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceParams P) {
                     if (TLAS) node_index += bvh_off;
                     const uint4 *np = P.nodes + (size_t)node_index * 5;
                     const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                    if (COUNT) c_node++;
+                    if (COUNT) {
+                        c_node++;
+                        if (lane_rank(__ballot(1)) == 0) c_wnode++;
+                    }
                     const uint32_t hitmask = node_intersect<NODE>(r, t, n0, n1, n2, n3, n4);
                     cur.x = n1.x;
                     tri.x = n1.y;
@@ -399,7 +408,10 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceParams P) {
                     }
                     const float4 *tp = P.tris + (size_t)gidx * 3;
                     const float4 a = tp[0], b = tp[1], c4 = tp[2];
-                    if (COUNT) c_tri++;
+                    if (COUNT) {
+                        c_tri++;
+                        if (lane_rank(__ballot(1)) == 0) c_wtri++;
+                    }
                     if (intersect_tri(r, a, b, c4, t, tie_first)) prim = gidx;
                 }
 
@@ -446,13 +458,16 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceParams P) {
         atomicAdd(&P.ctr->n_rays, (unsigned long long)c_rays);
         atomicAdd(&P.ctr->n_node, (unsigned long long)c_node);
         atomicAdd(&P.ctr->n_tri, (unsigned long long)c_tri);
+        atomicAdd(&P.ctr->n_wave_node, (unsigned long long)c_wnode);
+        atomicAdd(&P.ctr->n_wave_tri, (unsigned long long)c_wtri);
         atomicAdd(&P.ctr->n_hits, (unsigned long long)c_hits);
         atomicMax(&P.ctr->max_stack, c_maxsp);
     }
     if (lane == 0) {
         // the last wave out re-arms the queue for the next launch on this slot
+        if (P.wave_times) P.wave_times[2 * wave_global + 1] = wall_clock64();
         const unsigned int ticket = atomicAdd(&P.ctr->waves_done, 1u);
-        if (ticket == gridDim.x - 1u) {
+        if (ticket == gridDim.x * (blockDim.x / kWave) - 1u) {
             atomicExch(&P.ctr->next_item, 0u);
             atomicExch(&P.ctr->waves_done, 0u);
         }
@@ -461,7 +476,10 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceParams P) {
 
 template <int MODE, bool TLAS, int NODE, bool COUNT>
 hipError_t launch_one(const TraceParams &p, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL((k_trace<MODE, TLAS, NODE, COUNT>), dim3(grid), dim3(kWave), 0, stream, p);
+    // grid = total waves; p.waves_per_block waves share a workgroup (and nothing else)
+    const int wpb = (int)p.waves_per_block;
+    const size_t lds = (size_t)wpb * kLdsStack * kWave * sizeof(uint2);
+    hipLaunchKernelGGL((k_trace<MODE, TLAS, NODE, COUNT>), dim3(grid / wpb), dim3(kWave * wpb), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -488,7 +506,8 @@ hipError_t launch_mode(const TraceParams &p, bool tlas, int node, bool count, in
 template <int MODE, bool TLAS, int NODE, bool COUNT>
 int occupancy_one() {
     int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace<MODE, TLAS, NODE, COUNT>, kWave, 0) != hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace<MODE, TLAS, NODE, COUNT>, kWave,
+                                                     kLdsStack * kWave * sizeof(uint2)) != hipSuccess)
         return 0;
     return blocks;
 }
