@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--sem", type=int, default=3, help="trx_semantics bits (3 = TRX_SEM_CPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="frames in flight (1 = strictly one frame at a time)")
+    ap.add_argument("--sim-shards", type=int, default=1, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -78,43 +80,44 @@ def main():
     eye, look, fov = T.scene_camera(args.scene)
     view = T.view_from_camera(eye, look, fov, w, h)
     scene = T.Scene(flat, device=local_rank)
-    stream = torch.cuda.current_stream()
-    sp = stream.cuda_stream
-
+    # Frames are independent units of work: frame k runs on stream k % n_streams with its own
+    # buffers, so the tail of one frame (a few slow tiles) overlaps the start of the next.
+    n_streams = max(1, args.streams)
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
     shard_img = (rank, world, 0)
     shard_cmp = (rank, world, 1)
+    if args.sim_shards > 1:  # development aid: time one rank's shard of an N-way split on one GPU
+        shard_img = (0, args.sim_shards, 0)
     n_rays_total = w * h
-    fg = D.FrameGather(w, h, rank, world, "cuda")
-    locals_ = [fg.new_local(), fg.new_local()]
-    frame = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
+    fgs = [D.FrameGather(w, h, rank, world, "cuda") for _ in range(n_streams)]
+    locals_ = [fg.new_local() for fg in fgs]
+    frames = [torch.empty(n_rays_total, dtype=torch.int64, device="cuda") for _ in range(n_streams)]
 
     # algorithmic bytes of ONE launch on this rank (counting kernel = the reference's PROFILE_RT counters)
     st = scene.count_primary(view, w, h, sem=args.sem, shard=shard_img)
     launch_bytes = NODE_BYTES * st.n_node + TRI_BYTES * st.n_tri + HIT_BYTES * st.n_rays
 
-    def step(k, works):
+    def step(k):
+        j = k % n_streams
+        s = streams[j]
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
-        if world == 1:
-            # one GPU owns every tile: the kernel writes the row-major frame directly
-            ev0.record(stream)
-            scene.trace_primary_dev(view, w, h, frame.data_ptr(), sem=args.sem, shard=shard_img, stream=sp)
-            ev1.record(stream)
-            return ev0, ev1
-        buf = locals_[k & 1]
-        ev0.record(stream)
-        scene.trace_primary_dev(view, w, h, buf.data_ptr(), sem=args.sem, shard=shard_cmp, stream=sp)
-        ev1.record(stream)
-        if k > 0:
-            works[(k - 1) & 1].wait()
-            fg.assemble(frame)
-        works[k & 1] = fg.gather(buf, async_op=True)
+        with torch.cuda.stream(s):
+            if world == 1:
+                # one GPU owns every tile: the kernel writes the row-major frame directly
+                ev0.record(s)
+                scene.trace_primary_dev(view, w, h, frames[j].data_ptr(), sem=args.sem, shard=shard_img,
+                                        stream=s.cuda_stream)
+                ev1.record(s)
+            else:
+                ev0.record(s)
+                scene.trace_primary_dev(view, w, h, locals_[j].data_ptr(), sem=args.sem, shard=shard_cmp,
+                                        stream=s.cuda_stream)
+                ev1.record(s)
+                work = fgs[j].gather(locals_[j], async_op=True)  # the one collective: 8 B/ray all-gather
+                work.wait()                                      # stream s (not the host) waits for it
+                fgs[j].assemble(frames[j])
         return ev0, ev1
-
-    def finish(k_last, works):
-        if world > 1:
-            works[k_last & 1].wait()
-            fg.assemble(frame)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -122,20 +125,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    works = [None, None]
+    sync_all()
     for k in range(args.warmup):
-        step(k, works)
-    if args.warmup:
-        finish(args.warmup - 1, works)
+        step(k)
     sync_all()
     t0 = time.perf_counter()
     events = []
     for k in range(args.steps):
-        events.append(step(k, works))
-    finish(args.steps - 1, works)
+        events.append(step(k))
     sync_all()
     elapsed = time.perf_counter() - t0
-    scene.check(sp)
+    for s in streams:
+        scene.check(s.cuda_stream)
+    frame = frames[(args.steps - 1) % n_streams]
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
     t = torch.tensor([elapsed, kernel_ms * 1e-3, float(launch_bytes)], dtype=torch.float64, device="cuda")
@@ -143,7 +145,8 @@ def main():
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
-    value = n_rays_total * args.steps / elapsed / 1e6
+    rays_per_step = st.n_rays if args.sim_shards > 1 else n_rays_total
+    value = rays_per_step * args.steps / elapsed / 1e6
 
     out = None
     if rank == 0:
@@ -175,6 +178,7 @@ def main():
                 "builder": "binned-SAH BVH2 -> SAH-optimal BVH8 collapse (stands in for obvhs ploc_cwbvh)",
                 "parallelism": "8x8 tiles round-robin over %d rank(s), one all_gather of 8 B/ray per frame" % world,
                 "build_seconds": round(build_s, 2),
+                "frames_in_flight": n_streams,
             },
             "roofline": {
                 "bound": "hbm",

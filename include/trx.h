@@ -297,6 +297,10 @@ int trx_bvh_build_tris(const float *verts, uint64_t n_tris, uint32_t max_prims_p
  * (src/cwbvh.rs:114,132). */
 int trx_bvh_build_aabbs(const float *aabbs, uint64_t n, uint32_t max_prims_per_leaf,
                         int threads, trx_bvh **out);
+/* SAH weights of the 8-wide collapse for subsequent builds (process-wide): cost of visiting a node
+ * and of testing one primitive, the knobs behind the reference's --collapse-traversal-cost
+ * (src/main.rs:158-163, swept by src/auto_tune.rs:20-28).  Defaults 1.0 / 0.3. */
+int trx_set_build_costs(float traversal_cost, float prim_cost);
 void trx_bvh_destroy(trx_bvh *bvh);
 uint64_t trx_bvh_node_count(const trx_bvh *bvh);
 uint64_t trx_bvh_prim_count(const trx_bvh *bvh);

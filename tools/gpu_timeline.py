@@ -42,13 +42,16 @@ def timeline(tag):
     print("   alive waves at 0..100%% of the frame: %s" % alive, flush=True)
 
 
-for per_cu, wpb in [(0, 1), (8, 1), (12, 1), (16, 1), (20, 1), (24, 1), (32, 1), (16, 4), (20, 4), (24, 4), (20, 2)]:
-    v = 64 | (per_cu << 8) | (wpb << 16)
+NO_LPT, ONE_Q = 1 << 20, 1 << 21
+for tag, v in [("xcd queues + lpt", 64), ("xcd queues, no lpt", 64 | NO_LPT), ("single queue + lpt", 64 | ONE_Q),
+               ("single queue, no lpt", 64 | NO_LPT | ONE_Q), ("xcd+lpt 20 waves/CU", 64 | (20 << 8)),
+               ("xcd+lpt 12 waves/CU", 64 | (12 << 8)), ("xcd+lpt wpb4", 64 | (4 << 16))]:
     lib.trx_set_kernel_variant(v)
-    mn, mean = sc.bench_primary(view, w, h, sem=3, warmup=2, frames=10)
-    print("waves/CU %2d waves/block %d: min %.3f ms mean %.3f ms %.1f Mrays/s" % (per_cu, wpb, mn, mean, w * h / mn / 1e3),
-          flush=True)
-    if (per_cu, wpb) in [(0, 1), (12, 1), (20, 4)]:
+    mn, mean = sc.bench_primary(view, w, h, sem=3, warmup=8, frames=20)
+    print("%-24s: min %.3f ms mean %.3f ms %.1f Mrays/s" % (tag, mn, mean, w * h / mn / 1e3), flush=True)
+    if v in (64, 64 | NO_LPT):
+        for _ in range(6):
+            sc.trace_primary(view, w, h, sem=3)
         timeline("   timeline")
 lib.trx_set_kernel_variant(0)
 sc.close()

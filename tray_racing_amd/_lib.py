@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrx.so")
+LIB_PATH = os.environ.get("TRX_LIB") or os.path.join(_HERE, "libtrx.so")  # TRX_LIB: tuning builds
 
 TRX_OK = 0
 TRX_ERR_INVALID = -1
@@ -103,6 +103,7 @@ SIGNATURES = {
     "trx_shard_tiles": (_u32, [_u32, _u32, Shard]),
     "trx_bvh_build_tris": (_i, [_P, _u64, _u32, _i, C.POINTER(_P)]),
     "trx_bvh_build_aabbs": (_i, [_P, _u64, _u32, _i, C.POINTER(_P)]),
+    "trx_set_build_costs": (_i, [_f, _f]),
     "trx_bvh_destroy": (None, [_P]),
     "trx_bvh_node_count": (_u64, [_P]),
     "trx_bvh_prim_count": (_u64, [_P]),

@@ -30,6 +30,7 @@ namespace {
 
 thread_local std::string g_err;
 uint32_t g_variant = 0;
+float g_traversal_cost = 1.0f, g_prim_cost = 0.3f;
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -57,6 +58,11 @@ struct Slot {
     uint2 *spill = nullptr;
     hipEvent_t done = nullptr;
     bool used = false;
+    // tile-cost feedback: the previous frame traced on this slot measured every tile; the next one
+    // with the same image geometry starts its heaviest tiles first
+    uint32_t *cost = nullptr, *order = nullptr;
+    uint32_t lpt_capacity = 0;
+    uint64_t lpt_key = 0; // (width, height, shard) the order was built for; 0 = none
 };
 
 } // namespace
@@ -259,7 +265,32 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     grid = std::max((int)wpb, grid / (int)wpb * (int)wpb);
     p.waves_per_block = wpb;
     p.wave_times = s->d_wave_times;
+    p.single_queue = (g_variant >> 21) & 1u;
+    // tile order feedback (image modes, whole-tile refills only)
+    const bool lpt = mode != kModeRays && p.refill_idle == 64u && !((g_variant >> 20) & 1u);
+    const uint32_t n_tiles = (p.n_items + 63u) >> 6;
+    uint64_t key = 0;
+    if (lpt) {
+        if (slot.lpt_capacity < n_tiles) {
+            if (slot.cost) (void)hipFree(slot.cost);
+            if (slot.order) (void)hipFree(slot.order);
+            slot.cost = slot.order = nullptr;
+            slot.lpt_capacity = 0;
+            slot.lpt_key = 0;
+            HIP_TRY(hipMalloc(&slot.cost, (size_t)n_tiles * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&slot.order, (size_t)n_tiles * sizeof(uint32_t)));
+            slot.lpt_capacity = n_tiles;
+        }
+        key = ((uint64_t)p.width << 40) ^ ((uint64_t)p.height << 20) ^ ((uint64_t)p.shard_count << 8) ^ p.shard_index ^
+              ((uint64_t)(mode + 1) << 60);
+        p.order = slot.lpt_key == key ? slot.order : nullptr;
+        p.cost = slot.cost;
+    }
     HIP_TRY(launch_trace(p, mode, s->tlas, sem, count, grid, stream));
+    if (lpt) {
+        HIP_TRY(launch_sort_tiles(slot.cost, n_tiles, slot.order, stream));
+        slot.lpt_key = key;
+    }
     HIP_TRY(hipEventRecord(slot.done, stream));
     slot.used = true;
     if (ctr_out) *ctr_out = slot.ctr;
@@ -421,6 +452,8 @@ void trx_scene_destroy(trx_scene *s) {
     for (Slot &sl : s->slots) {
         if (sl.ctr) (void)hipFree(sl.ctr);
         if (sl.spill) (void)hipFree(sl.spill);
+        if (sl.cost) (void)hipFree(sl.cost);
+        if (sl.order) (void)hipFree(sl.order);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -798,6 +831,8 @@ int trx_bvh_build_tris(const float *verts, uint64_t n, uint32_t max_prims, int t
     BuildParams bp;
     bp.max_prims_per_leaf = max_prims;
     bp.threads = threads;
+    bp.traversal_cost = g_traversal_cost;
+    bp.prim_cost = g_prim_cost;
     try {
         build_cwbvh_from_tris(verts, n, bp, b->bvh);
     } catch (const std::exception &) {
@@ -817,6 +852,8 @@ int trx_bvh_build_aabbs(const float *aabbs, uint64_t n, uint32_t max_prims, int 
     BuildParams bp;
     bp.max_prims_per_leaf = max_prims;
     bp.threads = threads;
+    bp.traversal_cost = g_traversal_cost;
+    bp.prim_cost = g_prim_cost;
     try {
         build_cwbvh_from_aabbs((const Aabb *)aabbs, n, bp, b->bvh);
     } catch (const std::exception &) {
@@ -824,6 +861,13 @@ int trx_bvh_build_aabbs(const float *aabbs, uint64_t n, uint32_t max_prims, int 
         return fail(TRX_ERR_OOM, "out of memory building the BVH");
     }
     *out = b;
+    return TRX_OK;
+}
+
+int trx_set_build_costs(float traversal_cost, float prim_cost) {
+    if (!(traversal_cost > 0.f) || !(prim_cost > 0.f)) return fail(TRX_ERR_INVALID, "costs must be positive");
+    g_traversal_cost = traversal_cost;
+    g_prim_cost = prim_cost;
     return TRX_OK;
 }
 
@@ -851,6 +895,8 @@ int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32
     BuildParams bp;
     bp.max_prims_per_leaf = max_prims;
     bp.threads = threads;
+    bp.traversal_cost = g_traversal_cost;
+    bp.prim_cost = g_prim_cost;
     try {
         // without --tlas everything is flattened into the first object (src/main.rs:300-308)
         std::vector<uint64_t> counts;

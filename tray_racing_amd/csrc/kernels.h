@@ -11,8 +11,14 @@ namespace trx {
 
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kMaxBlock = 256;     // up to 4 waves per workgroup
-constexpr int kLdsStack = 12;      // traversal-stack entries per lane kept in LDS
-constexpr int kSpillStack = 52;    // further entries per lane in HBM (total 64 = oracle's ORC_STACK_SIZE)
+#ifndef TRX_LDS_STACK
+#define TRX_LDS_STACK 12
+#endif
+#ifndef TRX_MIN_WAVES
+#define TRX_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for
+#endif
+constexpr int kLdsStack = TRX_LDS_STACK;        // traversal-stack entries per lane kept in LDS
+constexpr int kSpillStack = 64 - TRX_LDS_STACK; // further entries per lane in HBM (total 64 = oracle's ORC_STACK_SIZE)
 constexpr uint32_t kMaxSteps = 1u << 22; // per-ray iteration cap: every wave reaches an exit
 
 enum TraceMode : int { kModePrimary = 0, kModeAo = 1, kModeRays = 2 };
@@ -25,8 +31,13 @@ struct ViewDev {
 };
 
 // Device-side counters of one launch slot.
+struct alignas(128) QueueHead {
+    unsigned int taken; // chunks handed out from this queue (self-resetting)
+    unsigned int pad[31];
+};
+
 struct SlotCounters {
-    unsigned int next_item;  // work queue head (self-resetting)
+    QueueHead heads[8];      // one work-queue head per XCD, each on its own 128-byte line
     unsigned int waves_done; // exit ticket (self-resetting)
     unsigned int overflow;   // rays whose stack overflowed or that hit the step cap (sticky)
     unsigned int pad;
@@ -49,7 +60,10 @@ struct TraceParams {
     uint32_t tlas_start;
     uint32_t width, height, tiles_x;
     uint32_t shard_index, shard_count;
-    uint32_t compact; // TRX_LAYOUT_SHARD: hit buffers indexed by work item
+    uint32_t compact; // TRX_LAYOUT_SHARD: hit buffers indexed by local_tile*64 + pixel-in-tile
+    uint32_t single_queue;  // tuning: one global queue instead of one per XCD
+    const uint32_t *order;  // chunk -> local tile (heaviest tiles first), or null = identity
+    uint32_t *cost;         // per-chunk cost feedback (wall-clock ticks), or null
     uint32_t frame;
     float ao_eps;
     uint32_t tie_first;
@@ -62,6 +76,9 @@ struct TraceParams {
 
 // Resident waves the persistent kernel should be launched with on `device`.
 int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count);
+
+// Builds the heaviest-first tile order for the next frame from measured per-tile costs.
+hipError_t launch_sort_tiles(const uint32_t *cost, uint32_t n_tiles, uint32_t *order, hipStream_t stream);
 
 // Enqueues one traversal kernel.  sem: trx_semantics bits.
 hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, int grid,

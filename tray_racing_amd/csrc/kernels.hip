@@ -214,12 +214,18 @@ __device__ __forceinline__ void sincos_det(float theta, float &s, float &c) {
     }
 }
 
+__device__ __forceinline__ uint32_t read_xcc_id() {
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x;
+}
+
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
 template <int MODE, bool TLAS, int NODE, bool COUNT>
-__global__ void __launch_bounds__(kMaxBlock) k_trace(const TraceParams P) {
+__global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceParams P) {
     // one stack region per wave of the workgroup; waves never synchronise with each other
     extern __shared__ uint2 lds_dyn[];
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -244,18 +250,67 @@ __global__ void __launch_bounds__(kMaxBlock) k_trace(const TraceParams P) {
     uint32_t c_node = 0, c_tri = 0, c_rays = 0, c_hits = 0, c_maxsp = 0, c_over = 0;
     uint32_t c_wnode = 0, c_wtri = 0; // wave-level executions (leader lane only): SIMD-efficiency denominators
 
+    // ---- work queues ---------------------------------------------------------------------
+    // Work is cut into chunks of 64 items (one 8x8 tile, or 64 explicit rays).  Chunk p belongs
+    // to queue p % 8 (ticket k of queue q is chunk 8k + q); a wave pulls from the queue of the XCD
+    // it runs on (one atomic head per XCD: a single head saturates near 90 dequeues/us) and
+    // steals from the other queues when its own runs dry.  The next ticket is requested as soon
+    // as the current one is taken, so the atomic's round trip overlaps the traversal.  P.order
+    // (when present) lists tiles heaviest-first, so every queue starts with its heavy tiles.
+    const uint32_t n_chunks = (P.n_items + 63u) >> 6;
+    uint32_t my_q = P.single_queue ? 0u : (read_xcc_id() & 7u);
+    uint32_t q_probes = 0;
+    uint32_t pending = 0; // prefetched ticket of queue my_q (lane 0)
+    if (lane == 0) pending = atomicAdd(&P.ctr->heads[my_q].taken, 1u);
+    uint32_t chunk_next = 0, chunk_left = 0; // items of the current chunk not yet handed to a lane
+    uint32_t tile_slot = TRX_INVALID;        // LPT feedback: chunk being timed
+    unsigned long long tile_t0 = 0;
+
     bool exhausted = false; // wave-uniform
     for (;;) {
-        // ---- refill idle lanes from the global queue --------------------------------
+        // ---- refill idle lanes from the queues --------------------------------------------
         const unsigned long long idle = __ballot(!has_ray);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (tile_slot != TRX_INVALID && n_idle == (uint32_t)kWave) {
+            // the whole tile is done: record what it cost (feeds the next frame's tile order)
+            if (lane == 0) P.cost[tile_slot] = (uint32_t)(wall_clock64() - tile_t0);
+            tile_slot = TRX_INVALID;
+        }
         if (!exhausted && n_idle >= P.refill_idle) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&P.ctr->next_item, n_idle);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base + n_idle >= P.n_items || base + n_idle < base) exhausted = true;
-            const uint32_t item = base + lane_rank(idle);
-            if (!has_ray && item < P.n_items && base <= item) {
+            const uint32_t rank = lane_rank(idle);
+            uint32_t given = 0, item = TRX_INVALID;
+            while (given < n_idle) {
+                if (chunk_left == 0u) {
+                    // take the prefetched ticket; walk to the next queue when this one is dry
+                    uint32_t ticket = __builtin_amdgcn_readfirstlane(pending);
+                    uint32_t q_count = P.single_queue ? n_chunks : ((n_chunks + 7u - my_q) >> 3);
+                    while (ticket >= q_count) {
+                        if (++q_probes >= (P.single_queue ? 1u : 8u)) break;
+                        my_q = (my_q + 1u) & 7u;
+                        if (lane == 0) pending = atomicAdd(&P.ctr->heads[my_q].taken, 1u);
+                        ticket = __builtin_amdgcn_readfirstlane(pending);
+                        q_count = (n_chunks + 7u - my_q) >> 3;
+                    }
+                    if (ticket >= q_count) {
+                        exhausted = true;
+                        break;
+                    }
+                    if (lane == 0) pending = atomicAdd(&P.ctr->heads[my_q].taken, 1u); // prefetch the next one
+                    const uint32_t chunk = P.single_queue ? ticket : ticket * 8u + my_q;
+                    chunk_next = chunk << 6;
+                    chunk_left = min(64u, P.n_items - chunk_next);
+                    if (P.cost && n_idle == (uint32_t)kWave && given == 0u) {
+                        tile_slot = P.order ? P.order[chunk] : chunk; // cost is filed under the tile, not the chunk
+                        tile_t0 = wall_clock64();
+                    }
+                }
+                const uint32_t take = min(n_idle - given, chunk_left);
+                if (rank >= given && rank < given + take) item = chunk_next + (rank - given);
+                chunk_next += take;
+                chunk_left -= take;
+                given += take;
+            }
+            if (!has_ray && item != TRX_INVALID) {
                 bool ok = false;
                 float dx = 0.0f, dy = 0.0f, dz = 0.0f;
                 if (MODE == kModeRays) {
@@ -267,12 +322,13 @@ __global__ void __launch_bounds__(kMaxBlock) k_trace(const TraceParams P) {
                     out_index = item;
                     ok = true;
                 } else {
-                    const uint32_t tile = (item >> 6) * P.shard_count + P.shard_index;
+                    const uint32_t chunk = item >> 6;
+                    const uint32_t tile = (P.order ? P.order[chunk] : chunk) * P.shard_count + P.shard_index;
                     const uint32_t k = item & 63u;
                     const uint32_t px = (tile % P.tiles_x) * 8u + (k & 7u);
                     const uint32_t py = (tile / P.tiles_x) * 8u + (k >> 3);
                     if (px < P.width && py < P.height) {
-                        out_index = P.compact ? item : py * P.width + px;
+                        out_index = P.compact ? (tile / P.shard_count) * 64u + k : py * P.width + px;
                         primary_dir(P.view, P.width, P.height, px, py, dx, dy, dz);
                         if (MODE == kModePrimary) {
                             r.ox = P.view.eye[0]; r.oy = P.view.eye[1]; r.oz = P.view.eye[2];
@@ -407,7 +463,10 @@ __global__ void __launch_bounds__(kMaxBlock) k_trace(const TraceParams P) {
                         break;
                     }
                     const float4 *tp = P.tris + (size_t)gidx * 3;
-                    const float4 a = tp[0], b = tp[1], c4 = tp[2];
+                    float4 a = tp[0], b = tp[1], c4 = tp[2];
+                    // keep the three 16-byte loads together: left alone the compiler sinks the v0 load
+                    // behind the determinant, which serialises two memory latencies per triangle
+                    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c4.x), "+v"(c4.y), "+v"(c4.z));
                     if (COUNT) {
                         c_tri++;
                         if (lane_rank(__ballot(1)) == 0) c_wtri++;
@@ -468,9 +527,39 @@ __global__ void __launch_bounds__(kMaxBlock) k_trace(const TraceParams P) {
         if (P.wave_times) P.wave_times[2 * wave_global + 1] = wall_clock64();
         const unsigned int ticket = atomicAdd(&P.ctr->waves_done, 1u);
         if (ticket == gridDim.x * (blockDim.x / kWave) - 1u) {
-            atomicExch(&P.ctr->next_item, 0u);
+            for (int q = 0; q < 8; q++) atomicExch(&P.ctr->heads[q].taken, 0u);
             atomicExch(&P.ctr->waves_done, 0u);
         }
+    }
+}
+
+// Longest-processing-time-first tile order from the previous frame's measured tile costs.
+// Counting sort on a log-scale key (8 buckets per octave), heaviest first; sorted position p is
+// chunk p, which belongs to queue p % 8, so every XCD's queue starts with heavy tiles.
+// One workgroup; n ~ 32k.
+__device__ __forceinline__ uint32_t cost_bucket(uint32_t c) {
+    if (c == 0u) return 0u;
+    const uint32_t msb = 31u - (uint32_t)__clz((int)c);
+    const uint32_t frac = msb >= 3u ? (c >> (msb - 3u)) & 7u : (c << (3u - msb)) & 7u;
+    return min(255u, msb * 8u + frac);
+}
+
+__global__ void __launch_bounds__(1024) k_sort_tiles(const uint32_t *cost, uint32_t n, uint32_t *order) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t cursor[256];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 256u) hist[tid] = 0u;
+    __syncthreads();
+    for (uint32_t t = tid; t < n; t += 1024u) atomicAdd(&hist[cost_bucket(cost[t])], 1u);
+    __syncthreads();
+    if (tid < 256u) {
+        uint32_t s = 0u;
+        for (uint32_t b = tid + 1u; b < 256u; b++) s += hist[b];
+        cursor[tid] = s; // first sorted position of this bucket (descending cost)
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < n; t += 1024u) {
+        order[atomicAdd(&cursor[cost_bucket(cost[t])], 1u)] = t;
     }
 }
 
@@ -529,6 +618,11 @@ int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count) {
     if (per_cu <= 0) per_cu = 8;
     if (per_cu > 32) per_cu = 32;
     return per_cu * prop.multiProcessorCount;
+}
+
+hipError_t launch_sort_tiles(const uint32_t *cost, uint32_t n_tiles, uint32_t *order, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sort_tiles, dim3(1), dim3(1024), 0, stream, cost, n_tiles, order);
+    return hipGetLastError();
 }
 
 hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, int grid,

@@ -94,8 +94,11 @@ class FlatScene:
         return self.instance_offsets.size > 0
 
 
-def flat_build(verts, object_counts=None, use_tlas=False, max_prims_per_leaf=3, threads=0):
+def flat_build(verts, object_counts=None, use_tlas=False, max_prims_per_leaf=3, threads=0, traversal_cost=None,
+               prim_cost=None):
     lib = L.load()
+    if traversal_cost is not None or prim_cost is not None:
+        L.check(lib.trx_set_build_costs(traversal_cost or 1.0, prim_cost or 0.3))
     verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
     if object_counts is None:
         object_counts = [verts.shape[0]]
