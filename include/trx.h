@@ -278,6 +278,12 @@ int trx_debug_wave_timeline(trx_scene *scene, const trx_view *view, uint32_t wid
                             uint32_t semantics, uint64_t *out_times, uint32_t max_waves,
                             uint32_t *out_waves);
 
+/* Diagnostics: per 8x8 tile (row-major tile id) the wall-clock cost of the tile in a normal frame
+ * (100 MHz ticks) and its wave-level iteration counts from a counting frame:
+ * (node steps << 16) | triangle rounds.  n_tiles = ceil(w/8) * ceil(h/8). */
+int trx_debug_tile_profile(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                           uint32_t semantics, uint32_t *out_cost, uint32_t *out_iters, uint32_t n_tiles);
+
 /* Kernel variant selection (tuning aid; 0 = default).  Returns the previous
  * value.  Variants compute identical results. */
 uint32_t trx_set_kernel_variant(uint32_t variant);

@@ -393,3 +393,27 @@ def test_full_size_hairball_ao_and_tlas_4k_sample(trx, orc):
     rec = sel[:, None] * 64 + np.arange(64)[None, :]
     assert_hits_equal(got[rec.ravel()], full[(py * w + px).ravel()], "san_miguel tlas 4k shard sample")
     sc.close()
+
+
+def test_bench_two_ranks_share_the_gpu(trx):
+    """bench.py's N > 1 path end to end on one GPU: two ranks (gloo, shard gather staged through
+    host memory) trace their tile shards on device 0; rank 0 checks the assembled frame."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "2", "--tris", "150000", "--width", "256", "--height", "136", "--dist-backend", "gloo",
+           "--verify", "--streams", "2", "--roofline-launches", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["parity_vs_oracle_full_frame"] is True and d["value"] > 0
+    assert d["scaling"] == "strong" and d["config"]["frames_in_flight"] == 2

@@ -99,6 +99,7 @@ SIGNATURES = {
     "trx_traverse1": (_i, [_P, C.POINTER(Ray), _u32, C.POINTER(RayHit)]),
     "trx_bench_primary": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _u32, _u32, C.POINTER(_f), C.POINTER(_f)]),
     "trx_set_kernel_variant": (_u32, [_u32]),
+    "trx_debug_tile_profile": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, _P, _u32]),
     "trx_debug_wave_timeline": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, _u32, C.POINTER(_u32)]),
     "trx_shard_tiles": (_u32, [_u32, _u32, Shard]),
     "trx_bvh_build_tris": (_i, [_P, _u64, _u32, _i, C.POINTER(_P)]),

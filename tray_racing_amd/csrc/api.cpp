@@ -56,13 +56,14 @@ constexpr uint32_t kDefaultWavesPerBlock = 1;
 struct Slot {
     SlotCounters *ctr = nullptr;
     uint2 *spill = nullptr;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr; // everything enqueued for this slot has finished
     bool used = false;
     // tile-cost feedback: the previous frame traced on this slot measured every tile; the next one
     // with the same image geometry starts its heaviest tiles first
-    uint32_t *cost = nullptr, *order = nullptr;
+    uint32_t *lpt = nullptr; // two sets of {16 counts, 16 lists}
     uint32_t lpt_capacity = 0;
-    uint64_t lpt_key = 0; // (width, height, shard) the order was built for; 0 = none
+    uint32_t lpt_parity = 0; // set written by the next frame
+    uint64_t lpt_key = 0;    // (width, height, shard, mode) the lists were measured for; 0 = none
 };
 
 } // namespace
@@ -78,6 +79,7 @@ struct trx_scene {
     int grid = 0;      // default number of persistent waves
     int cu_count = 0;
     unsigned long long *d_wave_times = nullptr; // diagnostics only (trx_debug_wave_timeline)
+    uint32_t *dbg_cost = nullptr, *dbg_iters = nullptr; // diagnostics only (trx_debug_tile_profile)
     Slot slots[kSlots];
     int next_slot = 0;
     std::mutex mu;
@@ -271,26 +273,49 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     const uint32_t n_tiles = (p.n_items + 63u) >> 6;
     uint64_t key = 0;
     if (lpt) {
-        if (slot.lpt_capacity < n_tiles) {
-            if (slot.cost) (void)hipFree(slot.cost);
-            if (slot.order) (void)hipFree(slot.order);
-            slot.cost = slot.order = nullptr;
+        // per slot: two sets of {16 bucket counts, 16 lists of n_tiles tile ids}; a frame reads the
+        // set the previous frame on this slot wrote and writes the other one
+        const uint32_t n_lists = 16 * kLptShards;
+        const uint32_t list_cap = n_tiles / 2 + 64; // a list holds ~1/8 of one bucket; overflow only drops the order
+        const size_t set_words = n_lists + (size_t)n_lists * list_cap;
+        if (slot.lpt_capacity != n_tiles) {
+            if (slot.lpt) (void)hipFree(slot.lpt);
+            slot.lpt = nullptr;
             slot.lpt_capacity = 0;
             slot.lpt_key = 0;
-            HIP_TRY(hipMalloc(&slot.cost, (size_t)n_tiles * sizeof(uint32_t)));
-            HIP_TRY(hipMalloc(&slot.order, (size_t)n_tiles * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&slot.lpt, 2 * set_words * sizeof(uint32_t)));
             slot.lpt_capacity = n_tiles;
         }
         key = ((uint64_t)p.width << 40) ^ ((uint64_t)p.height << 20) ^ ((uint64_t)p.shard_count << 8) ^ p.shard_index ^
               ((uint64_t)(mode + 1) << 60);
-        p.order = slot.lpt_key == key ? slot.order : nullptr;
-        p.cost = slot.cost;
+        uint32_t *set[2] = {slot.lpt, slot.lpt + set_words};
+        if (slot.lpt_key != key) { // new geometry: empty both sets, cold (identity) order this frame
+            HIP_TRY(hipMemsetAsync(set[0], 0, n_lists * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(set[1], 0, n_lists * sizeof(uint32_t), stream));
+            slot.lpt_parity = 0;
+            slot.lpt_key = key;
+        } else {
+            p.lpt_read_counts = set[slot.lpt_parity ^ 1];
+            p.lpt_read_lists = set[slot.lpt_parity ^ 1] + n_lists;
+        }
+        p.lpt_write_counts = set[slot.lpt_parity];
+        p.lpt_write_lists = set[slot.lpt_parity] + n_lists;
+        p.lpt_cap = list_cap;
+        slot.lpt_parity ^= 1;
+        // priority classes over the heaviest-first order (tuning: variant bits 22..24 pick the cuts)
+        // measured on bistro-class 1080p: {32,8,2} 0.566 ms, {64,16,4} 0.572, {128,32,8} 0.585, none 0.630
+        static const uint32_t cuts[8][3] = {{32, 8, 2}, {0, 0, 0}, {256, 64, 16}, {64, 16, 4}, {512, 128, 32},
+                                            {128, 0, 0}, {128, 32, 8}, {1024, 256, 64}};
+        const uint32_t *c = cuts[(g_variant >> 22) & 7u];
+        for (int i = 0; i < 3; i++) p.prio_cut[i] = c[i] ? n_tiles / c[i] : 0u;
+    }
+    if (s->dbg_cost) { // diagnostics: cold tile order, costs / iteration counts into the caller's buffers
+        p.lpt_read_counts = nullptr;
+        p.lpt_read_lists = nullptr;
+        p.cost = s->dbg_cost;
+        p.tile_iters = s->dbg_iters;
     }
     HIP_TRY(launch_trace(p, mode, s->tlas, sem, count, grid, stream));
-    if (lpt) {
-        HIP_TRY(launch_sort_tiles(slot.cost, n_tiles, slot.order, stream));
-        slot.lpt_key = key;
-    }
     HIP_TRY(hipEventRecord(slot.done, stream));
     slot.used = true;
     if (ctr_out) *ctr_out = slot.ctr;
@@ -452,8 +477,7 @@ void trx_scene_destroy(trx_scene *s) {
     for (Slot &sl : s->slots) {
         if (sl.ctr) (void)hipFree(sl.ctr);
         if (sl.spill) (void)hipFree(sl.spill);
-        if (sl.cost) (void)hipFree(sl.cost);
-        if (sl.order) (void)hipFree(sl.order);
+        if (sl.lpt) (void)hipFree(sl.lpt);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -787,6 +811,39 @@ int trx_bench_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h
     if (out_min_ms) *out_min_ms = mn;
     if (out_mean_ms) *out_mean_ms = (float)(sum / frames);
     return trx_scene_check(s, nullptr);
+}
+
+// Diagnostics: per-tile cost (100 MHz ticks, from a normal frame) and per-tile wave-level
+// iteration counts ((node steps << 16) | triangle rounds, from a counting frame), cold tile order.
+int trx_debug_tile_profile(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem,
+                           uint32_t *out_cost, uint32_t *out_iters, uint32_t n_tiles) {
+    if (!s || !out_cost || !out_iters) return fail(TRX_ERR_INVALID, "null argument");
+    if (n_tiles != ((w + 7) / 8) * ((h + 7) / 8)) return fail(TRX_ERR_INVALID, "n_tiles does not match the image");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = ensure_scratch(s, (uint64_t)w * h, 0);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMalloc(&s->dbg_cost, (size_t)n_tiles * 4));
+    hipError_t e = hipMalloc(&s->dbg_iters, (size_t)n_tiles * 4);
+    if (e == hipSuccess) e = hipMemset(s->dbg_iters, 0, (size_t)n_tiles * 4);
+    trx_stats st;
+    if (e == hipSuccess) rc = trx_count_primary(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, &st);
+    if (e == hipSuccess && !rc) e = hipMemcpy(out_iters, s->dbg_iters, (size_t)n_tiles * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && !rc) {
+        uint32_t *iters = s->dbg_iters;
+        s->dbg_iters = nullptr; // second pass: the normal kernel
+        for (int i = 0; i < 3 && !rc; i++) rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, nullptr);
+        s->dbg_iters = iters;
+        if (!rc) e = hipDeviceSynchronize();
+        if (e == hipSuccess && !rc) e = hipMemcpy(out_cost, s->dbg_cost, (size_t)n_tiles * 4, hipMemcpyDeviceToHost);
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipFree(s->dbg_cost);
+    if (s->dbg_iters) (void)hipFree(s->dbg_iters);
+    s->dbg_cost = s->dbg_iters = nullptr;
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(TRX_ERR_NO_DEVICE, "tile profile failed: %s", hipGetErrorString(e));
+    return TRX_OK;
 }
 
 // Diagnostics: per-wave [start, end] wall-clock stamps (100 MHz ticks) of one primary frame.

@@ -11,6 +11,7 @@ namespace trx {
 
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kMaxBlock = 256;     // up to 4 waves per workgroup
+constexpr uint32_t kLptShards = 8; // appenders per tile-cost bucket (16 buckets x 8 shards = 128 lists)
 #ifndef TRX_LDS_STACK
 #define TRX_LDS_STACK 12
 #endif
@@ -62,8 +63,15 @@ struct TraceParams {
     uint32_t shard_index, shard_count;
     uint32_t compact; // TRX_LAYOUT_SHARD: hit buffers indexed by local_tile*64 + pixel-in-tile
     uint32_t single_queue;  // tuning: one global queue instead of one per XCD
-    const uint32_t *order;  // chunk -> local tile (heaviest tiles first), or null = identity
-    uint32_t *cost;         // per-chunk cost feedback (wall-clock ticks), or null
+    // tile order feedback: 16 x kLptShards list counts + lists (lpt_cap entries each) read / written this frame
+    uint32_t *lpt_read_counts;
+    const uint32_t *lpt_read_lists;
+    uint32_t *lpt_write_counts;
+    uint32_t *lpt_write_lists;
+    uint32_t lpt_cap;
+    uint32_t *cost;         // diagnostics: per-tile cost (wall-clock ticks), or null
+    uint32_t prio_cut[3];   // chunks below these (heaviest-first) indices run at s_setprio 3 / 2 / 1
+    uint32_t *tile_iters;   // diagnostics (COUNT kernels): per tile (node steps << 16) | triangle rounds
     uint32_t frame;
     float ao_eps;
     uint32_t tie_first;
@@ -76,9 +84,6 @@ struct TraceParams {
 
 // Resident waves the persistent kernel should be launched with on `device`.
 int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count);
-
-// Builds the heaviest-first tile order for the next frame from measured per-tile costs.
-hipError_t launch_sort_tiles(const uint32_t *cost, uint32_t n_tiles, uint32_t *order, hipStream_t stream);
 
 // Enqueues one traversal kernel.  sem: trx_semantics bits.
 hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, int grid,

@@ -249,22 +249,46 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // COUNT only
     uint32_t c_node = 0, c_tri = 0, c_rays = 0, c_hits = 0, c_maxsp = 0, c_over = 0;
     uint32_t c_wnode = 0, c_wtri = 0; // wave-level executions (leader lane only): SIMD-efficiency denominators
+    uint32_t s_wnode = 0, s_wtri = 0; // their values when the current tile started
 
     // ---- work queues ---------------------------------------------------------------------
     // Work is cut into chunks of 64 items (one 8x8 tile, or 64 explicit rays).  Chunk p belongs
     // to queue p % 8 (ticket k of queue q is chunk 8k + q); a wave pulls from the queue of the XCD
     // it runs on (one atomic head per XCD: a single head saturates near 90 dequeues/us) and
     // steals from the other queues when its own runs dry.  The next ticket is requested as soon
-    // as the current one is taken, so the atomic's round trip overlaps the traversal.  P.order
-    // (when present) lists tiles heaviest-first, so every queue starts with its heavy tiles.
+    // as the current one is taken, so the atomic's round trip overlaps the traversal.
+    //
+    // Tile order feedback: a wave that finishes a tile files it in one of 16 cost buckets
+    // (sqrt(2)-wide classes of the tile's wall-clock time) of the NEXT frame's lists; this frame
+    // reads the lists the previous frame wrote, heaviest bucket first, so chunk p is the p-th
+    // heaviest tile (longest-processing-time-first) and every queue starts with heavy tiles.
     const uint32_t n_chunks = (P.n_items + 63u) >> 6;
     uint32_t my_q = P.single_queue ? 0u : (read_xcc_id() & 7u);
     uint32_t q_probes = 0;
     uint32_t pending = 0; // prefetched ticket of queue my_q (lane 0)
     if (lane == 0) pending = atomicAdd(&P.ctr->heads[my_q].taken, 1u);
     uint32_t chunk_next = 0, chunk_left = 0; // items of the current chunk not yet handed to a lane
-    uint32_t tile_slot = TRX_INVALID;        // LPT feedback: chunk being timed
+    uint32_t tile_slot = TRX_INVALID;        // tile being timed (cost feedback)
     unsigned long long tile_t0 = 0;
+    uint32_t cur_tile = 0, my_tile = 0;      // tile of the current chunk (uniform) / of this lane's item
+    // Lists are kept per (cost bucket, shard): kLptShards appenders per bucket, because one atomic
+    // word saturates near 90 appends/us.  Entry e = (15 - bucket) * kLptShards + shard is the e-th
+    // list of the heaviest-first concatenation; lane l holds the (exclusive) ends of entries l, l+64.
+    uint32_t end_a = 0, end_b = 0;
+    bool ordered = false;
+    if (P.lpt_read_counts) {
+        end_a = P.lpt_read_counts[(15u - (lane >> 3)) * kLptShards + (lane & 7u)];
+        end_b = P.lpt_read_counts[(15u - ((lane + 64u) >> 3)) * kLptShards + (lane & 7u)];
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t ya = __shfl_up(end_a, off), yb = __shfl_up(end_b, off);
+            if ((int)lane >= off) {
+                end_a += ya;
+                end_b += yb;
+            }
+        }
+        end_b += (uint32_t)__builtin_amdgcn_readlane((int)end_a, 63);
+        ordered = (uint32_t)__builtin_amdgcn_readlane((int)end_b, 63) == n_chunks; // complete lists for this geometry
+    }
 
     bool exhausted = false; // wave-uniform
     for (;;) {
@@ -273,7 +297,28 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (tile_slot != TRX_INVALID && n_idle == (uint32_t)kWave) {
             // the whole tile is done: record what it cost (feeds the next frame's tile order)
-            if (lane == 0) P.cost[tile_slot] = (uint32_t)(wall_clock64() - tile_t0);
+            if (lane == 0) {
+                const uint32_t c = (uint32_t)(wall_clock64() - tile_t0);
+                if (P.cost) P.cost[tile_slot] = c;
+                if (P.lpt_write_counts) {
+                    // class = 2*log2(c) in half-octaves, 2.56 us .. 0.49 ms
+                    const uint32_t msb = 31u - (uint32_t)__clz((int)(c | 1u));
+                    const uint32_t kk = 2u * msb + (msb ? (c >> (msb - 1u)) & 1u : 0u);
+                    const uint32_t b = kk < 16u ? 0u : min(kk - 16u, 15u);
+                    const uint32_t list = b * kLptShards + ((wave_global ^ tile_slot) & (kLptShards - 1u));
+                    const uint32_t pos = atomicAdd(&P.lpt_write_counts[list], 1u);
+                    if (pos < P.lpt_cap) P.lpt_write_lists[(size_t)list * P.lpt_cap + pos] = tile_slot;
+                }
+            }
+            if (COUNT && P.tile_iters) {
+                // wave-level node steps and triangle rounds of this tile (each is counted by one lane)
+                uint32_t dn = c_wnode - s_wnode, dt = c_wtri - s_wtri;
+                for (int off = 32; off > 0; off >>= 1) {
+                    dn += __shfl_xor(dn, off);
+                    dt += __shfl_xor(dt, off);
+                }
+                if (lane == 0) P.tile_iters[tile_slot] = (min(dn, 65535u) << 16) | min(dt, 65535u);
+            }
             tile_slot = TRX_INVALID;
         }
         if (!exhausted && n_idle >= P.refill_idle) {
@@ -299,13 +344,36 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     const uint32_t chunk = P.single_queue ? ticket : ticket * 8u + my_q;
                     chunk_next = chunk << 6;
                     chunk_left = min(64u, P.n_items - chunk_next);
-                    if (P.cost && n_idle == (uint32_t)kWave && given == 0u) {
-                        tile_slot = P.order ? P.order[chunk] : chunk; // cost is filed under the tile, not the chunk
+                    cur_tile = chunk;
+                    if (ordered) {
+                        // chunk -> bucket (heaviest first) -> tile
+                        uint32_t j = (uint32_t)__popcll(__ballot(chunk >= end_a));
+                        if (j == 64u) j += (uint32_t)__popcll(__ballot(chunk >= end_b));
+                        const uint32_t start = j == 0u ? 0u
+                                               : j <= 64u ? (uint32_t)__builtin_amdgcn_readlane((int)end_a, (int)(j - 1u))
+                                                          : (uint32_t)__builtin_amdgcn_readlane((int)end_b, (int)(j - 65u));
+                        const uint32_t list = (15u - (j >> 3)) * kLptShards + (j & 7u);
+                        cur_tile = P.lpt_read_lists[(size_t)list * P.lpt_cap + (chunk - start)];
+                        cur_tile = __builtin_amdgcn_readfirstlane(cur_tile);
+                        // the tiles that set the frame's critical path get issue priority over the
+                        // waves they share a SIMD with
+                        if (chunk < P.prio_cut[0]) __builtin_amdgcn_s_setprio(3);
+                        else if (chunk < P.prio_cut[1]) __builtin_amdgcn_s_setprio(2);
+                        else if (chunk < P.prio_cut[2]) __builtin_amdgcn_s_setprio(1);
+                        else __builtin_amdgcn_s_setprio(0);
+                    }
+                    if ((P.cost || P.lpt_write_counts) && n_idle == (uint32_t)kWave && given == 0u) {
+                        tile_slot = cur_tile; // cost is filed under the tile, not the chunk
                         tile_t0 = wall_clock64();
+                        s_wnode = c_wnode;
+                        s_wtri = c_wtri;
                     }
                 }
                 const uint32_t take = min(n_idle - given, chunk_left);
-                if (rank >= given && rank < given + take) item = chunk_next + (rank - given);
+                if (rank >= given && rank < given + take) {
+                    item = chunk_next + (rank - given);
+                    my_tile = cur_tile;
+                }
                 chunk_next += take;
                 chunk_left -= take;
                 given += take;
@@ -322,8 +390,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     out_index = item;
                     ok = true;
                 } else {
-                    const uint32_t chunk = item >> 6;
-                    const uint32_t tile = (P.order ? P.order[chunk] : chunk) * P.shard_count + P.shard_index;
+                    const uint32_t tile = my_tile * P.shard_count + P.shard_index;
                     const uint32_t k = item & 63u;
                     const uint32_t px = (tile % P.tiles_x) * 8u + (k & 7u);
                     const uint32_t py = (tile / P.tiles_x) * 8u + (k >> 3);
@@ -528,38 +595,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         const unsigned int ticket = atomicAdd(&P.ctr->waves_done, 1u);
         if (ticket == gridDim.x * (blockDim.x / kWave) - 1u) {
             for (int q = 0; q < 8; q++) atomicExch(&P.ctr->heads[q].taken, 0u);
+            // the lists this frame consumed become the next frame's (empty) write lists
+            if (P.lpt_read_counts)
+                for (uint32_t b = 0; b < 16u * kLptShards; b++) atomicExch(&P.lpt_read_counts[b], 0u);
             atomicExch(&P.ctr->waves_done, 0u);
         }
-    }
-}
-
-// Longest-processing-time-first tile order from the previous frame's measured tile costs.
-// Counting sort on a log-scale key (8 buckets per octave), heaviest first; sorted position p is
-// chunk p, which belongs to queue p % 8, so every XCD's queue starts with heavy tiles.
-// One workgroup; n ~ 32k.
-__device__ __forceinline__ uint32_t cost_bucket(uint32_t c) {
-    if (c == 0u) return 0u;
-    const uint32_t msb = 31u - (uint32_t)__clz((int)c);
-    const uint32_t frac = msb >= 3u ? (c >> (msb - 3u)) & 7u : (c << (3u - msb)) & 7u;
-    return min(255u, msb * 8u + frac);
-}
-
-__global__ void __launch_bounds__(1024) k_sort_tiles(const uint32_t *cost, uint32_t n, uint32_t *order) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t cursor[256];
-    const uint32_t tid = threadIdx.x;
-    if (tid < 256u) hist[tid] = 0u;
-    __syncthreads();
-    for (uint32_t t = tid; t < n; t += 1024u) atomicAdd(&hist[cost_bucket(cost[t])], 1u);
-    __syncthreads();
-    if (tid < 256u) {
-        uint32_t s = 0u;
-        for (uint32_t b = tid + 1u; b < 256u; b++) s += hist[b];
-        cursor[tid] = s; // first sorted position of this bucket (descending cost)
-    }
-    __syncthreads();
-    for (uint32_t t = tid; t < n; t += 1024u) {
-        order[atomicAdd(&cursor[cost_bucket(cost[t])], 1u)] = t;
     }
 }
 
@@ -618,11 +658,6 @@ int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count) {
     if (per_cu <= 0) per_cu = 8;
     if (per_cu > 32) per_cu = 32;
     return per_cu * prop.multiProcessorCount;
-}
-
-hipError_t launch_sort_tiles(const uint32_t *cost, uint32_t n_tiles, uint32_t *order, hipStream_t stream) {
-    hipLaunchKernelGGL(k_sort_tiles, dim3(1), dim3(1024), 0, stream, cost, n_tiles, order);
-    return hipGetLastError();
 }
 
 hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, int grid,
