@@ -259,6 +259,10 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     uint32_t refill = g_variant & 0x7fu;
     p.refill_idle = refill ? std::min(refill, 64u) : 64u;
     p.variant = g_variant;
+    {   // tuning: variant bits 25..28 = compaction threshold (0 = default, 15 = never)
+        const uint32_t c = (g_variant >> 25) & 0xfu;
+        p.tri_compact_min = c == 0u ? 2u : c == 15u ? 0xffffffffu : c;
+    }
     // tuning overrides (trx_set_kernel_variant): bits 8..15 waves per CU, bits 16..19 waves per workgroup
     uint32_t wpb = (g_variant >> 16) & 0xfu;
     if (wpb != 1 && wpb != 2 && wpb != 4) wpb = kDefaultWavesPerBlock;

@@ -20,6 +20,8 @@ constexpr uint32_t kLptShards = 8; // appenders per tile-cost bucket (16 buckets
 #endif
 constexpr int kLdsStack = TRX_LDS_STACK;        // traversal-stack entries per lane kept in LDS
 constexpr int kSpillStack = 64 - TRX_LDS_STACK; // further entries per lane in HBM (total 64 = oracle's ORC_STACK_SIZE)
+// LDS per wave: stack + ray table (2 x float4 per lane) + triangle-phase tables (group, result, prefix, heads)
+constexpr int kLdsBytesPerWave = TRX_LDS_STACK * kWave * 8 + kWave * 32 + kWave * 8 + kWave * 8 + kWave * 4 + kWave * 4;
 constexpr uint32_t kMaxSteps = 1u << 22; // per-ray iteration cap: every wave reaches an exit
 
 enum TraceMode : int { kModePrimary = 0, kModeAo = 1, kModeRays = 2 };
@@ -76,6 +78,7 @@ struct TraceParams {
     float ao_eps;
     uint32_t tie_first;
     uint32_t refill_idle; // refill the wave when at least this many lanes are idle (1..64)
+    uint32_t tri_compact_min; // spread the wave's triangle tests over all lanes when a lane owns this many
     uint32_t variant;
     uint32_t waves_per_block;        // 1, 2 or 4
     unsigned long long *wave_times;  // diagnostics: [2*wave] start, [2*wave+1] end (wall_clock64), or null

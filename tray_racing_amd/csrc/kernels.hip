@@ -220,6 +220,27 @@ __device__ __forceinline__ uint32_t read_xcc_id() {
     return x;
 }
 
+// Wave64 inclusive scans on the DPP network (row shifts, then row broadcasts): VALU only, no LDS.
+// Every lane of the wave must be active.
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -227,11 +248,17 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 template <int MODE, bool TLAS, int NODE, bool COUNT>
 __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceParams P) {
     // one stack region per wave of the workgroup; waves never synchronise with each other
-    extern __shared__ uint2 lds_dyn[];
+    extern __shared__ float4 lds_dyn[];
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave_in_block = threadIdx.x / kWave;
     const uint32_t wave_global = blockIdx.x * (blockDim.x / kWave) + wave_in_block;
-    uint2 *const lds_stack = lds_dyn + wave_in_block * (kLdsStack * kWave);
+    char *const lds_wave = reinterpret_cast<char *>(lds_dyn) + wave_in_block * kLdsBytesPerWave;
+    uint2 *const lds_stack = reinterpret_cast<uint2 *>(lds_wave);                          // [kLdsStack][64]
+    float4 *const lds_ray = reinterpret_cast<float4 *>(lds_wave + kLdsStack * kWave * 8);  // [64][2]: o,tmin | d
+    uint2 *const lds_grp = reinterpret_cast<uint2 *>(lds_ray + 2 * kWave);                 // [64] triangle group of the lane
+    uint2 *const lds_res = lds_grp + kWave;                                                // [64] {tt bits, triangle}
+    uint32_t *const lds_pref = reinterpret_cast<uint32_t *>(lds_res + kWave);              // [64] first pair of the lane
+    uint32_t *const lds_head = lds_pref + kWave;                                           // [64] run starts of a window
     uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave) + lane;
     const bool tie_first = P.tie_first != 0;
     if (P.wave_times && lane == 0) P.wave_times[2 * wave_global] = wall_clock64();
@@ -450,6 +477,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 }
                 if (ok) {
                     finish_ray_dir(r, dx, dy, dz);
+                    lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+                    lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
                     prim = TRX_INVALID;
                     sp = 0;
                     steps = 0;
@@ -469,10 +498,13 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         }
 
         // ---- traverse ------------------------------------------------------------
-        if (has_ray) {
-            const uint32_t keep = kWave - P.refill_idle; // leave when this few lanes remain
-            for (;;) {
-                uint2 tri;
+        // The loop is wave-uniform (every lane iterates, work is predicated on `act`), so that the
+        // triangle phase can use all 64 lanes whichever lanes own the triangles.
+        const uint32_t keep = kWave - P.refill_idle; // leave when this few lanes remain
+        for (;;) {
+            const bool act = has_ray;
+            uint2 tri = make_uint2(0u, 0u);
+            if (act) {
                 if (cur.y & 0xff000000u) {
                     const uint32_t hits_imask = cur.y;
                     const uint32_t child_bit = 31u - (uint32_t)__clz((int)hits_imask);
@@ -504,43 +536,105 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     tri = cur;
                     cur = make_uint2(0u, 0u);
                 }
-
-                while (tri.y != 0u) {
+                if (TLAS && tlas_sp == TRX_INVALID && tri.y != 0u) {
+                    // a TLAS primitive is an instance (query_tlas.hlsl:410-446): enter its BLAS
                     const uint32_t local = 31u - (uint32_t)__clz((int)tri.y);
                     tri.y &= ~(1u << local);
                     const uint32_t gidx = tri.x + local;
-                    if (TLAS && tlas_sp == TRX_INVALID) {
-                        // a TLAS primitive is an instance (query_tlas.hlsl:410-446)
-                        if (tri.y != 0u) {
-                            if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = tri;
-                            else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave] = tri;
-                            else overflow = true;
-                            sp++;
-                        }
-                        if (cur.y & 0xff000000u) {
-                            if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = cur;
-                            else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave] = cur;
-                            else overflow = true;
-                            sp++;
-                        }
-                        if (COUNT) c_maxsp = max(c_maxsp, sp);
-                        tlas_sp = sp;
-                        bvh_off = P.inst[gidx];
-                        cur = make_uint2(0u, 0x80000000u);
-                        break;
+                    if (tri.y != 0u) {
+                        if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = tri;
+                        else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave] = tri;
+                        else overflow = true;
+                        sp++;
                     }
-                    const float4 *tp = P.tris + (size_t)gidx * 3;
-                    float4 a = tp[0], b = tp[1], c4 = tp[2];
-                    // keep the three 16-byte loads together: left alone the compiler sinks the v0 load
-                    // behind the determinant, which serialises two memory latencies per triangle
-                    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c4.x), "+v"(c4.y), "+v"(c4.z));
-                    if (COUNT) {
-                        c_tri++;
-                        if (lane_rank(__ballot(1)) == 0) c_wtri++;
+                    if (cur.y & 0xff000000u) {
+                        if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = cur;
+                        else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave] = cur;
+                        else overflow = true;
+                        sp++;
                     }
-                    if (intersect_tri(r, a, b, c4, t, tie_first)) prim = gidx;
+                    if (COUNT) c_maxsp = max(c_maxsp, sp);
+                    tlas_sp = sp;
+                    bvh_off = P.inst[gidx];
+                    cur = make_uint2(0u, 0x80000000u);
+                    tri.y = 0u;
                 }
+            }
 
+            // ---- triangle phase ---------------------------------------------------------
+            // Each lane owns cnt triangle tests (the hit leaves of its node, highest bit first).
+            // Few per lane: every owner tests its own, one round per triangle.  Otherwise the
+            // wave's (ray, triangle) pairs are laid out densely over all 64 lanes: pair g goes to
+            // lane g % 64, tests read the owner's ray from LDS, and owners then commit their
+            // results in order, so a ray's triangle sequence (and its tie rule) is unchanged.
+            const uint32_t cnt = (uint32_t)__popc(tri.y);
+            if (__ballot(cnt != 0u) != 0ull) {
+                if (__ballot(cnt >= P.tri_compact_min) == 0ull) {
+                    while (tri.y != 0u) {
+                        const uint32_t local = 31u - (uint32_t)__clz((int)tri.y);
+                        tri.y &= ~(1u << local);
+                        const uint32_t gidx = tri.x + local;
+                        const float4 *tp = P.tris + (size_t)gidx * 3;
+                        float4 a = tp[0], b = tp[1], c4 = tp[2];
+                        // keep the three 16-byte loads together: left alone the compiler sinks the v0
+                        // load behind the determinant, serialising two memory latencies per triangle
+                        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c4.x), "+v"(c4.y), "+v"(c4.z));
+                        if (COUNT) {
+                            c_tri++;
+                            if (lane_rank(__ballot(1)) == 0) c_wtri++;
+                        }
+                        if (intersect_tri(r, a, b, c4, t, tie_first)) prim = gidx;
+                    }
+                } else {
+                    const uint32_t incl = wave_scan_add(cnt);
+                    const uint32_t excl = incl - cnt;
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    lds_grp[lane] = tri;
+                    lds_pref[lane] = excl;
+                    if (COUNT) c_tri += cnt;
+                    for (uint32_t base = 0; base < total; base += kWave) {
+                        // owner of every pair of this window: heads mark where each owner's run starts
+                        lds_head[lane] = 0u;
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t run_begin = max(excl, base), run_end = min(excl + cnt, base + kWave);
+                        if (run_begin < run_end) lds_head[run_begin - base] = lane + 1u;
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t owner1 = wave_scan_max(lds_head[lane]);
+                        const uint32_t g = base + lane;
+                        uint2 res = make_uint2(0x7fc00000u, 0u); // NaN: never commits
+                        if (g < total) {
+                            const uint32_t ol = owner1 - 1u;
+                            const uint2 grp = lds_grp[ol];
+                            uint32_t m = grp.y;
+                            for (uint32_t j = g - lds_pref[ol]; j > 0u; j--) m &= ~(1u << (31u - (uint32_t)__clz((int)m)));
+                            const uint32_t gidx = grp.x + (31u - (uint32_t)__clz((int)m));
+                            const float4 *tp = P.tris + (size_t)gidx * 3;
+                            float4 a = tp[0], b = tp[1], c4 = tp[2];
+                            const float4 ro = lds_ray[2u * ol], rd = lds_ray[2u * ol + 1u];
+                            asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c4.x), "+v"(c4.y), "+v"(c4.z));
+                            Ray orr;
+                            orr.ox = ro.x; orr.oy = ro.y; orr.oz = ro.z; orr.tmin = ro.w;
+                            orr.dx = rd.x; orr.dy = rd.y; orr.dz = rd.z;
+                            float tt = TRX_F32_MAX; // the range / tie test against the owner's t happens at commit
+                            if (intersect_tri(orr, a, b, c4, tt, false)) res = make_uint2(__float_as_uint(tt), gidx);
+                        }
+                        lds_res[lane] = res;
+                        __builtin_amdgcn_wave_barrier();
+                        for (uint32_t q = run_begin; q < run_end; q++) {
+                            const uint2 rr = lds_res[q - base];
+                            const float tt = __uint_as_float(rr.x);
+                            if (tie_first ? (tt < t) : (tt <= t)) {
+                                t = tt;
+                                prim = rr.y;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        if (COUNT && lane == 0) c_wtri++;
+                    }
+                }
+            }
+
+            if (act) {
                 bool done = false;
                 if ((cur.y & 0xff000000u) == 0u) {
                     if (sp == 0u) {
@@ -571,10 +665,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     }
                     c_over += overflow ? 1u : 0u;
                     has_ray = false;
-                    break;
                 }
-                if (!exhausted && (uint32_t)__popcll(__ballot(1)) <= keep) break;
             }
+            const uint32_t alive = (uint32_t)__popcll(__ballot(has_ray));
+            if (alive == 0u || (!exhausted && alive <= keep)) break;
         }
     }
 
@@ -607,7 +701,7 @@ template <int MODE, bool TLAS, int NODE, bool COUNT>
 hipError_t launch_one(const TraceParams &p, int grid, hipStream_t stream) {
     // grid = total waves; p.waves_per_block waves share a workgroup (and nothing else)
     const int wpb = (int)p.waves_per_block;
-    const size_t lds = (size_t)wpb * kLdsStack * kWave * sizeof(uint2);
+    const size_t lds = (size_t)wpb * kLdsBytesPerWave;
     hipLaunchKernelGGL((k_trace<MODE, TLAS, NODE, COUNT>), dim3(grid / wpb), dim3(kWave * wpb), lds, stream, p);
     return hipGetLastError();
 }
@@ -636,7 +730,7 @@ template <int MODE, bool TLAS, int NODE, bool COUNT>
 int occupancy_one() {
     int blocks = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace<MODE, TLAS, NODE, COUNT>, kWave,
-                                                     kLdsStack * kWave * sizeof(uint2)) != hipSuccess)
+                                                     kLdsBytesPerWave) != hipSuccess)
         return 0;
     return blocks;
 }
