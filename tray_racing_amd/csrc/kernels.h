@@ -21,7 +21,8 @@ constexpr uint32_t kLptShards = 8; // appenders per tile-cost bucket (16 buckets
 constexpr int kLdsStack = TRX_LDS_STACK;        // traversal-stack entries per lane kept in LDS
 constexpr int kSpillStack = 64 - TRX_LDS_STACK; // further entries per lane in HBM (total 64 = oracle's ORC_STACK_SIZE)
 // LDS per wave: stack + ray table (2 x float4 per lane) + triangle-phase tables (group, result, prefix, heads)
-constexpr int kLdsBytesPerWave = TRX_LDS_STACK * kWave * 8 + kWave * 32 + kWave * 8 + kWave * 8 + kWave * 4 + kWave * 4;
+constexpr int kLptPend = 32; // tile-list appends a wave parks in LDS before issuing them together
+constexpr int kLdsBytesPerWave = TRX_LDS_STACK * kWave * 8 + kWave * 32 + kWave * 8 + kWave * 8 + kWave * 4 + kWave * 4 + kLptPend * 8;
 constexpr uint32_t kMaxSteps = 1u << 22; // per-ray iteration cap: every wave reaches an exit
 
 enum TraceMode : int { kModePrimary = 0, kModeAo = 1, kModeRays = 2 };

@@ -245,6 +245,17 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Appends the parked {tile, list} entries to the next frame's tile lists, one lane per entry.
+__device__ __forceinline__ void flush_pending(const TraceParams &P, const uint2 *lds_pend, uint32_t n, uint32_t lane) {
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n) {
+        const uint2 e = lds_pend[lane];
+        const uint32_t pos = atomicAdd(&P.lpt_write_counts[e.y], 1u);
+        if (pos < P.lpt_cap) P.lpt_write_lists[(size_t)e.y * P.lpt_cap + pos] = e.x;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int MODE, bool TLAS, int NODE, bool COUNT>
 __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceParams P) {
     // one stack region per wave of the workgroup; waves never synchronise with each other
@@ -259,6 +270,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint2 *const lds_res = lds_grp + kWave;                                                // [64] {tt bits, triangle}
     uint32_t *const lds_pref = reinterpret_cast<uint32_t *>(lds_res + kWave);              // [64] first pair of the lane
     uint32_t *const lds_head = lds_pref + kWave;                                           // [64] run starts of a window
+    uint2 *const lds_pend = reinterpret_cast<uint2 *>(lds_head + kWave);                   // [kLptPend] {tile, list} to append
     uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave) + lane;
     const bool tie_first = P.tie_first != 0;
     if (P.wave_times && lane == 0) P.wave_times[2 * wave_global] = wall_clock64();
@@ -295,6 +307,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint32_t pending = 0; // prefetched ticket of queue my_q (lane 0)
     if (lane == 0) pending = atomicAdd(&P.ctr->heads[my_q].taken, 1u);
     uint32_t chunk_next = 0, chunk_left = 0; // items of the current chunk not yet handed to a lane
+    uint32_t n_pend = 0;                     // tile-list entries parked in lds_pend (uniform)
     uint32_t tile_slot = TRX_INVALID;        // tile being timed (cost feedback)
     unsigned long long tile_t0 = 0;
     uint32_t cur_tile = 0, my_tile = 0;      // tile of the current chunk (uniform) / of this lane's item
@@ -333,8 +346,16 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     const uint32_t kk = 2u * msb + (msb ? (c >> (msb - 1u)) & 1u : 0u);
                     const uint32_t b = kk < 16u ? 0u : min(kk - 16u, 15u);
                     const uint32_t list = b * kLptShards + ((wave_global ^ tile_slot) & (kLptShards - 1u));
-                    const uint32_t pos = atomicAdd(&P.lpt_write_counts[list], 1u);
-                    if (pos < P.lpt_cap) P.lpt_write_lists[(size_t)list * P.lpt_cap + pos] = tile_slot;
+                    // park the entry in LDS: the appends (returning atomics) are issued together,
+                    // one lane each, when the buffer fills or the wave exits, off every tile's path
+                    lds_pend[n_pend] = make_uint2(tile_slot, list);
+                }
+            }
+            if (P.lpt_write_counts) {
+                n_pend++;
+                if (n_pend == (uint32_t)kLptPend) {
+                    flush_pending(P, lds_pend, n_pend, lane);
+                    n_pend = 0;
                 }
             }
             if (COUNT && P.tile_iters) {
@@ -673,6 +694,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     }
 
     // ---- epilogue: flags, counters, queue reset ---------------------------------------
+    if (P.lpt_write_counts && n_pend) flush_pending(P, lds_pend, n_pend, lane);
     if (c_over) atomicAdd(&P.ctr->overflow, c_over);
     if (COUNT) {
         atomicAdd(&P.ctr->n_rays, (unsigned long long)c_rays);
