@@ -417,3 +417,40 @@ def test_bench_two_ranks_share_the_gpu(trx):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["parity_vs_oracle_full_frame"] is True and d["value"] > 0
     assert d["scaling"] == "strong" and d["config"]["frames_in_flight"] == 2
+
+
+def test_scheduling_variants_and_streams_do_not_change_results(trx, orc):
+    """Work-queue layout, tile-order feedback, issue priorities, the cooperative triangle phase and
+    frames in flight on several streams only change WHEN work is done: every combination must
+    reproduce the oracle's frame bit for bit, frame after frame (the order feedback kicks in from
+    the second frame of a launch slot)."""
+    import torch
+    from tray_racing_amd import dist as D
+    w, h = 320, 184
+    flat, view, osc, ov = make_scene(trx, orc, "bistro", 120000, w, h)
+    want, _ = osc.trace_primary(ov, w, h, sem=3)
+    want_ao, _ = osc.trace_ao(ov, w, h, want, sem=3, frame=4, ao_eps=0.01)
+    sc = trx.Scene(flat)
+    lib = trx.load()
+    NO_LPT, ONE_Q = 1 << 20, 1 << 21
+    never_compact, compact3 = 15 << 25, 3 << 25
+    try:
+        for variant in (0, NO_LPT, ONE_Q, NO_LPT | ONE_Q, never_compact, compact3, (1 << 22), 4 << 16, 12 << 8):
+            lib.trx_set_kernel_variant(variant)
+            for rep in range(6):  # > kSlots launches: every slot gets to read its own feedback
+                got, ao, _ = sc.trace_primary_ao(view, w, h, sem=3, frame=4, ao_eps=0.01)
+                assert_hits_equal(got, want, "variant 0x%x rep %d" % (variant, rep))
+                assert_hits_equal(ao, want_ao, "variant 0x%x rep %d ao" % (variant, rep))
+        lib.trx_set_kernel_variant(0)
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        outs = [torch.zeros(w * h, dtype=torch.int64, device="cuda") for _ in range(3)]
+        for k in range(30):
+            s = streams[k % 3]
+            sc.trace_primary_dev(view, w, h, outs[k % 3].data_ptr(), sem=3, stream=s.cuda_stream)
+        for s in streams:
+            sc.check(s.cuda_stream)
+        for o in outs:
+            assert_hits_equal(D.int64_to_hits(o), want, "3 frames in flight")
+    finally:
+        lib.trx_set_kernel_variant(0)
+        sc.close()
