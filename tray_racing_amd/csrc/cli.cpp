@@ -1,0 +1,279 @@
+// cli.cpp — `tray_racing_hip`: the reference's command line (src/main.rs:65-171) over the C ABI.
+//
+// Same flag names and the same 4-column result table (src/main.rs:634-640, printed once after
+// `--passes` passes, averaged: :188-207).  What differs is the backend: every frame is the primary +
+// AO frame of src/rt_gpu/rt_gpu_software.hlsl:47-144 traced by libtrx.so on an MI355X; the BVH is
+// built on the CPU by this repo's stand-in builder (the reference builds with OBVHS).  Links against
+// include/trx.h only.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/trx.h"
+
+namespace {
+
+struct Options { // src/main.rs:65-171 (flags this backend cannot honour are rejected loudly)
+    std::string input;
+    bool benchmark = false;
+    float render_time = 1.0f;
+    std::string build = "ploc_cwbvh";
+    unsigned max_prims_per_leaf = 3;
+    bool cpu = false, hardware = false, verbose = false, animate = false, png = false, tlas = false, flatten_blas = false;
+    unsigned width = 1920, height = 1080;
+    float collapse_traversal_cost = 1.0f;
+    unsigned passes = 3;
+    std::string preset;
+    int device = 0;
+    unsigned semantics = TRX_SEM_HLSL; // the GPU path of the reference is the HLSL text
+};
+
+struct Camera {
+    float eye[3] = {0, 0, 0}, look_at[3] = {0, 0, -1}, fov = 90.0f;
+};
+
+struct Stats {
+    std::string name;
+    double traversal_ms = 0, blas_build_time_s = 0, tlas_build_time_ms = 0;
+};
+
+[[noreturn]] void die(const std::string &msg) {
+    std::fprintf(stderr, "%s\n", msg.c_str());
+    std::exit(1);
+}
+
+void check(int rc, const char *what) {
+    if (rc != TRX_OK) die(std::string(what) + ": " + trx_last_error());
+}
+
+std::string dirname_of(const std::string &p) {
+    size_t k = p.find_last_of('/');
+    if (k == std::string::npos) return "";
+    return p.substr(0, k);
+}
+
+// The subset of RON the reference's scene files use (assets/scenes/*.ron): model_path, camera(eye,
+// look_at, fov, exposure), sun_direction; `//` comments.
+bool parse_ron(const std::string &path, std::string &model_path, Camera &cam) {
+    std::ifstream f(path);
+    if (!f) return false;
+    std::stringstream ss;
+    std::string line;
+    while (std::getline(f, line)) {
+        size_t c = line.find("//");
+        if (c != std::string::npos) line.erase(c);
+        ss << line << '\n';
+    }
+    const std::string s = ss.str();
+    auto tuple3 = [&](const char *key, float out[3]) {
+        size_t k = s.find(key);
+        if (k == std::string::npos) return false;
+        k = s.find('(', k);
+        if (k == std::string::npos) return false;
+        return std::sscanf(s.c_str() + k, "( %f , %f , %f", &out[0], &out[1], &out[2]) == 3;
+    };
+    size_t k = s.find("model_path");
+    if (k == std::string::npos) return false;
+    size_t q0 = s.find('"', k), q1 = q0 == std::string::npos ? q0 : s.find('"', q0 + 1);
+    if (q1 == std::string::npos) return false;
+    model_path = s.substr(q0 + 1, q1 - q0 - 1);
+    if (!tuple3("eye", cam.eye) || !tuple3("look_at", cam.look_at)) return false;
+    k = s.find("fov");
+    if (k == std::string::npos || std::sscanf(s.c_str() + s.find(':', k) + 1, " %f", &cam.fov) != 1) return false;
+    return true;
+}
+
+void usage() {
+    std::puts("tray_racing_hip -i <scene.ron|demoscene|standin:<name>>[,...] [--benchmark] [--render-time s]\n"
+              "  [--build ploc_cwbvh] [--max-prims-per-leaf 1..3] [--collapse-traversal-cost c] [--preset p]\n"
+              "  [--width w] [--height h] [--animate] [--tlas] [--flatten-blas] [--passes n] [--verbose] [--device d]\n"
+              "stand-in names: cornell demoscene kitchen bistro hairball san_miguel (seeded procedural scenes)");
+}
+
+Options parse_args(int argc, char **argv) {
+    Options o;
+    auto need = [&](int &i) -> const char * {
+        if (i + 1 >= argc) die(std::string("missing value for ") + argv[i]);
+        return argv[++i];
+    };
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        if (a == "-i") o.input = need(i);
+        else if (a == "--benchmark") o.benchmark = true;
+        else if (a == "--render-time") o.render_time = (float)std::atof(need(i));
+        else if (a == "--build") o.build = need(i);
+        else if (a == "--max-prims-per-leaf") o.max_prims_per_leaf = (unsigned)std::atoi(need(i));
+        else if (a == "--collapse-traversal-cost") o.collapse_traversal_cost = (float)std::atof(need(i));
+        else if (a == "--preset") o.preset = need(i);
+        else if (a == "--width") o.width = (unsigned)std::atoi(need(i));
+        else if (a == "--height") o.height = (unsigned)std::atoi(need(i));
+        else if (a == "--passes") o.passes = (unsigned)std::atoi(need(i));
+        else if (a == "--device") o.device = std::atoi(need(i));
+        else if (a == "--cpu") o.cpu = true;
+        else if (a == "--hardware") o.hardware = true;
+        else if (a == "--verbose") o.verbose = true;
+        else if (a == "--animate") o.animate = true;
+        else if (a == "--png") o.png = true;
+        else if (a == "--tlas") o.tlas = true;
+        else if (a == "--flatten-blas") o.flatten_blas = true;
+        else if (a == "--cpu-semantics") o.semantics = TRX_SEM_CPU;
+        else if (a == "-h" || a == "--help") {
+            usage();
+            std::exit(0);
+        } else if (a == "--search-distance" || a == "--search-depth-threshold" || a == "--sort-precision" ||
+                   a == "-r" || a == "--post-collapse-reinsertion-batch-ratio-multiplier") {
+            need(i); // PLOC parameters of the OBVHS builder: accepted, not used by the stand-in builder
+        } else if (a == "--split" || a == "--auto-tune" || a == "--disable-auto-tune-model-cache") {
+            // accepted for command-line compatibility; no effect here
+        } else {
+            die("unknown argument: " + a);
+        }
+    }
+    if (o.input.empty()) {
+        usage();
+        die("error: -i <input> is required");
+    }
+    if (o.build.find("cwbvh") != std::string::npos && o.max_prims_per_leaf > 3)
+        die("CWBVH only supports a maximum of 3 primitives per leaf."); // src/main.rs:176-178
+    if (o.build != "ploc_cwbvh") die("NO BVH BUILDER SPECIFIED (this backend serves --build ploc_cwbvh)"); // src/cwbvh.rs:99
+    if (o.cpu) die("--cpu is the reference's own rt_cpu path; the HIP backend has no CPU traversal");
+    if (o.hardware) die("--hardware needs ray-tracing hardware; MI355X (CDNA4) has none");
+    if (o.png) die("--png is CPU-only in the reference (src/rt_cpu/rt_cpu.rs:102-112) and not offered here");
+    if (o.passes == 0) o.passes = 1;
+    return o;
+}
+
+// one input of one pass: src/main.rs:241-478 (load, build, trace) -> Stats
+Stats render_input(const Options &o, const std::string &input) {
+    Stats st;
+    float *verts = nullptr;
+    uint64_t n_tris = 0, *counts = nullptr;
+    uint32_t n_objects = 0;
+    Camera cam;
+    if (input == "demoscene" || input.rfind("standin:", 0) == 0) {
+        const std::string name = input == "demoscene" ? "demoscene" : input.substr(8);
+        st.name = name;
+        check(trx_gen_scene(name.c_str(), 0, 1, &verts, &n_tris, &counts, &n_objects), "scene");
+        check(trx_scene_camera(name.c_str(), cam.eye, cam.look_at, &cam.fov), "camera");
+    } else {
+        std::string model;
+        if (!parse_ron(input, model, cam)) die("Failed to load config: " + input); // src/main.rs:262-267
+        if (!input.empty() && input[0] != '/' && !model.empty() && model[0] != '/') {
+            // "If we got a relative path to both the scene and the model, assume the path to the model is
+            // relative to the path to the scene" (three levels up, src/main.rs:271-284)
+            std::string base = dirname_of(dirname_of(dirname_of(input)));
+            if (!base.empty()) model = base + "/" + model;
+        }
+        size_t k = input.find_last_of('/');
+        st.name = input.substr(k == std::string::npos ? 0 : k + 1);
+        k = st.name.find_last_of('.');
+        if (k != std::string::npos) st.name.erase(k);
+        check(trx_load_model(model.c_str(), &verts, &n_tris, &counts, &n_objects), "model");
+    }
+    const bool tlas = o.tlas && !o.flatten_blas; // src/main.rs:300-308
+    if (o.verbose) std::printf("%u objects \"%s\"\ntriangles %llu\n", n_objects, st.name.c_str(), (unsigned long long)n_tris);
+    check(trx_set_build_costs(o.collapse_traversal_cost, 0.3f), "build costs");
+    trx_flat *flat = nullptr;
+    check(trx_flat_build(verts, counts, n_objects, tlas ? 1 : 0, o.max_prims_per_leaf, 0, &flat), "build");
+    st.blas_build_time_s = flat->blas_build_s;
+    st.tlas_build_time_ms = flat->tlas_build_s * 1000.0;
+    if (o.verbose) std::printf("nodes %llu tlas_start %u instances %u\n", (unsigned long long)flat->n_nodes, flat->tlas_start, flat->n_instances);
+
+    trx_scene *scene = nullptr;
+    check(trx_scene_create(flat->bvh_bytes, flat->n_nodes, flat->tri_verts, flat->n_tris, TRX_TRI_VERTS_36,
+                           flat->n_instances ? flat->instance_offsets : nullptr, flat->n_instances, flat->tlas_start,
+                           o.device, &scene), "scene upload");
+    trx_view view;
+    check(trx_view_from_camera(cam.eye, cam.look_at, cam.fov, (float)o.width, (float)o.height, &view), "camera");
+
+    // frames until render_time is used up; --benchmark adds the untimed warm-up dispatch and the result
+    // is the MINIMUM frame time (src/rt_gpu/rt_gpu_software.rs:289-302,339,376)
+    double total_ms = 0, min_ms = 1e30;
+    unsigned frames = 0, frame_count = 0;
+    if (o.benchmark) {
+        float ms = 0;
+        check(trx_trace_primary_ao(scene, &view, o.width, o.height, o.semantics, 0, 0.0001f, nullptr, nullptr, &ms), "warm-up");
+    }
+    do {
+        float ms = 0;
+        check(trx_trace_primary_ao(scene, &view, o.width, o.height, o.semantics, frame_count, 0.0001f, nullptr, nullptr, &ms),
+              "trace");
+        total_ms += ms;
+        min_ms = std::min(min_ms, (double)ms);
+        frames++;
+        if (o.animate) frame_count = frames;
+    } while (total_ms < o.render_time * 1000.0 && frames < 100000);
+    st.traversal_ms = o.benchmark ? min_ms : total_ms / frames;
+    if (o.verbose) std::printf("%.2fms   avg render time over %u frames (min %.3fms)\n", total_ms / frames, frames, min_ms);
+
+    trx_scene_destroy(scene);
+    trx_flat_destroy(flat);
+    trx_free(verts);
+    trx_free(counts);
+    return st;
+}
+
+void print_table(const std::vector<Stats> &rows) { // tabled Style::blank(), src/main.rs:207,634-640
+    const char *hdr[4] = {"name", "traversal_ms", "blas_build_time_s", "tlas_build_time_ms"};
+    std::vector<std::vector<std::string>> cells;
+    for (const Stats &s : rows) {
+        char a[64], b[64], c[64];
+        std::snprintf(a, sizeof(a), "%g", s.traversal_ms);
+        std::snprintf(b, sizeof(b), "%g", s.blas_build_time_s);
+        std::snprintf(c, sizeof(c), "%g", s.tlas_build_time_ms);
+        cells.push_back({s.name, a, b, c});
+    }
+    size_t wdt[4];
+    for (int k = 0; k < 4; k++) {
+        wdt[k] = std::strlen(hdr[k]);
+        for (auto &r : cells) wdt[k] = std::max(wdt[k], r[k].size());
+    }
+    for (int k = 0; k < 4; k++) std::printf(" %-*s ", (int)wdt[k], hdr[k]);
+    std::printf("\n");
+    for (auto &r : cells) {
+        for (int k = 0; k < 4; k++) std::printf(" %-*s ", (int)wdt[k], r[k].c_str());
+        std::printf("\n");
+    }
+}
+
+} // namespace
+
+int main(int argc, char **argv) {
+    Options o = parse_args(argc, argv);
+    if (trx_device_count() <= o.device) die("no HIP device " + std::to_string(o.device) + " (libtrx.so has no CPU fallback)");
+    std::vector<std::string> inputs;
+    {
+        std::stringstream ss(o.input);
+        std::string item;
+        while (std::getline(ss, item, ',')) if (!item.empty()) inputs.push_back(item);
+    }
+    std::vector<Stats> avg;
+    for (unsigned pass = 0; pass < o.passes; pass++) {
+        std::vector<Stats> stats;
+        for (const std::string &in : inputs) stats.push_back(render_input(o, in));
+        Stats a; // the "Avg" row, src/main.rs:479-488
+        a.name = "Avg";
+        for (const Stats &s : stats) {
+            a.traversal_ms += s.traversal_ms / stats.size();
+            a.blas_build_time_s += s.blas_build_time_s / stats.size();
+            a.tlas_build_time_ms += s.tlas_build_time_ms / stats.size();
+        }
+        stats.push_back(a);
+        if (avg.empty()) {
+            avg = stats;
+            for (Stats &s : avg) s.traversal_ms = s.blas_build_time_s = s.tlas_build_time_ms = 0;
+        }
+        for (size_t i = 0; i < stats.size(); i++) { // averaged over passes, src/main.rs:191-206
+            avg[i].traversal_ms += stats[i].traversal_ms / o.passes;
+            avg[i].blas_build_time_s += stats[i].blas_build_time_s / o.passes;
+            avg[i].tlas_build_time_ms += stats[i].tlas_build_time_ms / o.passes;
+        }
+    }
+    print_table(avg);
+    return 0;
+}
