@@ -27,7 +27,7 @@ import sys
 import time
 
 # concurrent kernels from several HIP streams need as many hardware queues (read at HIP init)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -60,7 +60,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sem", type=int, default=3, help="trx_semantics bits (3 = TRX_SEM_CPU)")
-    ap.add_argument("--streams", type=int, default=4, help="frames in flight (1 = strictly one frame at a time)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="frames in flight; 0 = 4 for 1-2 GPUs, 8 beyond (a rank's shard shrinks with N, its "
+                         "slowest tile does not); 1 = strictly one frame at a time")
     ap.add_argument("--roofline-launches", type=int, default=40, help="un-overlapped launches timed for `roofline`")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,7 +113,7 @@ def main():
     view = T.view_from_camera(eye, look, fov, w, h)
     scene = T.Scene(flat, device=local_rank)
 
-    n_streams = max(1, args.streams)
+    n_streams = args.streams if args.streams > 0 else (4 if max(world, args.sim_shards) <= 2 else 8)
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
     shard_img = (rank, world, 0)
     shard_cmp = (rank, world, 1)

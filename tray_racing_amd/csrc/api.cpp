@@ -50,7 +50,7 @@ int fail(int code, const char *fmt, ...) {
                         "%s failed: %s", #expr, hipGetErrorString(e_));                    \
     } while (0)
 
-constexpr int kSlots = 4;
+constexpr int kSlots = 8;
 constexpr uint32_t kDefaultWavesPerBlock = 1;
 
 struct Slot {
