@@ -240,6 +240,9 @@ int trx_trace_rays_dev(trx_scene *scene, const trx_ray *d_rays, uint64_t n_rays,
 int trx_count_primary(trx_scene *scene, const trx_view *view, uint32_t width,
                       uint32_t height, trx_shard shard, uint32_t semantics,
                       trx_hit *d_hits, trx_stats *stats);
+int trx_count_ao(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                 trx_shard shard, uint32_t semantics, uint32_t frame, float ao_eps,
+                 const trx_hit *d_primary, trx_hit *d_ao, trx_stats *stats);
 int trx_count_rays(trx_scene *scene, const trx_ray *d_rays, uint64_t n_rays,
                    uint32_t semantics, trx_hit *d_hits, trx_stats *stats);
 

@@ -1,11 +1,13 @@
 // kernels.hip — gfx950 (MI355X, wave64) CWBVH closest-hit kernels.
 //
-// One persistent wave = 64 ray slots.  A wave pulls work items (pixels of an
-// 8x8 tile, or explicit rays) from a global queue with one atomic per refill
-// (ballot + mbcnt give every idle lane its item), traverses with a per-lane
-// stack striped through LDS (entry i of lane l at [i*64 + l]: conflict-free
-// ds_write_b64/ds_read_b64) that spills to HBM past kLdsStack entries, and
-// refills idle lanes when enough of them have finished.
+// One persistent wave = 64 ray slots.  Waves pull 64-item chunks (an 8x8 pixel
+// tile, or 64 explicit rays) from one work queue per XCD, heaviest tiles first
+// (order learnt from the previous frame's measured tile times), traverse with a
+// per-lane stack striped through LDS (entry i of lane l at [i*64 + l]:
+// conflict-free ds_write_b64/ds_read_b64) that spills to HBM past kLdsStack
+// entries, and run the triangle tests of a node step cooperatively: the wave's
+// (ray, triangle) pairs are spread over all 64 lanes and committed by their
+// owners in order.  DESIGN.md section 4 has the measurements behind each choice.
 //
 // What each function restates (paths relative to the tray_racing checkout):
 //   node_intersect   src/rt_gpu/rt_gpu_software_query.hlsl:213-303
