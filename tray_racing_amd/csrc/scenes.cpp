@@ -485,11 +485,12 @@ void gen_hairball(Mesh &m, uint64_t target, uint64_t seed) {
     uint64_t strands = std::max<uint64_t>(1, target / (2 * seg));
     for (uint64_t s = 0; s < strands + 1 && m.tris() < target; s++) {
         V3 d = normalize(V3{rng.gauss(), rng.gauss(), rng.gauss()});
-        V3 p = d * 0.4f;
+        V3 p = d * 0.8f;
         V3 side = normalize(cross(d, V3{rng.gauss(), rng.gauss(), rng.gauss()}));
-        float step = 4.1f / seg * rng.range(0.8f, 1.2f), wdt = 0.004f;
+        float step = 6.0f / seg * rng.range(0.8f, 1.2f), wdt = 0.012f;
         for (int k = 0; k < seg && m.tris() < target; k++) {
-            V3 nd = normalize(d + V3{rng.gauss(), rng.gauss(), rng.gauss()} * 0.22f);
+            // curly but outward-bound, so the ball reaches its 4.5 radius like the real hairball
+            V3 nd = normalize(d + V3{rng.gauss(), rng.gauss(), rng.gauss()} * 0.2f + normalize(p) * 0.06f);
             V3 q = p + nd * step;
             if (dot(q, q) > 4.5f * 4.5f) {
                 nd = normalize(nd - normalize(q) * 1.2f);
