@@ -202,11 +202,12 @@ def main():
     out = None
     if rank == 0:
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, valu_insts = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        if os.path.exists(tpath) and world == 1 and args.scene == "bistro" and (w, h) == (1920, 1080):
+            try:  # PMC counters cannot be read live; these come from the committed rocprofv3 --pmc passes
+                tj = json.load(open(tpath))
+                traffic, valu_insts = tj.get("hbm_bytes_per_launch"), tj.get("valu_wave_insts_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None
         out = {
@@ -245,6 +246,7 @@ def main():
                 "bytes_per_launch": int(launch_bytes),
                 "nodes_per_ray": round(st.n_node / max(st.n_rays, 1), 3),
                 "tris_per_ray": round(st.n_tri / max(st.n_rays, 1), 3),
+                "valu_issue_frac": (round(valu_insts * 2.0 / (1024 * 2.4e9 * kernel_ms * 1e-3), 3) if valu_insts else None),
                 "note": "algorithmic (requested) bytes; coherent rays are served by L1/L2/Infinity Cache, "
                         "see `traffic` (measured HBM bytes per launch) and DESIGN.md section 4",
             },

@@ -250,6 +250,10 @@ int trx_count_rays(trx_scene *scene, const trx_ray *d_rays, uint64_t n_rays,
  * in-kernel and latched in device memory).  Synchronises `stream`. */
 int trx_scene_check(trx_scene *scene, void *stream);
 
+/* Re-entrancy: the *_dev entry points and trx_traverse1 may be called concurrently on one scene
+ * (launch slots); the synchronous entry points below, trx_count_* and trx_bench_primary share
+ * per-scene scratch buffers and are serialised by a per-scene lock. */
+
 /* ---- tracing: host-buffer convenience (synchronous) --------------------------
  * What rt_gpu_software::start returns to its caller is a time in ms
  * (src/rt_gpu/rt_gpu_software.rs:376); out_ms is the hipEvent time of the

@@ -82,7 +82,8 @@ struct trx_scene {
     uint32_t *dbg_cost = nullptr, *dbg_iters = nullptr; // diagnostics only (trx_debug_tile_profile)
     Slot slots[kSlots];
     int next_slot = 0;
-    std::mutex mu;
+    std::mutex mu;      // launch slots (every enqueue)
+    std::recursive_mutex host_mu; // scratch buffers and event pair of the synchronous entry points
     // scratch for the host-buffer convenience entry points
     trx_hit *d_scratch_a = nullptr, *d_scratch_b = nullptr;
     trx_ray *d_scratch_rays = nullptr;
@@ -648,6 +649,7 @@ static int finish_count(trx_scene *s, SlotCounters *ctr, trx_stats *stats) {
 int trx_count_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,
                       trx_hit *d_hits, trx_stats *stats) {
     if (!s) return fail(TRX_ERR_INVALID, "null scene");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     HIP_TRY(hipSetDevice(s->device));
     TraceParams p;
     std::memset(&p, 0, sizeof(p));
@@ -670,6 +672,7 @@ int trx_count_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h
 int trx_count_ao(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,
                  uint32_t frame, float ao_eps, const trx_hit *d_primary, trx_hit *d_ao, trx_stats *stats) {
     if (!s || !d_primary || !d_ao) return fail(TRX_ERR_INVALID, "null argument");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     HIP_TRY(hipSetDevice(s->device));
     TraceParams p;
     std::memset(&p, 0, sizeof(p));
@@ -689,6 +692,7 @@ int trx_count_ao(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx
 
 int trx_count_rays(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, trx_hit *d_hits, trx_stats *stats) {
     if (!s || !d_rays || n == 0 || n > (1ull << 30)) return fail(TRX_ERR_INVALID, "bad ray batch");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     HIP_TRY(hipSetDevice(s->device));
     if (!d_hits) {
         int rc = ensure_scratch(s, n, 0);
@@ -720,6 +724,7 @@ int trx_scene_check(trx_scene *s, void *stream) {
 int trx_trace_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, trx_hit *out_hits,
                       float *out_ms) {
     if (!s) return fail(TRX_ERR_INVALID, "null scene");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure_scratch(s, (uint64_t)w * h, 0);
     if (rc) return rc;
@@ -736,6 +741,7 @@ int trx_trace_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h
 int trx_trace_primary_ao(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint32_t frame,
                          float ao_eps, trx_hit *out_primary, trx_hit *out_ao, float *out_ms) {
     if (!s) return fail(TRX_ERR_INVALID, "null scene");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure_scratch(s, (uint64_t)w * h, 0);
     if (rc) return rc;
@@ -755,6 +761,7 @@ int trx_trace_primary_ao(trx_scene *s, const trx_view *view, uint32_t w, uint32_
 
 int trx_trace_rays(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t sem, trx_hit *out_hits, float *out_ms) {
     if (!s || (n && !rays)) return fail(TRX_ERR_INVALID, "null argument");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     if (n == 0) return TRX_OK;
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure_scratch(s, n, n);
@@ -815,6 +822,7 @@ int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *ou
 int trx_bench_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint32_t warmup,
                       uint32_t frames, float *out_min_ms, float *out_mean_ms) {
     if (!s || frames == 0) return fail(TRX_ERR_INVALID, "bad argument");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure_scratch(s, (uint64_t)w * h, 0);
     if (rc) return rc;
@@ -845,6 +853,7 @@ int trx_bench_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h
 int trx_debug_tile_profile(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem,
                            uint32_t *out_cost, uint32_t *out_iters, uint32_t n_tiles) {
     if (!s || !out_cost || !out_iters) return fail(TRX_ERR_INVALID, "null argument");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     if (n_tiles != ((w + 7) / 8) * ((h + 7) / 8)) return fail(TRX_ERR_INVALID, "n_tiles does not match the image");
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure_scratch(s, (uint64_t)w * h, 0);
@@ -877,6 +886,7 @@ int trx_debug_tile_profile(trx_scene *s, const trx_view *view, uint32_t w, uint3
 int trx_debug_wave_timeline(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem,
                             uint64_t *out_times, uint32_t max_waves, uint32_t *out_waves) {
     if (!s || !out_times || !out_waves) return fail(TRX_ERR_INVALID, "null argument");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure_scratch(s, (uint64_t)w * h, 0);
     if (rc) return rc;
