@@ -1,4 +1,4 @@
-"""Residency / tail diagnostics: per-wave lifetimes of one frame and a grid-shape sweep."""
+"""Residency / tail diagnostics: per-wave lifetimes of one frame (development aid)."""
 import ctypes as C
 import os
 import sys
@@ -11,6 +11,7 @@ from tray_racing_amd import _lib as L  # noqa: E402
 
 lib = L.load()
 name = sys.argv[1] if len(sys.argv) > 1 else "bistro"
+variants = [int(x, 0) for x in sys.argv[2:]] or [0]
 w, h = 1920, 1080
 verts, counts = T.gen_scene(name, 0, 1)
 flat = T.flat_build(verts, counts)
@@ -22,7 +23,7 @@ sc = T.Scene(flat)
 def timeline(tag):
     buf = np.zeros(2 * 8192, dtype=np.uint64)
     n = C.c_uint32()
-    for _ in range(2):
+    for _ in range(10):  # let every launch slot learn the tile order
         L.check(lib.trx_debug_wave_timeline(sc.handle, C.byref(view), w, h, 3, buf.ctypes.data_as(C.c_void_p), 8192,
                                             C.byref(n)))
     t = buf[: 2 * n.value].reshape(-1, 2).astype(np.int64)
@@ -31,27 +32,17 @@ def timeline(tag):
     end = (t[:, 1] - t0) / 100.0
     life = end - start
     total = end.max()
-    print("%s: %d waves, frame %.1f us | start p50 %.1f p99 %.1f max %.1f | end p10 %.1f p50 %.1f p90 %.1f max %.1f | "
-          "mean lifetime %.1f us (%.0f%% of frame)" % (tag, n.value, total, np.percentile(start, 50),
-                                                        np.percentile(start, 99), start.max(), np.percentile(end, 10),
-                                                        np.percentile(end, 50), np.percentile(end, 90), end.max(),
-                                                        life.mean(), 100 * life.mean() / total), flush=True)
-    # concurrency over time
+    print("%s: %d waves, frame %.1f us | end p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f | mean lifetime %.1f us (%.0f%% of frame)" % (
+        tag, n.value, total, np.percentile(end, 10), np.percentile(end, 50), np.percentile(end, 90), np.percentile(end, 99),
+        end.max(), life.mean(), 100 * life.mean() / total), flush=True)
     ts = np.linspace(0, total, 11)
-    alive = [(int(((start <= x) & (end > x)).sum())) for x in ts]
-    print("   alive waves at 0..100%% of the frame: %s" % alive, flush=True)
+    print("   alive waves at 0..100%% of the frame: %s" % [int(((start <= x) & (end > x)).sum()) for x in ts], flush=True)
 
 
-NO_LPT, ONE_Q = 1 << 20, 1 << 21
-for tag, v in [("xcd queues + lpt", 64), ("xcd queues, no lpt", 64 | NO_LPT), ("single queue + lpt", 64 | ONE_Q),
-               ("single queue, no lpt", 64 | NO_LPT | ONE_Q), ("xcd+lpt 20 waves/CU", 64 | (20 << 8)),
-               ("xcd+lpt 12 waves/CU", 64 | (12 << 8)), ("xcd+lpt wpb4", 64 | (4 << 16))]:
+for v in variants:
     lib.trx_set_kernel_variant(v)
-    mn, mean = sc.bench_primary(view, w, h, sem=3, warmup=8, frames=20)
-    print("%-24s: min %.3f ms mean %.3f ms %.1f Mrays/s" % (tag, mn, mean, w * h / mn / 1e3), flush=True)
-    if v in (64, 64 | NO_LPT):
-        for _ in range(6):
-            sc.trace_primary(view, w, h, sem=3)
-        timeline("   timeline")
+    mn, mean = sc.bench_primary(view, w, h, sem=3, warmup=10, frames=20)
+    print("variant 0x%x: min %.3f ms mean %.3f ms %.1f Mrays/s" % (v, mn, mean, w * h / mn / 1e3), flush=True)
+    timeline("   timeline")
 lib.trx_set_kernel_variant(0)
 sc.close()

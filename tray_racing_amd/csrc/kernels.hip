@@ -23,6 +23,10 @@
 // TRX_SEM_NODE_FMA), IEEE divide and sqrt, dot = (ax*bx + ay*by) + az*bz.
 #include "kernels.h"
 
+#ifndef TRX_NODE_UNROLL
+#define TRX_NODE_UNROLL 2
+#endif
+
 #pragma clang fp contract(off)
 
 namespace trx {
@@ -49,6 +53,16 @@ template <int NODE>
 __device__ __forceinline__ float plane(float q, float a, float b) {
     if (NODE & 2) return __builtin_fmaf(q, a, b);
     return q * a + b;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two planes at once: q * a + b on both halves (separate roundings unless NODE & 2)
+template <int NODE>
+__device__ __forceinline__ f32x2 plane2(f32x2 q, float a, float b) {
+    const f32x2 a2 = {a, a}, b2 = {b, b};
+    if (NODE & 2) return __builtin_elementwise_fma(q, a2, b2);
+    return q * a2 + b2;
 }
 
 __device__ __forceinline__ float ubyte(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xffu); }
@@ -80,7 +94,7 @@ __device__ __forceinline__ uint32_t node_intersect(const Ray &r, float max_dista
     }
     const bool nx = r.dx < 0.0f, ny = r.dy < 0.0f, nz = r.dz < 0.0f;
     uint32_t hit_mask = 0;
-#pragma unroll
+#pragma unroll TRX_NODE_UNROLL
     for (int i = 0; i < 2; i++) {
         const uint32_t meta4 = i == 0 ? n1.z : n1.w;
         const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
@@ -95,14 +109,14 @@ __device__ __forceinline__ uint32_t node_intersect(const Ray &r, float max_dista
         const uint32_t z_min = nz ? q_hi_z : q_lo_z, z_max = nz ? q_lo_z : q_hi_z;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const float tminx = plane<NODE>(ubyte(x_min, j), ax, bx);
-            const float tminy = plane<NODE>(ubyte(y_min, j), ay, by);
-            const float tminz = plane<NODE>(ubyte(z_min, j), az, bz);
-            const float tmaxx = plane<NODE>(ubyte(x_max, j), ax, bx);
-            const float tmaxy = plane<NODE>(ubyte(y_max, j), ay, by);
-            const float tmaxz = plane<NODE>(ubyte(z_max, j), az, bz);
-            const float tmin = fmaxf(fmaxf(fmaxf(tminx, tminy), tminz), 0.0001f);
-            const float tmax = fminf(fminf(fminf(tmaxx, tmaxy), tmaxz), max_distance);
+            // the near and far plane of one axis go through the same multiply and add: as a float2
+            // they are one v_pk_mul_f32 + one v_pk_add_f32 (two IEEE operations per lane in the issue
+            // slot of one), or one v_pk_fma_f32; the VALU issue rate is what bounds this kernel
+            const f32x2 tx = plane2<NODE>(f32x2{ubyte(x_min, j), ubyte(x_max, j)}, ax, bx);
+            const f32x2 ty = plane2<NODE>(f32x2{ubyte(y_min, j), ubyte(y_max, j)}, ay, by);
+            const f32x2 tz = plane2<NODE>(f32x2{ubyte(z_min, j), ubyte(z_max, j)}, az, bz);
+            const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0001f);
+            const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), max_distance);
             if (tmin <= tmax) {
                 const uint32_t child_bits = (child_bits4 >> (8 * j)) & 0xffu;
                 const uint32_t bit_index = (bit_index4 >> (8 * j)) & 0xffu;
