@@ -56,7 +56,45 @@ struct Bvh2Builder {
     std::vector<uint32_t> idx;
     std::vector<Node2> nodes;
 
-    static constexpr int kBins = 16;
+    static constexpr int kBins = 32;
+
+    static constexpr uint32_t kSweepMax = 48;
+
+    // Exact SAH for small ranges: for every axis sort by centroid and sweep all n-1 splits.
+    uint32_t sweep_split(uint32_t begin, uint32_t end, const Aabb &bounds) {
+        const uint32_t n = end - begin;
+        uint32_t order[3][kSweepMax];
+        float right_area[kSweepMax];
+        float best_cost = kInf;
+        int best_axis = -1;
+        uint32_t best_k = 0;
+        for (int axis = 0; axis < 3; axis++) {
+            uint32_t *o = order[axis];
+            for (uint32_t i = 0; i < n; i++) o[i] = idx[begin + i];
+            std::sort(o, o + n, [&](uint32_t a, uint32_t b) {
+                float ca = cen[3 * (size_t)a + axis], cb = cen[3 * (size_t)b + axis];
+                return ca < cb || (ca == cb && a < b);
+            });
+            Aabb acc = empty_box();
+            for (uint32_t i = n - 1; i > 0; i--) {
+                grow(acc, boxes[o[i]]);
+                right_area[i] = half_area(acc);
+            }
+            acc = empty_box();
+            for (uint32_t k = 1; k < n; k++) { // left = o[0..k), right = o[k..n)
+                grow(acc, boxes[o[k - 1]]);
+                float cost = half_area(acc) * (float)k + right_area[k] * (float)(n - k);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_k = k;
+                }
+            }
+        }
+        (void)bounds;
+        for (uint32_t i = 0; i < n; i++) idx[begin + i] = order[best_axis][i];
+        return begin + best_k;
+    }
 
     // Splits [begin,end) in place; returns the split position (begin < mid < end).
     uint32_t split(uint32_t begin, uint32_t end, Aabb &bounds_out) {
@@ -69,6 +107,7 @@ struct Bvh2Builder {
         bounds_out = bounds;
         uint32_t n = end - begin;
         if (n == 2) return begin + 1;
+        if (n <= kSweepMax) return sweep_split(begin, end, bounds);
 
         float best_cost = kInf;
         int best_axis = -1, best_bin = -1;
