@@ -335,6 +335,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     if (P.lpt_read_counts) {
         end_a = P.lpt_read_counts[(15u - (lane >> 3)) * kLptShards + (lane & 7u)];
         end_b = P.lpt_read_counts[(15u - ((lane + 64u) >> 3)) * kLptShards + (lane & 7u)];
+        // a list that overflowed its capacity dropped entries: fall back to the natural order
+        const bool intact = __ballot(end_a > P.lpt_cap || end_b > P.lpt_cap) == 0ull;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t ya = __shfl_up(end_a, off), yb = __shfl_up(end_b, off);
             if ((int)lane >= off) {
@@ -343,7 +345,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             }
         }
         end_b += (uint32_t)__builtin_amdgcn_readlane((int)end_a, 63);
-        ordered = (uint32_t)__builtin_amdgcn_readlane((int)end_b, 63) == n_chunks; // complete lists for this geometry
+        ordered = intact && (uint32_t)__builtin_amdgcn_readlane((int)end_b, 63) == n_chunks; // complete lists
     }
 
     bool exhausted = false; // wave-uniform
