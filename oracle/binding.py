@@ -121,7 +121,7 @@ class Scene:
             lib.orc_tris_from_verts(_ptr(self.verts), self.verts.shape[0], _ptr(self.tris))
         self.inst = np.ascontiguousarray(instance_offsets if instance_offsets is not None else [], dtype=np.uint32)
         self.c = SceneC(_ptr(self.nodes), self.nodes.shape[0], _ptr(self.tris), self.tris.shape[0],
-                        _ptr(self.inst) if self.inst.size else None, self.inst.size, tlas_start)
+                        _ptr(self.inst) if self.inst.size else None, self.inst.size, int(tlas_start))
 
     @classmethod
     def from_flat(cls, flat):

@@ -101,6 +101,35 @@ def main():
         return e
 
     save("ties_rays", flat, None, 0, 0, tie_extra)
+    # 5. the reference's 24-byte f16 triangle format + explicit rays through a TLAS, GPU AO epsilon
+    verts, counts = T.gen_scene("kitchen", 4000, 3)
+    eye, look, fov = T.scene_camera("kitchen")
+    flat = T.flat_build(verts, counts, use_tlas=True)
+    view = T.view_from_camera(eye, look, fov, 56, 40)
+    packed = T.pack_tris_f16(flat.tri_verts)
+    rng = np.random.default_rng(42)
+    rr = np.zeros(700, dtype=T.RAY_DTYPE)
+    pts = flat.tri_verts.reshape(-1, 3)
+    rr["origin"] = rng.uniform(pts.min(0), pts.max(0), size=(700, 3)).astype(np.float32)
+    d = rng.normal(size=(700, 3)).astype(np.float32)
+    d[:20, 1] = 0.0
+    rr["direction"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rr["tmin"] = np.where(np.arange(700) % 5 == 0, 0.3, 0.0).astype(np.float32)
+    rr["tmax"] = np.where(np.arange(700) % 3 == 0, 2.5, O.F32_MAX).astype(np.float32)
+
+    def f16_extra(osc):
+        osc16 = O.Scene(flat.nodes, None, flat.instance_offsets, flat.tlas_start, tri_f16=packed)
+        ov = O.view_from_bytes(view)
+        e = {"tri_f16": packed, "rays": rr}
+        for sem in SEMS:
+            prim, _ = osc16.trace_primary(ov, 56, 40, sem=sem)
+            e["orc_f16_primary_sem%d" % sem] = prim
+            e["orc_f16_ao_eps1e-4_sem%d" % sem] = osc16.trace_ao(ov, 56, 40, prim, sem=sem, frame=9, ao_eps=0.0001)[0]
+            e["orc_rays_sem%d" % sem] = osc.trace_rays(rr, sem=sem)[0]
+            e["bf_rays_sem%d" % sem] = osc.brute_rays(rr, sem=sem)
+        return e
+
+    save("kitchen_tlas_f16_56x40", flat, view, 56, 40, f16_extra)
 
 
 if __name__ == "__main__":

@@ -69,6 +69,25 @@ def test_golden_ties_and_zero_directions(trx):
     sc.close()
 
 
+def test_golden_f16_tlas_rays(trx):
+    """The reference's 24-byte f16 triangles through a TLAS, AO with the GPU epsilon (1e-4,
+    rt_gpu_software.hlsl:115), and explicit rays with tmin / tmax ranges."""
+    g = np.load(os.path.join(GOLDEN, "kitchen_tlas_f16_56x40.npz"))
+    flat = GoldenFlat(trx, g).flat
+    w, h = int(g["width"]), int(g["height"])
+    view = load_view(trx, g["view"])
+    sc16 = trx.Scene(flat, tri_format=trx.TRI_F16_24, tri_bytes=g["tri_f16"])
+    sc = trx.Scene(flat)
+    for sem in (0, 3):
+        prim, ao, _ = sc16.trace_primary_ao(view, w, h, sem=sem, frame=9, ao_eps=0.0001)
+        assert_hits_equal(prim, g["orc_f16_primary_sem%d" % sem], "f16 primary sem %d" % sem)
+        assert_hits_equal(ao, g["orc_f16_ao_eps1e-4_sem%d" % sem], "f16 ao sem %d" % sem)
+        got, _ = sc.trace_rays(g["rays"], sem=sem)
+        assert_hits_equal(got, g["orc_rays_sem%d" % sem], "tlas rays sem %d" % sem)
+    sc16.close()
+    sc.close()
+
+
 # ---- live comparison on seeded scenes, every semantics combination ------------------------------
 
 @pytest.mark.parametrize("name,n,w,h,tlas", [("cornell", 0, 96, 64, False), ("kitchen", 20000, 120, 72, False),

@@ -332,3 +332,20 @@ def test_reference_assets_oracle_vs_bruteforce(trx, orc, scene):
             got, st = osc.trace_primary(ov, w, h, sem=sem)
             assert st.n_hits > 100
             assert_matches_bruteforce(osc, rays, got, osc.brute_primary(ov, w, h, sem=sem), sem)
+
+
+def test_golden_f16_tlas_rays(orc):
+    g, osc = load_golden(orc, "kitchen_tlas_f16_56x40")
+    w, h = int(g["width"]), int(g["height"])
+    view = orc.view_from_bytes(g["view"].tobytes())
+    osc16 = orc.Scene(g["nodes"], None, g["instance_offsets"], int(g["tlas_start"]), tri_f16=g["tri_f16"])
+    for sem in (0, 3):
+        prim, _ = osc16.trace_primary(view, w, h, sem=sem)
+        assert_hits_equal(prim, g["orc_f16_primary_sem%d" % sem], "f16 primary sem %d" % sem)
+        ao, _ = osc16.trace_ao(view, w, h, prim, sem=sem, frame=9, ao_eps=0.0001)
+        assert_hits_equal(ao, g["orc_f16_ao_eps1e-4_sem%d" % sem], "f16 ao sem %d" % sem)
+        got, _ = osc.trace_rays(g["rays"], sem=sem)
+        assert_hits_equal(got, g["orc_rays_sem%d" % sem], "tlas rays sem %d" % sem)
+        bf = g["bf_rays_sem%d" % sem]
+        near = bf["t"] < 2e-4
+        assert_matches_bruteforce(osc, g["rays"][~near], got[~near], bf[~near], sem)
