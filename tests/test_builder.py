@@ -97,3 +97,41 @@ def test_build_is_deterministic_across_thread_counts(trx):
     a = trx.flat_build(verts, counts, threads=1)
     b = trx.flat_build(verts, counts, threads=4)
     assert (a.nodes == b.nodes).all() and (a.tri_source == b.tri_source).all()
+
+
+@pytest.mark.parametrize("setting", [(0.02, 4), (0.5, 2), (1.0, 1)])
+def test_reinsertion_keeps_the_tree_valid_and_the_hits_unchanged(trx, orc, setting):
+    """The BVH2 reinsertion pass (obvhs `reinsertion_batch_ratio`, src/main.rs:113-118) only moves
+    subtrees: the collapsed tree must stay sound, hold every triangle once, and answer like
+    brute force."""
+    verts, counts = trx.gen_scene("bistro", 20000, 3)
+    eye, look, fov = trx.scene_camera("bistro")
+    view = trx.view_from_camera(eye, look, fov, 40, 24)
+    try:
+        off = trx.flat_build(verts, counts, reinsertion=0.0)
+        on = trx.flat_build(verts, counts, reinsertion=setting)
+        again = trx.flat_build(verts, counts, reinsertion=setting, threads=1)
+    finally:
+        trx.flat_build(verts[:1], reinsertion=(0.02, 4))  # back to the library default
+    assert (on.nodes == again.nodes).all() and (on.tri_source == again.tri_source).all()
+    assert not (on.nodes.shape == off.nodes.shape and (on.nodes == off.nodes).all())
+    assert sorted(on.tri_source.tolist()) == list(range(verts.shape[0]))
+    so, sn = orc.Scene.from_flat(off), orc.Scene.from_flat(on)
+    assert sn.validate()[0] == 0
+    ov = orc.view_from_bytes(view)
+    want = sn.brute_primary(ov, 40, 24, sem=3)
+    got, st_on = sn.trace_primary(ov, 40, 24, sem=3)
+    _, st_off = so.trace_primary(ov, 40, 24, sem=3)
+    assert (got["t"] == want["t"]).all()
+    hit = want["prim"] != 0xffffffff
+    assert (hit == (got["prim"] != 0xffffffff)).all()
+    # the pass exists to cut traversal work; allow noise on a 960-ray view but not a regression
+    assert st_on.n_node + st_on.n_tri < 1.1 * (st_off.n_node + st_off.n_tri)
+
+
+def test_reinsertion_rejects_bad_arguments(trx):
+    lib = trx._lib.load()
+    assert lib.trx_set_build_reinsertion(-0.1, 2) != 0
+    assert lib.trx_set_build_reinsertion(1.5, 2) != 0
+    assert lib.trx_set_build_reinsertion(0.1, -1) != 0
+    assert lib.trx_set_build_reinsertion(0.02, 4) == 0

@@ -31,6 +31,8 @@ namespace {
 thread_local std::string g_err;
 uint32_t g_variant = 0;
 float g_traversal_cost = 1.0f, g_prim_cost = 0.3f;
+float g_reinsert_ratio = 0.02f;
+int g_reinsert_iters = 4;
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -927,6 +929,8 @@ int trx_bvh_build_tris(const float *verts, uint64_t n, uint32_t max_prims, int t
     bp.threads = threads;
     bp.traversal_cost = g_traversal_cost;
     bp.prim_cost = g_prim_cost;
+    bp.reinsertion_batch_ratio = g_reinsert_ratio;
+    bp.reinsertion_iterations = g_reinsert_iters;
     try {
         build_cwbvh_from_tris(verts, n, bp, b->bvh);
     } catch (const std::exception &) {
@@ -948,6 +952,8 @@ int trx_bvh_build_aabbs(const float *aabbs, uint64_t n, uint32_t max_prims, int 
     bp.threads = threads;
     bp.traversal_cost = g_traversal_cost;
     bp.prim_cost = g_prim_cost;
+    bp.reinsertion_batch_ratio = g_reinsert_ratio;
+    bp.reinsertion_iterations = g_reinsert_iters;
     try {
         build_cwbvh_from_aabbs((const Aabb *)aabbs, n, bp, b->bvh);
     } catch (const std::exception &) {
@@ -962,6 +968,14 @@ int trx_set_build_costs(float traversal_cost, float prim_cost) {
     if (!(traversal_cost > 0.f) || !(prim_cost > 0.f)) return fail(TRX_ERR_INVALID, "costs must be positive");
     g_traversal_cost = traversal_cost;
     g_prim_cost = prim_cost;
+    return TRX_OK;
+}
+
+int trx_set_build_reinsertion(float batch_ratio, int iterations) {
+    if (!(batch_ratio >= 0.f) || batch_ratio > 1.f || iterations < 0)
+        return fail(TRX_ERR_INVALID, "reinsertion: ratio in [0,1], iterations >= 0");
+    g_reinsert_ratio = batch_ratio;
+    g_reinsert_iters = iterations;
     return TRX_OK;
 }
 
@@ -991,6 +1005,8 @@ int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32
     bp.threads = threads;
     bp.traversal_cost = g_traversal_cost;
     bp.prim_cost = g_prim_cost;
+    bp.reinsertion_batch_ratio = g_reinsert_ratio;
+    bp.reinsertion_iterations = g_reinsert_iters;
     try {
         // without --tlas everything is flattened into the first object (src/main.rs:300-308)
         std::vector<uint64_t> counts;

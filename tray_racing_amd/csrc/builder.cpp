@@ -5,6 +5,8 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -255,6 +257,186 @@ struct Bvh2Builder {
             for (int i = 0; i < threads; i++) pool.emplace_back(worker);
             for (auto &th : pool) th.join();
         }
+    }
+};
+
+// ---- BVH2 reinsertion optimisation ------------------------------------------
+// Meister & Bittner 2018, "Parallel Reinsertion for Bounding Volume Hierarchy
+// Optimization" (the pass obvhs runs after PLOC, knob `reinsertion_batch_ratio`
+// behind the reference's `-r`, src/main.rs:113-118).  The nodes with the largest
+// surface area are taken out one at a time and put back where the summed area
+// of the inner nodes drops the most; the search walks from the node's old place
+// towards the root and explores each sibling subtree with branch-and-bound.
+// Candidates are processed sequentially in a fixed order, so the result does
+// not depend on the thread count.
+struct Reinserter {
+    static constexpr uint32_t kNone = 0xffffffffu;
+    std::vector<Node2> &nodes;
+    std::vector<uint32_t> parent;
+    std::vector<std::pair<float, uint32_t>> stack;
+
+    explicit Reinserter(std::vector<Node2> &n) : nodes(n), parent(n.size(), kNone) {
+        for (uint32_t i = 0; i < nodes.size(); i++)
+            if (nodes[i].count > 1) parent[nodes[i].left] = parent[nodes[i].right] = i;
+    }
+    bool leaf(uint32_t i) const { return nodes[i].count == 1; }
+    uint32_t sibling(uint32_t i) const {
+        const Node2 &p = nodes[parent[i]];
+        return p.left == i ? p.right : p.left;
+    }
+    double inner_area() const {
+        double s = 0.0;
+        for (const Node2 &n : nodes)
+            if (n.count > 1) s += half_area(n.box);
+        return s;
+    }
+
+    // Best place below `top` for a box of area `area`; `gain` is what the tree
+    // has saved so far by taking the node out (everything above `top`).
+    void search(uint32_t top, float gain, const Aabb &box, float area, uint32_t &best_to, float &best_gain) {
+        stack.clear();
+        stack.emplace_back(gain, top);
+        while (!stack.empty()) {
+            auto [g, id] = stack.back();
+            stack.pop_back();
+            if (g - area <= best_gain) continue; // even a zero-growth insertion cannot win
+            const Node2 &dst = nodes[id];
+            Aabb merged = dst.box;
+            grow(merged, box);
+            float here = g - half_area(merged); // new inner node holding {dst, node}
+            if (here > best_gain) {
+                best_gain = here;
+                best_to = id;
+            }
+            if (dst.count > 1) {
+                // going below dst instead grows dst to `merged`
+                float below = here + half_area(dst.box);
+                stack.emplace_back(below, dst.left);
+                stack.emplace_back(below, dst.right);
+            }
+        }
+    }
+
+    bool find(uint32_t from, uint32_t &to) {
+        const uint32_t p = parent[from];
+        const Aabb box = nodes[from].box;
+        const float area = half_area(box);
+        float gain = half_area(nodes[p].box); // p disappears
+        float best_gain = 0.f;
+        uint32_t best_to = kNone;
+        uint32_t sib = sibling(from);
+        search(sib, gain, box, area, best_to, best_gain);
+        Aabb shrunk = nodes[sib].box; // what the path node looks like without `from`
+        for (uint32_t cur = p; parent[cur] != kNone; cur = parent[cur]) {
+            sib = sibling(cur);
+            search(sib, gain, box, area, best_to, best_gain);
+            grow(shrunk, nodes[sib].box);
+            gain += half_area(nodes[parent[cur]].box) - half_area(shrunk);
+        }
+        to = best_to;
+        return best_to != kNone;
+    }
+
+    void replace_child(uint32_t par, uint32_t old_child, uint32_t new_child) {
+        if (nodes[par].left == old_child)
+            nodes[par].left = new_child;
+        else
+            nodes[par].right = new_child;
+        parent[new_child] = par;
+    }
+    void refit_up(uint32_t i) {
+        for (; i != kNone; i = parent[i]) {
+            Aabb b = nodes[nodes[i].left].box;
+            grow(b, nodes[nodes[i].right].box);
+            if (std::memcmp(&b, &nodes[i].box, sizeof(Aabb)) == 0) break;
+            nodes[i].box = b;
+        }
+    }
+    void move(uint32_t from, uint32_t to) {
+        const uint32_t p = parent[from], s = sibling(from), g = parent[p];
+        replace_child(g, p, s);
+        const uint32_t tp = parent[to];
+        replace_child(tp, to, p);
+        nodes[p].left = to;
+        nodes[p].right = from;
+        parent[to] = p;
+        parent[from] = p;
+        nodes[p].box = nodes[to].box;
+        grow(nodes[p].box, nodes[from].box);
+        refit_up(g);
+        refit_up(tp);
+    }
+
+    uint32_t run(float batch_ratio, int iterations) {
+        const size_t n = nodes.size();
+        uint32_t moved = 0;
+        if (n < 8 || batch_ratio <= 0.f) return 0;
+        std::vector<std::pair<float, uint32_t>> cand;
+        for (int it = 0; it < iterations; it++) {
+            cand.clear();
+            for (uint32_t i = 1; i < n; i++)
+                if (parent[i] != 0) cand.emplace_back(half_area(nodes[i].box), i);
+            size_t take = std::min(cand.size(), (size_t)std::max(1.0, (double)n * batch_ratio));
+            auto larger = [](const std::pair<float, uint32_t> &a, const std::pair<float, uint32_t> &b) {
+                return a.first > b.first || (a.first == b.first && a.second < b.second);
+            };
+            std::partial_sort(cand.begin(), cand.begin() + take, cand.end(), larger);
+            uint32_t moved_now = 0;
+            for (size_t c = 0; c < take; c++) {
+                uint32_t from = cand[c].second, to;
+                if (parent[from] == 0 || parent[from] == kNone) continue; // an earlier move put it under the root
+                if (find(from, to)) {
+                    move(from, to);
+                    moved_now++;
+                }
+            }
+            moved += moved_now;
+            if (moved_now == 0) break;
+        }
+        if (moved) relayout();
+        return moved;
+    }
+
+    // Back to DFS pre-order (left child == self + 1, a subtree over k primitives
+    // owns 2k-1 consecutive nodes), which the collapse below relies on.
+    void relayout() {
+        const size_t n = nodes.size();
+        // primitive counts, children before parents
+        std::vector<uint32_t> order;
+        order.reserve(n);
+        order.push_back(0);
+        for (size_t i = 0; i < order.size(); i++) {
+            const Node2 &nd = nodes[order[i]];
+            if (nd.count > 1) {
+                order.push_back(nd.left);
+                order.push_back(nd.right);
+            }
+        }
+        std::vector<uint32_t> cnt(n, 1);
+        for (size_t i = order.size(); i-- > 0;) {
+            const Node2 &nd = nodes[order[i]];
+            if (nd.count > 1) cnt[order[i]] = cnt[nd.left] + cnt[nd.right];
+        }
+        std::vector<Node2> out(n);
+        std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 0u}}; // (old, new)
+        while (!todo.empty()) {
+            auto [o, w] = todo.back();
+            todo.pop_back();
+            const Node2 &nd = nodes[o];
+            Node2 &dst = out[w];
+            dst.box = nd.box;
+            dst.prim = nd.prim;
+            dst.count = cnt[o];
+            if (nd.count > 1) {
+                dst.left = w + 1;
+                dst.right = w + 2 * cnt[nd.left];
+                todo.emplace_back(nd.right, dst.right);
+                todo.emplace_back(nd.left, dst.left);
+            } else {
+                dst.left = dst.right = 0;
+            }
+        }
+        nodes.swap(out);
     }
 };
 
@@ -514,9 +696,15 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
     b2.cen.assign(centroids, centroids + 3 * n);
     b2.run((uint32_t)n, threads);
     out.total_aabb = b2.nodes[0].box;
+    if (params.reinsertion_batch_ratio > 0.f && params.reinsertion_iterations > 0) {
+        Reinserter opt(b2.nodes);
+        opt.run(params.reinsertion_batch_ratio, params.reinsertion_iterations);
+    }
 
     Collapser col(b2.nodes, params, out);
     col.compute_costs();
+    out.sah_cost = col.dec[0].cost / std::max(half_area(b2.nodes[0].box), 1e-30f);
+    if (getenv("TRX_BUILD_VERBOSE")) fprintf(stderr, "[trx build] n=%llu sah8=%.3f\n", (unsigned long long)n, out.sah_cost);
     if (b2.nodes[0].count > 1) col.dec[0].type = kInternal; // the root is always a node
     out.nodes.reserve(n / 4 + 16);
     out.primitive_indices.reserve(n);

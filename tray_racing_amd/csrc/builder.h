@@ -19,12 +19,17 @@ struct CwBvh {
     std::vector<uint32_t> primitive_indices;
     Aabb total_aabb;
     double build_seconds = 0.0;
+    float sah_cost = 0.f; // collapse cost of the root / root area
 };
 
 struct BuildParams {
     uint32_t max_prims_per_leaf = 3; // CWBVH limit (src/main.rs:176-178)
     float traversal_cost = 1.0f;     // collapse_traversal_cost analogue (src/main.rs:158-163)
     float prim_cost = 0.3f;
+    // BVH2 reinsertion pass: fraction of the nodes (largest area first) re-placed
+    // per iteration (obvhs `reinsertion_batch_ratio`, src/main.rs:113-118); 0 = off
+    float reinsertion_batch_ratio = 0.02f;
+    int reinsertion_iterations = 4;
     int threads = 0; // <= 0: hardware_concurrency
 };
 

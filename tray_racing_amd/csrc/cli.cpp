@@ -6,6 +6,7 @@
 // built on the CPU by this repo's stand-in builder (the reference builds with OBVHS).  Links against
 // include/trx.h only.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,6 +30,7 @@ struct Options { // src/main.rs:65-171 (flags this backend cannot honour are rej
     float collapse_traversal_cost = 1.0f;
     unsigned passes = 3;
     std::string preset;
+    float reinsertion_batch_ratio = -1.0f; // -r; < 0: library default
     int device = 0;
     unsigned semantics = TRX_SEM_HLSL; // the GPU path of the reference is the HLSL text
 };
@@ -125,8 +127,10 @@ Options parse_args(int argc, char **argv) {
         else if (a == "-h" || a == "--help") {
             usage();
             std::exit(0);
+        } else if (a == "-r") {
+            o.reinsertion_batch_ratio = (float)std::atof(need(i));
         } else if (a == "--search-distance" || a == "--search-depth-threshold" || a == "--sort-precision" ||
-                   a == "-r" || a == "--post-collapse-reinsertion-batch-ratio-multiplier") {
+                   a == "--post-collapse-reinsertion-batch-ratio-multiplier") {
             need(i); // PLOC parameters of the OBVHS builder: accepted, not used by the stand-in builder
         } else if (a == "--split" || a == "--auto-tune" || a == "--disable-auto-tune-model-cache") {
             // accepted for command-line compatibility; no effect here
@@ -178,6 +182,11 @@ Stats render_input(const Options &o, const std::string &input) {
     const bool tlas = o.tlas && !o.flatten_blas; // src/main.rs:300-308
     if (o.verbose) std::printf("%u objects \"%s\"\ntriangles %llu\n", n_objects, st.name.c_str(), (unsigned long long)n_tris);
     check(trx_set_build_costs(o.collapse_traversal_cost, 0.3f), "build costs");
+    if (o.reinsertion_batch_ratio >= 0.f) {
+        // obvhs: 0..1 is the candidate ratio of one pass, above 1 the whole set is evaluated several times
+        float r = o.reinsertion_batch_ratio;
+        check(trx_set_build_reinsertion(r > 1.f ? 1.f : r, r > 1.f ? (int)std::ceil(r) : 1), "reinsertion");
+    }
     trx_flat *flat = nullptr;
     check(trx_flat_build(verts, counts, n_objects, tlas ? 1 : 0, o.max_prims_per_leaf, 0, &flat), "build");
     st.blas_build_time_s = flat->blas_build_s;
