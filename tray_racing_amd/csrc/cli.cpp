@@ -15,6 +15,8 @@
 #include <string>
 #include <vector>
 
+#include <zlib.h>
+
 #include "../../include/trx.h"
 
 namespace {
@@ -147,9 +149,70 @@ Options parse_args(int argc, char **argv) {
     if (o.build != "ploc_cwbvh") die("NO BVH BUILDER SPECIFIED (this backend serves --build ploc_cwbvh)"); // src/cwbvh.rs:99
     if (o.cpu) die("--cpu is the reference's own rt_cpu path; the HIP backend has no CPU traversal");
     if (o.hardware) die("--hardware needs ray-tracing hardware; MI355X (CDNA4) has none");
-    if (o.png) die("--png is CPU-only in the reference (src/rt_cpu/rt_cpu.rs:102-112) and not offered here");
     if (o.passes == 0) o.passes = 1;
     return o;
+}
+
+// 8-bit RGBA PNG, one zlib stream, filter 0 on every scanline
+void put_be32(std::vector<unsigned char> &v, uint32_t x) {
+    for (int k = 3; k >= 0; k--) v.push_back((unsigned char)(x >> (8 * k)));
+}
+void png_chunk(std::ofstream &f, const char *tag, const std::vector<unsigned char> &body) {
+    std::vector<unsigned char> head, crc_in(tag, tag + 4);
+    put_be32(head, (uint32_t)body.size());
+    crc_in.insert(crc_in.end(), body.begin(), body.end());
+    std::vector<unsigned char> tail;
+    put_be32(tail, (uint32_t)crc32(0L, crc_in.data(), (uInt)crc_in.size()));
+    f.write((const char *)head.data(), 4);
+    f.write((const char *)crc_in.data(), (std::streamsize)crc_in.size());
+    f.write((const char *)tail.data(), 4);
+}
+bool write_png(const std::string &path, const std::vector<unsigned char> &rgba, unsigned w, unsigned h) {
+    std::vector<unsigned char> raw;
+    raw.reserve((size_t)h * (w * 4 + 1));
+    for (unsigned y = 0; y < h; y++) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgba.begin() + (size_t)y * w * 4, rgba.begin() + (size_t)(y + 1) * w * 4);
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<unsigned char> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+    z.resize(zlen);
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    f.write((const char *)sig, 8);
+    std::vector<unsigned char> ihdr;
+    put_be32(ihdr, w);
+    put_be32(ihdr, h);
+    const unsigned char fmt[5] = {8, 6, 0, 0, 0}; // 8 bit, RGBA
+    ihdr.insert(ihdr.end(), fmt, fmt + 5);
+    png_chunk(f, "IHDR", ihdr);
+    png_chunk(f, "IDAT", z);
+    png_chunk(f, "IEND", {});
+    return (bool)f;
+}
+
+// The reference's image: AO term of the primary hit, 1/t where the primary ray missed, gamma 2.2 to u8
+// (src/rt_cpu/rt_cpu.rs:57-85,102-112; the same shading ends the GPU shader, rt_gpu_software.hlsl:47-144).
+void save_png(const Options &o, trx_scene *scene, const trx_view &view, unsigned frame_count, const std::string &name) {
+    const size_t n = (size_t)o.width * o.height;
+    std::vector<trx_hit> primary(n), ao(n);
+    float ms = 0;
+    check(trx_trace_primary_ao(scene, &view, o.width, o.height, o.semantics, frame_count, 0.0001f, primary.data(),
+                               ao.data(), &ms), "png frame");
+    std::vector<unsigned char> rgba(n * 4);
+    for (size_t i = 0; i < n; i++) {
+        float col = 1.0f / primary[i].t;
+        if (primary[i].t < 3.4028234663852886e38f) col = ao[i].t < 3.4028234663852886e38f ? ao[i].t / (1.0f + ao[i].t) : 1.0f;
+        const float g = std::pow(col, 2.2f) * 255.0f;
+        const unsigned char c = (unsigned char)(uint32_t)(g < 0.f ? 0.f : g);
+        rgba[4 * i + 0] = rgba[4 * i + 1] = rgba[4 * i + 2] = c;
+        rgba[4 * i + 3] = 255;
+    }
+    const std::string path = name + "_rend.png";
+    if (!write_png(path, rgba, o.width, o.height)) die("Failed to save image " + path);
+    if (o.verbose) std::printf("saved %s\n", path.c_str());
 }
 
 // one input of one pass: src/main.rs:241-478 (load, build, trace) -> Stats
@@ -219,6 +282,7 @@ Stats render_input(const Options &o, const std::string &input) {
     } while (total_ms < o.render_time * 1000.0 && frames < 100000);
     st.traversal_ms = o.benchmark ? min_ms : total_ms / frames;
     if (o.verbose) std::printf("%.2fms   avg render time over %u frames (min %.3fms)\n", total_ms / frames, frames, min_ms);
+    if (o.png) save_png(o, scene, view, frame_count, st.name);
 
     trx_scene_destroy(scene);
     trx_flat_destroy(flat);
