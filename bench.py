@@ -5,9 +5,10 @@ A step is one pass of the hot path over one 1920x1080 frame of primary rays
 (2,073,600 rays generated in-kernel; scene resident in HBM before the timed
 region).  With N > 1 (one process per GPU under torch.distributed.run) the
 frame's 8x8 tiles are dealt round-robin to the ranks (tile % N == rank), each
-rank traces its tiles into a compact shard buffer and ONE all-gather (RCCL)
-assembles the frame on every rank.  Total work is fixed as N grows:
-"scaling": "strong".
+rank traces its tiles straight into its block of a gather buffer and ONE in-place
+all-gather (RCCL) per batch of `--gather-batch` frames brings the hit records to
+every rank, which de-interleaves them into row-major frames (all inside the
+timed region).  Total work is fixed as N grows: "scaling": "strong".
 
 Frames are independent units of work, so `--streams` frames are kept in flight
 (frame k on HIP stream k % streams with its own buffers): the tail of a frame —
@@ -63,6 +64,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=0,
                     help="frames in flight; 0 = 4 for 1-2 GPUs, 8 beyond (a rank's shard shrinks with N, its "
                          "slowest tile does not); 1 = strictly one frame at a time")
+    ap.add_argument("--gather-batch", type=int, default=0,
+                    help="N > 1: frames completed by one all-gather; 0 = 8 (a 1080p frame is only 2 MB per rank at N = 8)")
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="frames submitted per kernel launch (1..8); 0 = 1 on one GPU, the gather batch beyond")
     ap.add_argument("--roofline-launches", type=int, default=40, help="un-overlapped launches timed for `roofline`")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,41 +125,70 @@ def main():
     if args.sim_shards > 1:  # development aid: time one rank's shard of an N-way split on one GPU
         shard_img = (0, args.sim_shards, 0)
     n_rays_total = w * h
-    fgs = [D.FrameGather(w, h, rank, world, "cuda") for _ in range(n_streams)]
-    locals_ = [fg.new_local() for fg in fgs]
-    frames = [torch.empty(n_rays_total, dtype=torch.int64, device="cuda") for _ in range(n_streams)]
+    # N > 1: frames are gathered in batches of F (one in-place all-gather per F frames: fewer, larger
+    # collectives).  Batch b runs on stream b % streams: F kernels back to back, the all-gather, the
+    # de-interleave; `streams` batches are in flight, so a gather overlaps the tracing of other batches.
+    F = 1 if world == 1 else (args.gather_batch if args.gather_batch > 0 else 8)
+    fgs = [D.FrameGather(w, h, rank, world, "cuda", batch=F) for _ in range(n_streams)] if world > 1 else []
+    frames = [torch.empty(F * n_rays_total, dtype=torch.int64, device="cuda") for _ in range(n_streams)]
+    state = {"k": 0, "batch": 0, "last": None}
 
     # algorithmic bytes of ONE launch on this rank (counting kernel = the reference's PROFILE_RT counters)
     st = scene.count_primary(view, w, h, sem=args.sem, shard=shard_img)
     launch_bytes = NODE_BYTES * st.n_node + TRI_BYTES * st.n_tri + HIT_BYTES * st.n_rays
 
-    def step(k):
-        j = k % n_streams
-        s = streams[j]
+    L_launch = args.frames_per_launch if args.frames_per_launch > 0 else (1 if world == 1 else F)
+    L_launch = max(1, min(L_launch, 8, F if world > 1 else 8))
+    if world == 1 and L_launch > 1:
+        frames = [torch.empty(L_launch * n_rays_total, dtype=torch.int64, device="cuda") for _ in range(n_streams)]
+
+    def trace(s, ptr, shard, n, stride):
+        """n frames in one launch (n == 1: the plain entry point), bracketed by events on the launching stream."""
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(s):
-            if world == 1:
-                # one GPU owns every tile: the kernel writes the row-major frame directly
-                ev0.record(s)
-                scene.trace_primary_dev(view, w, h, frames[j].data_ptr(), sem=args.sem, shard=shard_img,
-                                        stream=s.cuda_stream)
-                ev1.record(s)
-            else:
-                ev0.record(s)
-                scene.trace_primary_dev(view, w, h, locals_[j].data_ptr(), sem=args.sem, shard=shard_cmp,
-                                        stream=s.cuda_stream)
-                ev1.record(s)
+        ev0.record(s)
+        if n == 1:
+            scene.trace_primary_dev(view, w, h, ptr, sem=args.sem, shard=shard, stream=s.cuda_stream)
+        else:
+            scene.trace_primary_batch_dev([view] * n, w, h, ptr, stride, sem=args.sem, shard=shard, stream=s.cuda_stream)
+        ev1.record(s)
+        return ev0, ev1, n
+
+    def run_frames(n, events):
+        """Enqueue n frames (nothing here waits on the GPU)."""
+        done = 0
+        if world == 1:
+            while done < n:
+                m = min(L_launch, n - done)
+                j = state["k"] % n_streams
+                state["k"] += 1
+                with torch.cuda.stream(streams[j]):
+                    # one GPU owns every tile: the kernel writes the row-major frame(s) directly
+                    events.append(trace(streams[j], frames[j].data_ptr(), shard_img, m, n_rays_total))
+                state["last"] = frames[j][(m - 1) * n_rays_total: m * n_rays_total]
+                done += m
+            return
+        while done < n:
+            m = min(F, n - done)
+            j = state["batch"] % n_streams
+            fg, s = fgs[j], streams[j]
+            with torch.cuda.stream(s):
+                for f0 in range(0, m, L_launch):
+                    mm = min(L_launch, m - f0)
+                    events.append(trace(s, fg.slot(f0, m).data_ptr(), shard_cmp, mm, fg.records))
                 if args.dist_backend == "nccl":
-                    work = fgs[j].gather(locals_[j], async_op=True)  # the one collective: 8 B/ray all-gather
-                    work.wait()                                      # stream s (not the host) waits for it
+                    work = fg.gather(m=m, async_op=True)         # the one collective: 8 B/ray, m frames at once
+                    work.wait()                                   # stream s (not the host) waits for it
                 else:  # test mode: the same gather staged through host memory
                     s.synchronize()
-                    host = torch.empty((world, fgs[j].records), dtype=torch.int64)
-                    dist.all_gather_into_tensor(host.view(-1), locals_[j].cpu())
-                    fgs[j].gathered.copy_(host)
-                fgs[j].assemble(frames[j])
-        return ev0, ev1
+                    nrec = m * fg.records
+                    host = torch.empty(world * nrec, dtype=torch.int64)
+                    dist.all_gather_into_tensor(host, fg.flat[rank * nrec:(rank + 1) * nrec].cpu())
+                    fg.flat[: world * nrec].copy_(host)
+                fg.assemble(frames[j][: m * n_rays_total], m=m)
+            state["last"] = frames[j][(m - 1) * n_rays_total: m * n_rays_total]
+            state["batch"] += 1
+            done += m
 
     def sync_all():
         torch.cuda.synchronize()
@@ -163,19 +197,17 @@ def main():
         torch.cuda.synchronize()
 
     sync_all()
-    for k in range(args.warmup):
-        step(k)
+    run_frames(args.warmup, [])
     sync_all()
     t0 = time.perf_counter()
     events = []
-    for k in range(args.steps):
-        events.append(step(k))
+    run_frames(args.steps, events)
     sync_all()
     elapsed = time.perf_counter() - t0
     for s in streams:
         scene.check(s.cuda_stream)
-    frame = frames[(args.steps - 1) % n_streams]
-    in_flight_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+    frame = state["last"]
+    in_flight_ms = sum(a.elapsed_time(b) for a, b, _ in events) / len(events)   # per launch
 
     # roofline leg: the same launch with ONE frame in flight, hipEvents on the launching stream
     s0 = streams[0]
@@ -185,7 +217,7 @@ def main():
             ev0 = torch.cuda.Event(enable_timing=True)
             ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record(s0)
-            scene.trace_primary_dev(view, w, h, (frames[0] if world == 1 else locals_[0]).data_ptr(), sem=args.sem,
+            scene.trace_primary_dev(view, w, h, (frames[0] if world == 1 else fgs[0].slot(0, 1)).data_ptr(), sem=args.sem,
                                     shard=(shard_img if world == 1 else shard_cmp), stream=s0.cuda_stream)
             ev1.record(s0)
             single.append((ev0, ev1))
@@ -228,8 +260,12 @@ def main():
                             "(BASELINE.json configs[2])" % (args.scene, flat.n_tris, flat.n_nodes, w, h),
                 "semantics": "TRX_SEM_CPU" if args.sem == 3 else "bits=%d" % args.sem,
                 "builder": "binned-SAH BVH2 -> SAH-optimal BVH8 collapse (stands in for obvhs ploc_cwbvh)",
-                "parallelism": "8x8 tiles round-robin over %d rank(s), one all_gather of 8 B/ray per frame" % world,
-                "frames_in_flight": n_streams,
+                "parallelism": ("one GPU owns every 8x8 tile" if world == 1 else
+                                "8x8 tiles round-robin over %d ranks; hit shards (8 B/ray) all-gathered in place, %d frames "
+                                "per collective, and de-interleaved to row-major frames on every rank" % (world, F)),
+                "frames_in_flight": n_streams,   # kernels in flight (one per stream)
+                "frames_per_launch": L_launch,
+                "frames_per_gather": F,
                 "build_seconds": round(build_s, 2),
             },
             "roofline": {

@@ -220,6 +220,17 @@ int trx_trace_primary_dev(trx_scene *scene, const trx_view *view, uint32_t width
                           uint32_t height, trx_shard shard, uint32_t semantics,
                           trx_hit *d_hits, void *stream);
 
+/* n_frames (1..TRX_MAX_BATCH_FRAMES) primary frames in ONE launch: frame f is traced with views[f] and its
+ * records go to d_hits + f * frame_stride (in trx_hit records; frame_stride >= one frame's records for the
+ * shard layout).  The reference renders frame after frame with one dispatch each
+ * (src/rt_gpu/rt_gpu_software.rs:289-302); submitting several of them together gives the kernel's work queues
+ * n_frames x the tiles to balance, which matters when a rank's share of one frame is small (tile shards on 8
+ * GPUs: 4050 tiles for 4096 resident waves).  Results are identical to n_frames separate launches. */
+#define TRX_MAX_BATCH_FRAMES 8
+int trx_trace_primary_batch_dev(trx_scene *scene, const trx_view *views, uint32_t n_frames, uint32_t width,
+                                uint32_t height, trx_shard shard, uint32_t semantics, trx_hit *d_hits,
+                                uint64_t frame_stride, void *stream);
+
 /* AO pass of src/rt_gpu/rt_gpu_software.hlsl:105-128 / src/rt_cpu/rt_cpu.rs:61-80:
  * for every pixel whose d_primary hit is valid, build the AO ray (normal from
  * the hit triangle flipped toward the viewer, origin = eye + d*t - d*ao_eps,

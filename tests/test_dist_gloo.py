@@ -59,6 +59,20 @@ def worker(rank, world, port, q):
         want, _ = osc.trace_primary(ov, W, H, sem=3)
         ok = bool((frame["t"].view(np.uint32) == want["t"].view(np.uint32)).all() and
                   (frame["prim"] == want["prim"]).all())
+        # a batch of 3 frames (of a buffer sized for 4) completed by ONE in-place all-gather
+        fgb = D.FrameGather(W, H, rank, world, "cpu", batch=4)
+        eye, look, fov = T.scene_camera("cornell")
+        wants = []
+        for f in range(3):
+            vf = O.view_from_bytes(T.view_from_camera((eye[0] + 0.3 * f, eye[1], eye[2]), look, fov, W, H))
+            fgb.slot(f, 3).copy_(D.hits_to_int64(oracle_compact_shard(osc, vf, W, H, rank, world, fgb.records)))
+            wants.append(osc.trace_primary(vf, W, H, sem=3)[0])
+        fgb.gather(m=3, async_op=True).wait()
+        got = D.int64_to_hits(fgb.assemble(m=3)).reshape(3, W * H)
+        for f in range(3):
+            ok = ok and bool((got[f]["t"].view(np.uint32) == wants[f]["t"].view(np.uint32)).all() and
+                             (got[f]["prim"] == wants[f]["prim"]).all())
+        ok = ok and not np.array_equal(wants[0]["prim"], wants[2]["prim"])
         # timing reduce used by bench.py: max over ranks
         t = torch.tensor([float(rank + 1)])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -138,6 +138,46 @@ def test_triangle_formats(trx, orc):
 
 # ---- shards, layouts, odd sizes ------------------------------------------------------------------
 
+def test_frames_per_launch_match_separate_launches(trx, orc):
+    """trx_trace_primary_batch_dev: several frames (different cameras) in one launch, both layouts and a
+    strided output, must equal the oracle frame by frame; repeated so the tile-order feedback is live."""
+    import torch
+    from tray_racing_amd import dist as D
+    w, h = 200, 120
+    flat, _view, osc, _ov = make_scene(trx, orc, "bistro", 60000, w, h)
+    eye, look, fov = trx.scene_camera("bistro")
+    views = [trx.view_from_camera((eye[0] + 0.7 * f, eye[1] + 0.2 * f, eye[2]), look, fov, w, h) for f in range(5)]
+    wants = [osc.trace_primary(orc.view_from_bytes(v), w, h, sem=3)[0] for v in views]
+    sc = trx.Scene(flat)
+    stride = w * h + 96
+    out = torch.full((5 * stride,), -1, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        sc.trace_primary_batch_dev(views, w, h, out.data_ptr(), stride, sem=3)
+    sc.check()
+    for f in range(5):
+        assert_hits_equal(D.int64_to_hits(out[f * stride:f * stride + w * h]), wants[f], "image layout, frame %d" % f)
+        assert (out[f * stride + w * h:(f + 1) * stride] == -1).all()
+    # tile shards of 3 ranks, compact layout, gathered by hand
+    world = 3
+    fgs = [D.FrameGather(w, h, r, world, "cuda", batch=4) for r in range(world)]
+    for r in range(world):
+        for _ in range(2):
+            sc.trace_primary_batch_dev(views[:4], w, h, fgs[r].slot(0, 4).data_ptr(), fgs[r].records, sem=3,
+                                       shard=(r, world, 1))
+    sc.check()
+    n = 4 * fgs[0].records
+    for r in range(world):   # what the in-place all-gather would deliver to rank 0
+        fgs[0].flat[r * n:(r + 1) * n].copy_(fgs[r].flat[r * n:(r + 1) * n])
+    frames = D.int64_to_hits(fgs[0].assemble(m=4)).reshape(4, w * h)
+    for f in range(4):
+        assert_hits_equal(frames[f], wants[f], "shard layout, frame %d" % f)
+    with pytest.raises(trx.TrxError, match="n_frames"):
+        sc.trace_primary_batch_dev(views + views, w, h, out.data_ptr(), stride, sem=3)
+    with pytest.raises(trx.TrxError, match="frame_stride"):
+        sc.trace_primary_batch_dev(views[:2], w, h, out.data_ptr(), 10, sem=3)
+    sc.close()
+
+
 def test_shards_and_layouts(trx, orc):
     import torch
     from tray_racing_amd import dist as D
@@ -429,13 +469,14 @@ def test_bench_two_ranks_share_the_gpu(trx):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
            "--warmup", "2", "--tris", "150000", "--width", "256", "--height", "136", "--dist-backend", "gloo",
-           "--verify", "--streams", "2", "--roofline-launches", "2"]
+           "--verify", "--streams", "2", "--roofline-launches", "2", "--gather-batch", "4"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["parity_vs_oracle_full_frame"] is True and d["value"] > 0
     assert d["scaling"] == "strong" and d["config"]["frames_in_flight"] == 2
+    assert d["config"]["frames_per_gather"] == 4   # 6 timed frames = one full batch + a partial one
 
 
 def test_scheduling_variants_and_streams_do_not_change_results(trx, orc):

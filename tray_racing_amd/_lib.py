@@ -88,6 +88,7 @@ SIGNATURES = {
     "trx_scene_set_geometry_ranges": (_i, [_P, _P, _u32]),
     "trx_view_from_camera": (_i, [C.POINTER(_f), C.POINTER(_f), _f, _f, _f, C.POINTER(View)]),
     "trx_trace_primary_dev": (_i, [_P, C.POINTER(View), _u32, _u32, Shard, _u32, _P, _P]),
+    "trx_trace_primary_batch_dev": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, Shard, _u32, _P, _u64, _P]),
     "trx_trace_ao_dev": (_i, [_P, C.POINTER(View), _u32, _u32, Shard, _u32, _u32, _f, _P, _P, _P]),
     "trx_trace_rays_dev": (_i, [_P, _P, _u64, _u32, _P, _P]),
     "trx_count_primary": (_i, [_P, C.POINTER(View), _u32, _u32, Shard, _u32, _P, C.POINTER(Stats)]),

@@ -60,6 +60,8 @@ struct Slot {
     uint2 *spill = nullptr;
     hipEvent_t done = nullptr; // everything enqueued for this slot has finished
     bool used = false;
+    hipStream_t last_stream = nullptr; // stream of the last launch on this slot
+    uint64_t last_use = 0;             // launch counter at that time (oldest slot is recycled first)
     // tile-cost feedback: the previous frame traced on this slot measured every tile; the next one
     // with the same image geometry starts its heaviest tiles first
     uint32_t *lpt = nullptr; // two sets of {16 counts, 16 lists}
@@ -83,7 +85,7 @@ struct trx_scene {
     unsigned long long *d_wave_times = nullptr; // diagnostics only (trx_debug_wave_timeline)
     uint32_t *dbg_cost = nullptr, *dbg_iters = nullptr; // diagnostics only (trx_debug_tile_profile)
     Slot slots[kSlots];
-    int next_slot = 0;
+    uint64_t launches = 0;
     std::mutex mu;      // launch slots (every enqueue)
     std::recursive_mutex host_mu; // scratch buffers and event pair of the synchronous entry points
     // scratch for the host-buffer convenience entry points
@@ -242,8 +244,21 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     if (sem & ~7u) return fail(TRX_ERR_INVALID, "unknown semantics bits 0x%x", sem);
     HIP_TRY(hipSetDevice(s->device));
     std::lock_guard<std::mutex> lock(s->mu);
-    Slot &slot = s->slots[s->next_slot];
-    s->next_slot = (s->next_slot + 1) % kSlots;
+    // A stream keeps its slot: its launches are ordered anyway, and the slot's tile-order feedback
+    // stays with the caller's frame loop.  Otherwise take an unused slot, else the oldest one, and
+    // make the stream wait for that slot's last kernel.
+    int pick = -1;
+    for (int i = 0; i < kSlots && pick < 0; i++)
+        if (s->slots[i].used && s->slots[i].last_stream == stream) pick = i;
+    for (int i = 0; i < kSlots && pick < 0; i++)
+        if (!s->slots[i].used) pick = i;
+    if (pick < 0) {
+        pick = 0;
+        for (int i = 1; i < kSlots; i++)
+            if (s->slots[i].last_use < s->slots[pick].last_use) pick = i;
+    }
+    Slot &slot = s->slots[pick];
+    const bool same_stream = slot.used && slot.last_stream == stream;
     if (!slot.ctr) {
         HIP_TRY(hipMalloc(&slot.ctr, sizeof(SlotCounters)));
         HIP_TRY(hipMemset(slot.ctr, 0, sizeof(SlotCounters)));
@@ -251,7 +266,9 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         HIP_TRY(hipMalloc(&slot.spill, (size_t)s->cu_count * 32 * kSpillStack * kWave * sizeof(uint2)));
         HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     }
-    if (slot.used) HIP_TRY(hipStreamWaitEvent(stream, slot.done, 0));
+    if (slot.used && !same_stream) HIP_TRY(hipStreamWaitEvent(stream, slot.done, 0));
+    slot.last_stream = stream;
+    slot.last_use = ++s->launches;
     p.nodes = s->d_nodes;
     p.tris = s->d_tris;
     p.inst = s->d_inst;
@@ -264,6 +281,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     // coherence than idle lanes cost); incoherent rays (AO, explicit batches): replace finished rays
     // once 20 lanes idle (bistro-class AO pass 1.72 -> 1.16 ms, kitchen-class 0.75 -> 0.46 ms)
     p.refill_idle = refill ? std::min(refill, 64u) : (mode == kModePrimary ? 64u : 20u);
+    if (p.n_frames > 1) p.refill_idle = 64u; // the kernel takes the frame of a wave from its (whole) tile
     p.variant = g_variant;
     {   // tuning: variant bits 25..28 = compaction threshold (0 = default, 15 = never)
         const uint32_t c = (g_variant >> 25) & 0xfu;
@@ -297,7 +315,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
             slot.lpt_capacity = n_tiles;
         }
         key = ((uint64_t)p.width << 40) ^ ((uint64_t)p.height << 20) ^ ((uint64_t)p.shard_count << 8) ^ p.shard_index ^
-              ((uint64_t)(mode + 1) << 60);
+              ((uint64_t)(mode + 1) << 60) ^ ((uint64_t)p.n_frames << 56);
         uint32_t *set[2] = {slot.lpt, slot.lpt + set_words};
         if (slot.lpt_key != key) { // new geometry: empty both sets, cold (identity) order this frame
             HIP_TRY(hipMemsetAsync(set[0], 0, n_lists * sizeof(uint32_t), stream));
@@ -349,7 +367,10 @@ int image_params(TraceParams &p, const trx_view *view, uint32_t w, uint32_t h, t
     p.shard_count = shard.count;
     p.compact = shard.layout == TRX_LAYOUT_SHARD ? 1u : 0u;
     p.n_items = (uint32_t)(local * 64);
-    fill_view(view, p.view);
+    p.n_frames = 1;
+    p.tiles_per_frame = (uint32_t)local;
+    p.frame_stride = 0;
+    fill_view(view, p.views[0]);
     return TRX_OK;
 }
 
@@ -577,6 +598,30 @@ int trx_trace_primary_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32
     std::memset(&p, 0, sizeof(p));
     int rc = image_params(p, view, w, h, shard);
     if (rc) return rc;
+    p.out = d_hits;
+    if (p.n_items == 0) return TRX_OK;
+    return enqueue(s, p, kModePrimary, sem, false, (hipStream_t)stream, nullptr);
+}
+
+int trx_trace_primary_batch_dev(trx_scene *s, const trx_view *views, uint32_t n_frames, uint32_t w, uint32_t h,
+                                trx_shard shard, uint32_t sem, trx_hit *d_hits, uint64_t frame_stride, void *stream) {
+    if (!s || !d_hits || !views) return fail(TRX_ERR_INVALID, "null argument");
+    if (n_frames == 0 || n_frames > (uint32_t)kMaxBatchFrames)
+        return fail(TRX_ERR_INVALID, "n_frames %u outside 1..%d", n_frames, kMaxBatchFrames);
+    TraceParams p;
+    std::memset(&p, 0, sizeof(p));
+    int rc = image_params(p, views, w, h, shard);
+    if (rc) return rc;
+    const uint64_t frame_records = p.compact ? (uint64_t)p.tiles_per_frame * 64 : (uint64_t)w * h;
+    if (n_frames > 1 && frame_stride < frame_records)
+        return fail(TRX_ERR_INVALID, "frame_stride %llu < %llu records of one frame", (unsigned long long)frame_stride,
+                    (unsigned long long)frame_records);
+    if ((uint64_t)p.n_items * n_frames > 0x7fffffffull || frame_stride * (n_frames - 1) + frame_records > 0xffffffffull)
+        return fail(TRX_ERR_INVALID, "batch of %u frames too large", n_frames);
+    for (uint32_t f = 1; f < n_frames; f++) fill_view(&views[f], p.views[f]);
+    p.n_frames = n_frames;
+    p.frame_stride = (uint32_t)frame_stride;
+    p.n_items *= n_frames;
     p.out = d_hits;
     if (p.n_items == 0) return TRX_OK;
     return enqueue(s, p, kModePrimary, sem, false, (hipStream_t)stream, nullptr);

@@ -27,6 +27,8 @@ constexpr uint32_t kMaxSteps = 1u << 22; // per-ray iteration cap: every wave re
 
 enum TraceMode : int { kModePrimary = 0, kModeAo = 1, kModeRays = 2 };
 
+constexpr int kMaxBatchFrames = 8;
+
 struct ViewDev {
     float view_inv[16];
     float proj_inv[16];
@@ -83,7 +85,10 @@ struct TraceParams {
     uint32_t variant;
     uint32_t waves_per_block;        // 1, 2 or 4
     unsigned long long *wave_times;  // diagnostics: [2*wave] start, [2*wave+1] end (wall_clock64), or null
-    ViewDev view;
+    // frames per launch (image modes): frame f = local_tile / tiles_per_frame uses views[f] and writes its
+    // records at out + f * frame_stride; one launch then balances n_frames x the tiles
+    uint32_t n_frames, tiles_per_frame, frame_stride;
+    ViewDev views[kMaxBatchFrames];
 };
 
 // Resident waves the persistent kernel should be launched with on `device`.

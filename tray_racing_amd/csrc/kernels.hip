@@ -456,15 +456,23 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     out_index = item;
                     ok = true;
                 } else {
-                    const uint32_t tile = my_tile * P.shard_count + P.shard_index;
+                    // whole-tile refills only when frames are batched, so the frame is wave-uniform
+                    uint32_t local_tile = my_tile, frame_base = 0u, vf = 0u;
+                    if (P.n_frames > 1u) {
+                        vf = __builtin_amdgcn_readfirstlane(my_tile / P.tiles_per_frame);
+                        local_tile = my_tile - vf * P.tiles_per_frame;
+                        frame_base = vf * P.frame_stride;
+                    }
+                    const ViewDev &view = P.views[vf];
+                    const uint32_t tile = local_tile * P.shard_count + P.shard_index;
                     const uint32_t k = item & 63u;
                     const uint32_t px = (tile % P.tiles_x) * 8u + (k & 7u);
                     const uint32_t py = (tile / P.tiles_x) * 8u + (k >> 3);
                     if (px < P.width && py < P.height) {
-                        out_index = P.compact ? (tile / P.shard_count) * 64u + k : py * P.width + px;
-                        primary_dir(P.view, P.width, P.height, px, py, dx, dy, dz);
+                        out_index = frame_base + (P.compact ? local_tile * 64u + k : py * P.width + px);
+                        primary_dir(view, P.width, P.height, px, py, dx, dy, dz);
                         if (MODE == kModePrimary) {
-                            r.ox = P.view.eye[0]; r.oy = P.view.eye[1]; r.oz = P.view.eye[2];
+                            r.ox = view.eye[0]; r.oy = view.eye[1]; r.oz = view.eye[2];
                             ok = true;
                         } else {
                             const trx_hit ph = P.primary[out_index];
@@ -480,9 +488,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                                 const float nd = (nx * -dx + ny * -dy) + nz * -dz;
                                 const float sg = copysignf(1.0f, nd);
                                 nx *= sg; ny *= sg; nz *= sg;
-                                r.ox = (P.view.eye[0] + dx * ph.t) - dx * P.ao_eps;
-                                r.oy = (P.view.eye[1] + dy * ph.t) - dy * P.ao_eps;
-                                r.oz = (P.view.eye[2] + dz * ph.t) - dz * P.ao_eps;
+                                r.ox = (view.eye[0] + dx * ph.t) - dx * P.ao_eps;
+                                r.oy = (view.eye[1] + dy * ph.t) - dy * P.ao_eps;
+                                r.oz = (view.eye[2] + dz * ph.t) - dz * P.ao_eps;
                                 const float u1 = hash_noise(px, py, P.frame);
                                 const float u2 = hash_noise(px, py, P.frame + 1024u);
                                 const float rr = sqrtf(u1);

@@ -5,7 +5,8 @@ derives from its per-pixel independence (src/rt_cpu/rt_cpu.rs:35-37): the
 read-only scene is replicated, 8x8 tiles are dealt round-robin to ranks
 (tile % world == rank, include/trx.h trx_shard), every rank traces its tiles
 into a compact buffer (TRX_LAYOUT_SHARD) and ONE all-gather of 8 B/ray over
-RCCL/xGMI brings the frame together.  There is no other collective on the path.
+RCCL/xGMI brings a frame - or a batch of frames - together.  There is no other
+collective on the path.
 
 Everything here is tensor plumbing (torch.distributed); it works on CPU
 tensors with the gloo backend, which is how tests/ covers world_size > 1.
@@ -44,20 +45,39 @@ def pixel_index_of_records(width, height, world, device="cpu"):
 
 
 class FrameGather:
-    """Gathers per-rank compact hit shards (int64 view of {t f32, prim u32}) into a frame.
+    """Gathers per-rank compact hit shards (int64 view of {t f32, prim u32}) into frames.
 
-    `local` buffers hold max_shard_tiles*64 records (8 B each, viewed as int64) so
-    every rank contributes an equal-sized block to all_gather_into_tensor.
+    One buffer holds up to `batch` frames of every rank, laid out [world][m][records] for a
+    batch of m frames, so that ONE all-gather completes m frames: rank r traces frame f of
+    the batch straight into `slot(f, m)` (its own block of the buffer) and the all-gather
+    runs in place.  `records` = max_shard_tiles*64, equal on every rank.  Fewer, larger
+    collectives are what RCCL over xGMI rewards (a 1080p frame is only 2 MB per rank).
     """
 
-    def __init__(self, width, height, rank, world, device):
+    def __init__(self, width, height, rank, world, device, batch=1):
         self.width, self.height, self.rank, self.world = width, height, rank, world
         self.device = torch.device(device)
+        self.batch = max(1, int(batch))
         self.records = max_shard_tiles(width, height, world) * 64
-        self.gathered = torch.empty((world, self.records), dtype=torch.int64, device=self.device)
-        idx = pixel_index_of_records(width, height, world, self.device)
-        self._valid = (idx >= 0).view(-1)
-        self._pix = idx.view(-1)[self._valid]
+        self.flat = torch.empty(world * self.batch * self.records, dtype=torch.int64, device=self.device)
+        idx = pixel_index_of_records(width, height, world, self.device).view(-1)
+        src = torch.nonzero(idx >= 0).view(-1)                     # record -> pixel, valid records only
+        inv = torch.empty(width * height, dtype=torch.int64, device=self.device)
+        inv[idx[src]] = src                                        # pixel -> record of a 1-frame gather
+        self._inv_rank = inv // self.records
+        self._inv_off = inv % self.records
+        self._index = {}
+
+    @property
+    def gathered(self):
+        """[world, records] view of a one-frame gather."""
+        return self.flat[: self.world * self.records].view(self.world, self.records)
+
+    def slot(self, f=0, m=1):
+        """Where this rank's frame f of an m-frame batch lives (trace into it, then gather(m=m))."""
+        assert 0 <= f < m <= self.batch
+        o = (self.rank * m + f) * self.records
+        return self.flat[o:o + self.records]
 
     def new_local(self):
         # +inf / 0xFFFFFFFF (miss) everywhere so padding is well defined
@@ -65,18 +85,30 @@ class FrameGather:
         miss = int(np.array([0x7F800000 | (0xFFFFFFFF << 32)], dtype=np.uint64).view(np.int64)[0])
         return torch.full((self.records,), miss, dtype=torch.int64, device=self.device)
 
-    def gather(self, local, async_op=False):
-        """One all-gather of the frame's hit records (the only collective on the path)."""
+    def gather(self, local=None, async_op=False, m=1):
+        """One all-gather of m frames of hit records (the only collective on the path), in place;
+        a separate `local` buffer (m == 1) is copied into this rank's block first."""
+        if local is not None:
+            assert m == 1
+            self.slot(0, 1).copy_(local)
         if self.world == 1:
-            self.gathered[0].copy_(local)
             return None
-        return dist.all_gather_into_tensor(self.gathered.view(-1), local, async_op=async_op)
+        n = m * self.records
+        return dist.all_gather_into_tensor(self.flat[: self.world * n], self.flat[self.rank * n:(self.rank + 1) * n],
+                                           async_op=async_op)
 
-    def assemble(self, out=None):
-        """De-interleave gathered tile records into the row-major image (int64 per pixel)."""
+    def _batch_index(self, m):
+        if m not in self._index:
+            f = torch.arange(m, device=self.device).view(m, 1)
+            self._index[m] = ((self._inv_rank.view(1, -1) * m + f) * self.records + self._inv_off.view(1, -1)).reshape(-1)
+        return self._index[m]
+
+    def assemble(self, out=None, m=1):
+        """De-interleave gathered tile records into row-major images: out is [m * width*height] int64
+        (one index_select, no host synchronisation)."""
         if out is None:
-            out = torch.empty(self.width * self.height, dtype=torch.int64, device=self.device)
-        out[self._pix] = self.gathered.view(-1)[self._valid]
+            out = torch.empty(m * self.width * self.height, dtype=torch.int64, device=self.device)
+        torch.index_select(self.flat, 0, self._batch_index(m), out=out.view(-1))
         return out
 
 

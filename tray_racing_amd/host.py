@@ -223,6 +223,13 @@ class Scene:
         L.check(self._lib.trx_trace_primary_dev(self._h, C.byref(view), width, height, L.Shard(*shard), sem,
                                                 C.c_void_p(d_hits), C.c_void_p(stream)))
 
+    def trace_primary_batch_dev(self, views, width, height, d_hits, frame_stride, sem=L.SEM_HLSL, shard=(0, 1),
+                                stream=0):
+        """len(views) frames (1..8) in one launch; frame f lands at d_hits + f*frame_stride records."""
+        arr = (L.View * len(views))(*views)
+        L.check(self._lib.trx_trace_primary_batch_dev(self._h, arr, len(views), width, height, L.Shard(*shard), sem,
+                                                      C.c_void_p(d_hits), frame_stride, C.c_void_p(stream)))
+
     def trace_ao_dev(self, view, width, height, d_primary, d_ao, sem=L.SEM_HLSL, frame=0, ao_eps=0.01,
                      shard=(0, 1), stream=0):
         L.check(self._lib.trx_trace_ao_dev(self._h, C.byref(view), width, height, L.Shard(*shard), sem, frame, ao_eps,
