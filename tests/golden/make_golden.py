@@ -8,7 +8,12 @@ Each .npz carries its INPUTS (80-byte nodes, triangles, instance table, view)
 and the expected outputs, so the tests do not depend on the builder or on
 /root/reference being present.
 
-Run from the repo root:  python tests/golden/make_golden.py
+The `ref_*` fixtures are built from the two small OBJ assets the reference ships
+(assets/obj/cornell_box.obj, assets/obj/box.obj) with the cameras of their .ron scene
+files: they can only be regenerated where /root/reference is mounted; the fixtures
+themselves (CWBVH + f32 triangles + expected hits) travel.
+
+Run from the repo root:  python tests/golden/make_golden.py [name-substring ...]
 """
 import os
 import sys
@@ -55,7 +60,21 @@ def tie_scene():
     return verts, r
 
 
+ONLY = sys.argv[1:]
+REF_ASSETS = "/root/reference/assets"
+
+
+def ron_camera(path):
+    """eye / look_at / fov of a tray_racing scene file (assets/scenes/*.ron)."""
+    import re
+    txt = open(path).read()
+    vec = lambda key: [float(x) for x in re.search(key + r":\s*\(([^)]*)\)", txt).group(1).split(",")]
+    return vec("eye"), vec("look_at"), float(re.search(r"fov:\s*([-0-9.]+)", txt).group(1))
+
+
 def save(name, flat, view, w, h, extra):
+    if ONLY and not any(o in name for o in ONLY):
+        return
     osc = O.Scene.from_flat(flat)
     out = dict(nodes=flat.nodes, tri_verts=flat.tri_verts, instance_offsets=flat.instance_offsets,
                tlas_start=np.uint32(flat.tlas_start), width=np.uint32(w), height=np.uint32(h))
@@ -130,6 +149,18 @@ def main():
         return e
 
     save("kitchen_tlas_f16_56x40", flat, view, 56, 40, f16_extra)
+    # 6./7. the reference's own small assets (the only geometry it ships), its loader rules and its cameras
+    if os.path.exists(os.path.join(REF_ASSETS, "obj", "cornell_box.obj")):
+        verts, counts = T.load_meshs(os.path.join(REF_ASSETS, "obj", "cornell_box.obj"))
+        eye, look, fov = ron_camera(os.path.join(REF_ASSETS, "scenes", "cornell_box.ron"))
+        flat = T.flat_build(verts, counts)
+        save("ref_cornell_box_64", flat, T.view_from_camera(eye, look, fov, 64, 64), 64, 64, None)
+        verts, counts = T.load_meshs(os.path.join(REF_ASSETS, "obj", "box.obj"))
+        eye, look, fov = ron_camera(os.path.join(REF_ASSETS, "scenes", "box.ron"))
+        flat = T.flat_build(verts, counts, use_tlas=True)
+        save("ref_box_tlas_48", flat, T.view_from_camera(eye, look, fov, 48, 48), 48, 48, None)
+    else:
+        print("reference assets not mounted: ref_* fixtures left as they are")
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@ def assert_matches_bruteforce(osc, rays, got, bf, sem):
     return diff.size
 
 
-@pytest.mark.parametrize("name", ["cornell_64", "cornell_tlas_48", "soup_52x44"])
+@pytest.mark.parametrize("name", ["cornell_64", "cornell_tlas_48", "soup_52x44", "ref_cornell_box_64", "ref_box_tlas_48"])
 def test_golden_images(orc, name):
     g, osc = load_golden(orc, name)
     w, h = int(g["width"]), int(g["height"])
@@ -43,7 +43,7 @@ def test_golden_images(orc, name):
         ao, _ = osc.trace_ao(view, w, h, prim, sem=sem, frame=2, ao_eps=0.01)
         assert_hits_equal(ao, g["orc_ao_sem%d" % sem], "%s sem %d ao" % (name, sem))
         assert_matches_bruteforce(osc, rays, prim, g["bf_primary_sem%d" % sem], sem)
-        assert st.n_hits > 0.2 * w * h
+        assert st.n_hits > (0.05 if name == "ref_box_tlas_48" else 0.2) * w * h   # box.ron looks past the box
 
 
 def test_golden_ties(orc):

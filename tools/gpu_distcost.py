@@ -15,7 +15,8 @@ from tray_racing_amd import dist as D  # noqa: E402
 
 dist.init_process_group("nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:29533",
                         device_id=torch.device("cuda", 0))
-w, h, sim = 1920, 1080, 8
+w, h = 1920, 1080
+sim = int(os.environ.get("SIM_SHARDS", "8"))
 name = sys.argv[1] if len(sys.argv) > 1 else "bistro"
 verts, counts = T.gen_scene(name, 0, 1)
 flat = T.flat_build(verts, counts)
