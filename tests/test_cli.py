@@ -131,3 +131,26 @@ def test_cli_png_is_the_reference_shading(tmp_path):
     diff = np.abs(img[..., 0].astype(int) - want.astype(int))
     assert diff.max() <= 1 and (diff != 0).mean() < 0.01   # powf rounding may move a value across an integer
     assert 0.05 < (img[..., 0] > 0).mean()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/assets/scenes/cornell_box.ron"),
+                    reason="the reference checkout is not mounted here")
+def test_cli_reads_the_scene_files_the_reference_ships():
+    """--dry-run (scene file + model + build, no device): the RON subset and the relative-model-path rule
+    (src/main.rs:262-284) on the reference's own assets/scenes/*.ron, run from the reference's root."""
+    r = run("-i", "assets/scenes/cornell_box.ron,assets/scenes/box.ron", "--dry-run", "--verbose", "--passes", "1", "--tlas",
+            cwd="/root/reference")
+    assert r.returncode == 0, r.stderr
+    assert re.search(r"5 objects \"cornell_box\"\s+triangles 3968", r.stdout)
+    assert re.search(r"2 objects \"box\"\s+triangles 14", r.stdout)
+    assert "camera eye 0 1 2.1 look_at 0 1 0 fov 90" in r.stdout              # assets/scenes/cornell_box.ron
+    assert "camera eye 3 1.5 1.4 look_at -3.94386 1.5 -1.73035 fov 90" in r.stdout  # assets/scenes/box.ron
+    rows = parse_table(r.stdout[r.stdout.index(" name"):])
+    assert set(rows) == {"cornell_box", "box", "Avg"} and rows["box"][2] > 0
+    # every scene file of the reference parses (the models of most are absent: .MISSING_LARGE_BLOBS)
+    for f in sorted(os.listdir("/root/reference/assets/scenes")):
+        r = run("-i", "assets/scenes/" + f, "--dry-run", "--passes", "1", cwd="/root/reference")
+        ok_model = f in ("cornell_box.ron", "box.ron")
+        assert (r.returncode == 0) == ok_model, (f, r.stderr)
+        if not ok_model:
+            assert "Failed to load config" not in r.stderr, f   # the scene file itself parsed; only the model is missing

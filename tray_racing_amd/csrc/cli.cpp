@@ -33,6 +33,7 @@ struct Options { // src/main.rs:65-171 (flags this backend cannot honour are rej
     unsigned passes = 3;
     std::string preset;
     float reinsertion_batch_ratio = -1.0f; // -r; < 0: library default
+    bool dry_run = false; // load + build only (no device needed)
     int device = 0;
     unsigned semantics = TRX_SEM_HLSL; // the GPU path of the reference is the HLSL text
 };
@@ -96,6 +97,7 @@ void usage() {
     std::puts("tray_racing_hip -i <scene.ron|demoscene|standin:<name>>[,...] [--benchmark] [--render-time s]\n"
               "  [--build ploc_cwbvh] [--max-prims-per-leaf 1..3] [--collapse-traversal-cost c] [--preset p]\n"
               "  [--width w] [--height h] [--animate] [--tlas] [--flatten-blas] [--passes n] [--verbose] [--device d]\n"
+              "  [--png] [--cpu-semantics] [--dry-run (load + build only, needs no GPU)] [-r reinsertion_batch_ratio]\n"
               "stand-in names: cornell demoscene kitchen bistro hairball san_miguel (seeded procedural scenes)");
 }
 
@@ -126,6 +128,7 @@ Options parse_args(int argc, char **argv) {
         else if (a == "--tlas") o.tlas = true;
         else if (a == "--flatten-blas") o.flatten_blas = true;
         else if (a == "--cpu-semantics") o.semantics = TRX_SEM_CPU;
+        else if (a == "--dry-run") o.dry_run = true;
         else if (a == "-h" || a == "--help") {
             usage();
             std::exit(0);
@@ -255,6 +258,14 @@ Stats render_input(const Options &o, const std::string &input) {
     st.blas_build_time_s = flat->blas_build_s;
     st.tlas_build_time_ms = flat->tlas_build_s * 1000.0;
     if (o.verbose) std::printf("nodes %llu tlas_start %u instances %u\n", (unsigned long long)flat->n_nodes, flat->tlas_start, flat->n_instances);
+    if (o.dry_run) { // scene file, model and build only: nothing below this line works without a device
+        if (o.verbose) std::printf("camera eye %g %g %g look_at %g %g %g fov %g\n", cam.eye[0], cam.eye[1], cam.eye[2],
+                                   cam.look_at[0], cam.look_at[1], cam.look_at[2], cam.fov);
+        trx_flat_destroy(flat);
+        trx_free(verts);
+        trx_free(counts);
+        return st;
+    }
 
     trx_scene *scene = nullptr;
     check(trx_scene_create(flat->bvh_bytes, flat->n_nodes, flat->tri_verts, flat->n_tris, TRX_TRI_VERTS_36,
@@ -318,7 +329,7 @@ void print_table(const std::vector<Stats> &rows) { // tabled Style::blank(), src
 
 int main(int argc, char **argv) {
     Options o = parse_args(argc, argv);
-    if (trx_device_count() <= o.device) die("no HIP device " + std::to_string(o.device) + " (libtrx.so has no CPU fallback)");
+    if (!o.dry_run && trx_device_count() <= o.device) die("no HIP device " + std::to_string(o.device) + " (libtrx.so has no CPU fallback)");
     std::vector<std::string> inputs;
     {
         std::stringstream ss(o.input);
