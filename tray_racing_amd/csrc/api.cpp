@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +18,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/trx.h"
@@ -1069,11 +1072,51 @@ int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32
         tri_out.reserve(total * 9);
         tri_source.reserve(total);
         double blas_s = 0.0, tlas_s = 0.0;
+        // BLAS builds: large objects one after the other with every thread, the (many) small ones of a
+        // TLAS scene concurrently with one thread each; assembly below stays in object order
+        std::vector<CwBvh> built(counts.size());
+        std::vector<uint64_t> firsts(counts.size());
+        {
+            uint64_t f0 = 0;
+            for (size_t i = 0; i < counts.size(); i++) { firsts[i] = f0; f0 += counts[i]; }
+            const auto t0 = std::chrono::steady_clock::now();
+            int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+            if (nthreads < 1) nthreads = 1;
+            const uint64_t kSmall = 65536;
+            std::vector<size_t> small;
+            for (size_t i = 0; i < counts.size(); i++) {
+                if (counts[i] > kSmall || counts.size() == 1 || nthreads == 1)
+                    build_cwbvh_from_tris(verts + firsts[i] * 9, counts[i], bp, built[i]);
+                else
+                    small.push_back(i);
+            }
+            if (!small.empty()) {
+                BuildParams one = bp;
+                one.threads = 1;
+                std::atomic<size_t> next{0};
+                std::atomic<bool> failed{false};
+                auto worker = [&]() {
+                    try {
+                        for (size_t k = next.fetch_add(1); k < small.size(); k = next.fetch_add(1)) {
+                            const size_t i = small[k];
+                            build_cwbvh_from_tris(verts + firsts[i] * 9, counts[i], one, built[i]);
+                        }
+                    } catch (...) {
+                        failed = true;
+                    }
+                };
+                std::vector<std::thread> pool;
+                const int n = (int)std::min<size_t>((size_t)nthreads, small.size());
+                for (int t = 0; t < n; t++) pool.emplace_back(worker);
+                for (auto &th : pool) th.join();
+                if (failed) throw std::bad_alloc();
+            }
+            blas_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
         uint64_t first = 0;
-        for (uint64_t cnt : counts) {
-            CwBvh bvh;
-            build_cwbvh_from_tris(verts + first * 9, cnt, bp, bvh);
-            blas_s += bvh.build_seconds;
+        for (size_t bi = 0; bi < counts.size(); bi++) {
+            const uint64_t cnt = counts[bi];
+            CwBvh &bvh = built[bi];
             const uint32_t tri_offset = (uint32_t)(tri_out.size() / 9);
             blas_tri_start.push_back(tri_offset);
             // permute triangles into primitive_indices order (mod.rs:38-43)
