@@ -16,6 +16,10 @@ namespace {
 
 constexpr float kInf = std::numeric_limits<float>::infinity();
 
+// the builder's large working arrays (hundreds of megabytes on the 4-5 M triangle scenes)
+template <class T>
+using BigVec = std::vector<T>;
+
 inline Aabb empty_box() {
     return Aabb{{kInf, kInf, kInf}, {-kInf, -kInf, -kInf}};
 }
@@ -54,9 +58,9 @@ struct Task {
 
 struct Bvh2Builder {
     const Aabb *boxes;
-    std::vector<float> cen; // 3 per primitive
-    std::vector<uint32_t> idx;
-    std::vector<Node2> nodes;
+    BigVec<float> cen; // 3 per primitive
+    BigVec<uint32_t> idx;
+    BigVec<Node2> nodes;
 
     static constexpr int kBins = 32;
 
@@ -271,11 +275,9 @@ struct Bvh2Builder {
 // not depend on the thread count.
 struct Reinserter {
     static constexpr uint32_t kNone = 0xffffffffu;
-    std::vector<Node2> &nodes;
-    std::vector<uint32_t> parent;
-    std::vector<std::pair<float, uint32_t>> stack;
-
-    explicit Reinserter(std::vector<Node2> &n) : nodes(n), parent(n.size(), kNone) {
+    BigVec<Node2> &nodes;
+    BigVec<uint32_t> parent;
+    explicit Reinserter(BigVec<Node2> &n) : nodes(n), parent(n.size(), kNone) {
         for (uint32_t i = 0; i < nodes.size(); i++)
             if (nodes[i].count > 1) parent[nodes[i].left] = parent[nodes[i].right] = i;
     }
@@ -293,7 +295,9 @@ struct Reinserter {
 
     // Best place below `top` for a box of area `area`; `gain` is what the tree
     // has saved so far by taking the node out (everything above `top`).
-    void search(uint32_t top, float gain, const Aabb &box, float area, uint32_t &best_to, float &best_gain) {
+    typedef std::vector<std::pair<float, uint32_t>> Scratch;
+    void search(Scratch &stack, uint32_t top, float gain, const Aabb &box, float area, uint32_t &best_to,
+                float &best_gain) const {
         stack.clear();
         stack.emplace_back(gain, top);
         while (!stack.empty()) {
@@ -317,7 +321,7 @@ struct Reinserter {
         }
     }
 
-    bool find(uint32_t from, uint32_t &to) {
+    bool find(Scratch &stack, uint32_t from, uint32_t &to) const {
         const uint32_t p = parent[from];
         const Aabb box = nodes[from].box;
         const float area = half_area(box);
@@ -325,11 +329,11 @@ struct Reinserter {
         float best_gain = 0.f;
         uint32_t best_to = kNone;
         uint32_t sib = sibling(from);
-        search(sib, gain, box, area, best_to, best_gain);
+        search(stack, sib, gain, box, area, best_to, best_gain);
         Aabb shrunk = nodes[sib].box; // what the path node looks like without `from`
         for (uint32_t cur = p; parent[cur] != kNone; cur = parent[cur]) {
             sib = sibling(cur);
-            search(sib, gain, box, area, best_to, best_gain);
+            search(stack, sib, gain, box, area, best_to, best_gain);
             grow(shrunk, nodes[sib].box);
             gain += half_area(nodes[parent[cur]].box) - half_area(shrunk);
         }
@@ -363,15 +367,20 @@ struct Reinserter {
         parent[from] = p;
         nodes[p].box = nodes[to].box;
         grow(nodes[p].box, nodes[from].box);
+        // primitive counts stay exact (the re-layout needs them): the old path loses `from`, the new gains it
+        const uint32_t moved_prims = nodes[from].count;
+        nodes[p].count = nodes[to].count + moved_prims;
+        for (uint32_t a = g; a != kNone; a = parent[a]) nodes[a].count -= moved_prims;
+        for (uint32_t a = tp; a != kNone; a = parent[a]) nodes[a].count += moved_prims;
         refit_up(g);
         refit_up(tp);
     }
 
-    uint32_t run(float batch_ratio, int iterations) {
+    uint32_t run(float batch_ratio, int iterations, int threads) {
         const size_t n = nodes.size();
         uint32_t moved = 0;
         if (n < 8 || batch_ratio <= 0.f) return 0;
-        std::vector<std::pair<float, uint32_t>> cand;
+        BigVec<std::pair<float, uint32_t>> cand;
         for (int it = 0; it < iterations; it++) {
             cand.clear();
             for (uint32_t i = 1; i < n; i++)
@@ -380,12 +389,16 @@ struct Reinserter {
             auto larger = [](const std::pair<float, uint32_t> &a, const std::pair<float, uint32_t> &b) {
                 return a.first > b.first || (a.first == b.first && a.second < b.second);
             };
-            std::partial_sort(cand.begin(), cand.begin() + take, cand.end(), larger);
+            if (take < cand.size()) std::nth_element(cand.begin(), cand.begin() + take, cand.end(), larger);
+            std::sort(cand.begin(), cand.begin() + take, larger);
+            // one at a time, each search on the tree as the previous move left it (sequential: the searches
+            // cost little next to the memory passes around them, and stale searches lose tree quality)
             uint32_t moved_now = 0;
+            Scratch scratch;
             for (size_t c = 0; c < take; c++) {
                 uint32_t from = cand[c].second, to;
                 if (parent[from] == 0 || parent[from] == kNone) continue; // an earlier move put it under the root
-                if (find(from, to)) {
+                if (find(scratch, from, to)) {
                     move(from, to);
                     moved_now++;
                 }
@@ -393,48 +406,53 @@ struct Reinserter {
             moved += moved_now;
             if (moved_now == 0) break;
         }
-        if (moved) relayout();
+        if (moved) relayout(threads);
         return moved;
     }
 
     // Back to DFS pre-order (left child == self + 1, a subtree over k primitives
     // owns 2k-1 consecutive nodes), which the collapse below relies on.
-    void relayout() {
+    void relayout(int threads) {
         const size_t n = nodes.size();
-        // primitive counts, children before parents
-        std::vector<uint32_t> order;
-        order.reserve(n);
-        order.push_back(0);
-        for (size_t i = 0; i < order.size(); i++) {
-            const Node2 &nd = nodes[order[i]];
-            if (nd.count > 1) {
-                order.push_back(nd.left);
-                order.push_back(nd.right);
+        BigVec<Node2> out(n);
+        typedef std::pair<uint32_t, uint32_t> Job; // (old index, new index) of a subtree root
+        auto place = [&](Job root, uint32_t stop_below, std::vector<Job> *deferred) {
+            std::vector<Job> todo{root};
+            while (!todo.empty()) {
+                auto [o, w] = todo.back();
+                todo.pop_back();
+                const Node2 &nd = nodes[o];
+                if (deferred && nd.count <= stop_below) { // small enough: a worker places this subtree
+                    deferred->push_back(Job(o, w));
+                    continue;
+                }
+                Node2 &dst = out[w];
+                dst.box = nd.box;
+                dst.prim = nd.prim;
+                dst.count = nd.count;
+                if (nd.count > 1) {
+                    dst.left = w + 1;
+                    dst.right = w + 2 * nodes[nd.left].count;
+                    todo.emplace_back(nd.right, dst.right);
+                    todo.emplace_back(nd.left, dst.left);
+                } else {
+                    dst.left = dst.right = 0;
+                }
             }
-        }
-        std::vector<uint32_t> cnt(n, 1);
-        for (size_t i = order.size(); i-- > 0;) {
-            const Node2 &nd = nodes[order[i]];
-            if (nd.count > 1) cnt[order[i]] = cnt[nd.left] + cnt[nd.right];
-        }
-        std::vector<Node2> out(n);
-        std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 0u}}; // (old, new)
-        while (!todo.empty()) {
-            auto [o, w] = todo.back();
-            todo.pop_back();
-            const Node2 &nd = nodes[o];
-            Node2 &dst = out[w];
-            dst.box = nd.box;
-            dst.prim = nd.prim;
-            dst.count = cnt[o];
-            if (nd.count > 1) {
-                dst.left = w + 1;
-                dst.right = w + 2 * cnt[nd.left];
-                todo.emplace_back(nd.right, dst.right);
-                todo.emplace_back(nd.left, dst.left);
-            } else {
-                dst.left = dst.right = 0;
-            }
+        };
+        std::vector<Job> jobs;
+        const uint32_t grain = std::max<uint32_t>(1024u, nodes[0].count / (uint32_t)(std::max(1, threads) * 16));
+        if (threads <= 1) {
+            place(Job(0u, 0u), 0u, nullptr);
+        } else {
+            place(Job(0u, 0u), grain, &jobs);
+            std::atomic<size_t> next{0};
+            auto worker = [&]() {
+                for (size_t k = next.fetch_add(1); k < jobs.size(); k = next.fetch_add(1)) place(jobs[k], 0u, nullptr);
+            };
+            std::vector<std::thread> pool;
+            for (int t = 0; t < threads; t++) pool.emplace_back(worker);
+            for (auto &th : pool) th.join();
         }
         nodes.swap(out);
     }
@@ -448,12 +466,12 @@ struct Decision {
 };
 
 struct Collapser {
-    const std::vector<Node2> &n2;
-    std::vector<Decision> dec; // 7 per BVH2 node
+    const BigVec<Node2> &n2;
+    BigVec<Decision> dec; // 7 per BVH2 node
     BuildParams params;
     CwBvh &out;
 
-    Collapser(const std::vector<Node2> &nodes, const BuildParams &p, CwBvh &o)
+    Collapser(const BigVec<Node2> &nodes, const BuildParams &p, CwBvh &o)
         : n2(nodes), dec(nodes.size() * 7), params(p), out(o) {}
 
     void compute_costs() {
@@ -694,15 +712,24 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
     Bvh2Builder b2;
     b2.boxes = boxes;
     b2.cen.assign(centroids, centroids + 3 * n);
+    const bool verbose = getenv("TRX_BUILD_VERBOSE") != nullptr && n > 100000;
+    auto lap = [&](const char *what) {
+        if (verbose)
+            fprintf(stderr, "[trx build] %-12s %.3f s\n", what,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    };
     b2.run((uint32_t)n, threads);
+    lap("bvh2");
     out.total_aabb = b2.nodes[0].box;
     if (params.reinsertion_batch_ratio > 0.f && params.reinsertion_iterations > 0) {
         Reinserter opt(b2.nodes);
-        opt.run(params.reinsertion_batch_ratio, params.reinsertion_iterations);
+        opt.run(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads);
+        lap("reinsertion");
     }
 
     Collapser col(b2.nodes, params, out);
     col.compute_costs();
+    lap("collapse dp");
     out.sah_cost = col.dec[0].cost / std::max(half_area(b2.nodes[0].box), 1e-30f);
     if (getenv("TRX_BUILD_VERBOSE")) fprintf(stderr, "[trx build] n=%llu sah8=%.3f\n", (unsigned long long)n, out.sah_cost);
     if (b2.nodes[0].count > 1) col.dec[0].type = kInternal; // the root is always a node
@@ -710,6 +737,7 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
     out.primitive_indices.reserve(n);
     out.nodes.resize(1);
     col.emit(0, 0);
+    lap("emit");
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
