@@ -328,7 +328,8 @@ int trx_set_build_costs(float traversal_cost, float prim_cost);
 /* BVH2 reinsertion pass for subsequent builds (process-wide): per iteration the `batch_ratio`
  * fraction of the nodes with the largest area is re-placed where the tree's summed area drops the
  * most (Meister & Bittner 2018) — obvhs' `reinsertion_batch_ratio`, the reference's `-r`
- * (src/main.rs:113-118).  batch_ratio 0 switches the pass off.  Default 0.02 x 4 iterations. */
+ * (src/main.rs:113-118).  batch_ratio 0 switches the pass off.  Default 0.02 x 4 iterations.  Applied to
+ * triangle builds only: over instance boxes (TLAS) it measured worse and is skipped. */
 int trx_set_build_reinsertion(float batch_ratio, int iterations);
 void trx_bvh_destroy(trx_bvh *bvh);
 uint64_t trx_bvh_node_count(const trx_bvh *bvh);

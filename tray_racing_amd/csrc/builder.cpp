@@ -731,7 +731,7 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
     col.compute_costs();
     lap("collapse dp");
     out.sah_cost = col.dec[0].cost / std::max(half_area(b2.nodes[0].box), 1e-30f);
-    if (getenv("TRX_BUILD_VERBOSE")) fprintf(stderr, "[trx build] n=%llu sah8=%.3f\n", (unsigned long long)n, out.sah_cost);
+    if (verbose) fprintf(stderr, "[trx build] n=%llu sah8=%.3f\n", (unsigned long long)n, out.sah_cost);
     if (b2.nodes[0].count > 1) col.dec[0].type = kInternal; // the root is always a node
     out.nodes.reserve(n / 4 + 16);
     out.primitive_indices.reserve(n);
