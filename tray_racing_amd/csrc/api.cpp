@@ -1144,6 +1144,9 @@ int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32
             // 62.9 -> 67.4 node visits per ray with it, 62.7 with the pass in the BLASes only)
             BuildParams bpt = bp;
             bpt.reinsertion_batch_ratio = 0.f;
+            // ... and an instance is dearer than a node visit: cost 3 instead of 0.3 keeps one instance per leaf
+            // slot, each with its own quantised box (same scene: 62.7 -> 60.6 node visits per ray)
+            bpt.prim_cost = std::max(bpt.prim_cost, 3.0f);
             build_cwbvh_from_aabbs(blas_aabb.data(), blas_aabb.size(), bpt, tlas);
             tlas_s = tlas.build_seconds;
             for (uint32_t pi : tlas.primitive_indices) inst.push_back(blas_offset[pi]);
