@@ -454,6 +454,45 @@ def test_full_size_hairball_ao_and_tlas_4k_sample(trx, orc):
     sc.close()
 
 
+def test_full_size_shard_union_and_counter_sums(trx, orc):
+    """Size-independent properties at configs[4]'s full size (san-miguel-class, TLAS, 3840x2160 over 8 ranks):
+    the 8 compact shards, gathered and de-interleaved, ARE the single-launch frame bit for bit, and the
+    per-shard traversal counters add up to the full frame's.  Plus, on the bistro-class scene, the explicit-ray
+    entry point fed the oracle's primary rays answers like in-kernel ray generation."""
+    import torch
+    from tray_racing_amd import dist as D
+    verts, counts = trx.gen_scene("san_miguel", 0, 1)
+    flat = trx.flat_build(verts, counts, use_tlas=True)
+    eye, look, fov = trx.scene_camera("san_miguel")
+    w, h, world = 3840, 2160, 8
+    view = trx.view_from_camera(eye, look, fov, w, h)
+    sc = trx.Scene(flat)
+    full = torch.empty(w * h, dtype=torch.int64, device="cuda")
+    sc.trace_primary_dev(view, w, h, full.data_ptr(), sem=3)
+    fg = D.FrameGather(w, h, 0, world, "cuda")
+    tot = [0, 0, 0, 0]
+    for r in range(world):
+        block = fg.flat[r * fg.records:(r + 1) * fg.records]
+        sc.trace_primary_dev(view, w, h, block.data_ptr(), sem=3, shard=(r, world, 1))
+        st = sc.count_primary(view, w, h, sem=3, shard=(r, world))
+        tot = [a + b for a, b in zip(tot, (st.n_rays, st.n_node, st.n_tri, st.n_hits))]
+    sc.check()
+    assert torch.equal(fg.assemble(), full)
+    st = sc.count_primary(view, w, h, sem=3)
+    assert tot == [st.n_rays, st.n_node, st.n_tri, st.n_hits] and st.n_rays == w * h
+    hits = D.int64_to_hits(full)
+    assert int(np.isfinite(hits["t"]).sum()) == st.n_hits > 0.9 * w * h
+    sc.close()
+
+    w, h = 640, 360
+    flat, view, osc, ov = make_scene(trx, orc, "bistro", 0, w, h)
+    sc = trx.Scene(flat)
+    by_kernel, _ = sc.trace_primary(view, w, h, sem=3)
+    by_rays, _ = sc.trace_rays(osc.primary_rays(ov, w, h), sem=3)
+    assert_hits_equal(by_rays, by_kernel, "explicit primary rays vs in-kernel generation")
+    sc.close()
+
+
 def test_bench_two_ranks_share_the_gpu(trx):
     """bench.py's N > 1 path end to end on one GPU: two ranks (gloo, shard gather staged through
     host memory) trace their tile shards on device 0; rank 0 checks the assembled frame."""
