@@ -74,7 +74,8 @@ def parse():
     ap.add_argument("--sim-shards", type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the shard gather through host memory (lets N ranks share one GPU in tests)")
-    ap.add_argument("--verify", action="store_true", help="rank 0 checks the assembled frame against the oracle")
+    ap.add_argument("--dump-frame", default="", help="rank 0 writes the last timed frame (int64 {t, prim} records, "
+                                                      ".npy) here, with the scene's flat buffers next to it (tests)")
     return ap.parse_args()
 
 
@@ -290,13 +291,13 @@ def main():
             },
         }
 
-    # CPU baseline: the oracle (a port, not the reference binary) on the host cores, rank 0 at N=1 only
-    if rank == 0 and world > 1 and args.verify:
-        from oracle import binding as O
-        want, _ = O.Scene.from_flat(flat).trace_primary(O.view_from_bytes(view), w, h, sem=args.sem)
-        gpu = D.int64_to_hits(frame)
-        out["parity_vs_oracle_full_frame"] = bool((gpu["t"].view(np.uint32) == want["t"].view(np.uint32)).all() and
-                                                  (gpu["prim"] == want["prim"]).all())
+    if rank == 0 and args.dump_frame:
+        np.save(args.dump_frame, frame.detach().cpu().numpy())
+        np.savez(args.dump_frame + ".scene.npz", nodes=flat.nodes, tri_verts=flat.tri_verts,
+                 instance_offsets=flat.instance_offsets, tlas_start=np.uint32(flat.tlas_start),
+                 view=np.frombuffer(bytes(view), dtype=np.uint8), width=np.uint32(w), height=np.uint32(h))
+    # CPU baseline: the oracle (a port, not the reference binary) on the host cores, rank 0 at N=1 only; it is
+    # the only place this file touches oracle/ (as the thing timed beside the GPU, and as the frame's checker)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.sim_shards == 1:
         from oracle import binding as O
         osc = O.Scene.from_flat(flat)

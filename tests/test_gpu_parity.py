@@ -493,9 +493,10 @@ def test_full_size_shard_union_and_counter_sums(trx, orc):
     sc.close()
 
 
-def test_bench_two_ranks_share_the_gpu(trx):
+def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path):
     """bench.py's N > 1 path end to end on one GPU: two ranks (gloo, shard gather staged through
-    host memory) trace their tile shards on device 0; rank 0 checks the assembled frame."""
+    host memory) trace their tile shards on device 0 in batches; the frame rank 0 ends up with is
+    checked against the oracle here."""
     import json
     import socket
     import subprocess
@@ -505,17 +506,24 @@ def test_bench_two_ranks_share_the_gpu(trx):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    dump = str(tmp_path / "frame.npy")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
            "--warmup", "2", "--tris", "150000", "--width", "256", "--height", "136", "--dist-backend", "gloo",
-           "--verify", "--streams", "2", "--roofline-launches", "2", "--gather-batch", "4"]
+           "--dump-frame", dump, "--streams", "2", "--roofline-launches", "2", "--gather-batch", "4"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["parity_vs_oracle_full_frame"] is True and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["value"] > 0
     assert d["scaling"] == "strong" and d["config"]["frames_in_flight"] == 2
     assert d["config"]["frames_per_gather"] == 4   # 6 timed frames = one full batch + a partial one
+    g = np.load(dump + ".scene.npz")
+    osc = orc.Scene(g["nodes"], g["tri_verts"], g["instance_offsets"], int(g["tlas_start"]))
+    want, _ = osc.trace_primary(orc.view_from_bytes(g["view"].tobytes()), int(g["width"]), int(g["height"]), sem=3)
+    from tray_racing_amd import dist as D
+    import torch
+    assert_hits_equal(D.int64_to_hits(torch.from_numpy(np.load(dump))), want, "2-rank bench frame")
 
 
 def test_scheduling_variants_and_streams_do_not_change_results(trx, orc):
