@@ -115,3 +115,23 @@ def test_no_cpu_fallback_without_a_device(trx, has_gpu):
     with pytest.raises(trx.TrxError) as e:
         trx.Scene(flat)
     assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def build_c_consumer(name, tmp_path):
+    """gcc -std=c11 -pedantic: include/trx.h must be valid C and libtrx.so linkable from C."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / name)
+    libdir = os.path.join(root, "tray_racing_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", name + ".c"), "-o", exe, "-L", libdir, "-ltrx",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_header_is_plain_c_and_the_library_links_from_c(trx, tmp_path):
+    import subprocess
+    exe = build_c_consumer("host_only", tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    assert out.stdout.startswith("objects 5 triangles")

@@ -493,6 +493,29 @@ def test_full_size_shard_union_and_counter_sums(trx, orc):
     sc.close()
 
 
+def test_c_program_over_the_abi_matches_the_oracle(trx, orc, tmp_path):
+    """tests/c_abi/trace_frame.c: a plain C11 host (no Python, no torch) drives scene generation, the build,
+    the upload and one primary + AO frame through include/trx.h; its frame checksums equal the oracle's."""
+    import subprocess
+    from test_abi import build_c_consumer
+    exe = build_c_consumer("trace_frame", tmp_path)
+    w, h = 160, 96
+    out = subprocess.run([exe, "kitchen", "20000", str(w), str(h), "0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got_p, got_a, n_nodes = out.stdout.split()
+    flat, _view, osc, ov = make_scene(trx, orc, "kitchen", 20000, w, h)
+    assert int(n_nodes) == flat.n_nodes
+    prim, _ = osc.trace_primary(ov, w, h, sem=0)
+    ao, _ = osc.trace_ao(ov, w, h, prim, sem=0, frame=5, ao_eps=0.01)
+
+    def fnv(a):
+        hsh = 1469598103934665603
+        for b in np.ascontiguousarray(a).view(np.uint8).tobytes():
+            hsh = ((hsh ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%016x" % hsh
+    assert (got_p, got_a) == (fnv(prim), fnv(ao))
+
+
 def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path):
     """bench.py's N > 1 path end to end on one GPU: two ranks (gloo, shard gather staged through
     host memory) trace their tile shards on device 0 in batches; the frame rank 0 ends up with is
