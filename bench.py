@@ -262,7 +262,7 @@ def main():
                 "workload": "%s-class procedural stand-in, %d tris, %d CWBVH nodes, primary rays %dx%d "
                             "(BASELINE.json configs[2])" % (args.scene, flat.n_tris, flat.n_nodes, w, h),
                 "semantics": "TRX_SEM_CPU" if args.sem == 3 else "bits=%d" % args.sem,
-                "builder": "binned-SAH BVH2 -> SAH-optimal BVH8 collapse (stands in for obvhs ploc_cwbvh)",
+                "builder": "binned-SAH BVH2 -> reinsertion pass -> SAH-optimal BVH8 collapse (stands in for obvhs ploc_cwbvh)",
                 "parallelism": ("one GPU owns every 8x8 tile" if world == 1 else
                                 "8x8 tiles round-robin over %d ranks; hit shards (8 B/ray) all-gathered in place, %d frames "
                                 "per collective, and de-interleaved to row-major frames on every rank" % (world, F)),
