@@ -331,6 +331,10 @@ int trx_set_build_costs(float traversal_cost, float prim_cost);
  * (src/main.rs:113-118).  batch_ratio 0 switches the pass off.  Default 0.02 x 4 iterations.  Applied to
  * triangle builds only: over instance boxes (TLAS) it measured worse and is skipped. */
 int trx_set_build_reinsertion(float batch_ratio, int iterations);
+/* The reference's --preset names (src/main.rs:125-131,563-570: "fastest_build" ... "very_slow_build", "" =
+ * defaults) mapped onto this builder's knobs — SAH bins, exact-sweep threshold, reinsertion ratio and
+ * iterations; "medium_build" is the default setting.  Process-wide, for subsequent builds. */
+int trx_set_build_preset(const char *name);
 void trx_bvh_destroy(trx_bvh *bvh);
 uint64_t trx_bvh_node_count(const trx_bvh *bvh);
 uint64_t trx_bvh_prim_count(const trx_bvh *bvh);

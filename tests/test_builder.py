@@ -135,3 +135,27 @@ def test_reinsertion_rejects_bad_arguments(trx):
     assert lib.trx_set_build_reinsertion(1.5, 2) != 0
     assert lib.trx_set_build_reinsertion(0.1, -1) != 0
     assert lib.trx_set_build_reinsertion(0.02, 4) == 0
+
+
+def test_build_presets(trx, orc):
+    """trx_set_build_preset: the reference's --preset names (src/main.rs:125-131,563-570) select build-time /
+    quality settings of this builder; every one must give a sound tree that answers like brute force."""
+    verts, counts = trx.gen_scene("kitchen", 12000, 2)
+    eye, look, fov = trx.scene_camera("kitchen")
+    ov = orc.view_from_bytes(trx.view_from_camera(eye, look, fov, 32, 20))
+    work = {}
+    try:
+        for preset in ("fastest_build", "very_fast_build", "fast_build", "medium_build", "slow_build", "very_slow_build"):
+            flat = trx.flat_build(verts, counts, preset=preset)
+            osc = orc.Scene.from_flat(flat)
+            assert osc.validate()[0] == 0, preset
+            got, st = osc.trace_primary(ov, 32, 20, sem=3)
+            assert (got["t"] == osc.brute_primary(ov, 32, 20, sem=3)["t"]).all(), preset
+            work[preset] = st.n_node
+        default = trx.flat_build(verts, counts, preset="")
+        assert (default.nodes == trx.flat_build(verts, counts, preset="medium_build").nodes).all()
+        with pytest.raises(trx.TrxError, match="unknown preset"):
+            trx.flat_build(verts, counts, preset="warp_speed")
+    finally:
+        trx.flat_build(verts[:1], preset="")
+    assert work["very_slow_build"] < work["fastest_build"]   # the slow end buys fewer node visits

@@ -29,6 +29,9 @@ def test_cli_rejects_what_the_reference_rejects():
     for flag, msg in (("--cpu", "no CPU traversal"), ("--hardware", "ray-tracing hardware")):
         r = run("-i", "standin:cornell", flag)
         assert r.returncode != 0 and msg in r.stderr
+    r = run("-i", "standin:cornell", "--preset", "warp_speed", "--dry-run")
+    assert r.returncode != 0 and "unknown preset" in r.stderr
+    assert run("-i", "standin:cornell", "--preset", "very_fast_build", "--dry-run", "--passes", "1").returncode == 0
     assert run().returncode != 0
 
 

@@ -36,6 +36,8 @@ uint32_t g_variant = 0;
 float g_traversal_cost = 1.0f, g_prim_cost = 0.3f;
 float g_reinsert_ratio = 0.02f;
 int g_reinsert_iters = 4;
+int g_sah_bins = 32;
+uint32_t g_sweep_max = 48;
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -979,6 +981,8 @@ int trx_bvh_build_tris(const float *verts, uint64_t n, uint32_t max_prims, int t
     bp.prim_cost = g_prim_cost;
     bp.reinsertion_batch_ratio = g_reinsert_ratio;
     bp.reinsertion_iterations = g_reinsert_iters;
+    bp.sah_bins = g_sah_bins;
+    bp.sweep_max = g_sweep_max;
     try {
         build_cwbvh_from_tris(verts, n, bp, b->bvh);
     } catch (const std::exception &) {
@@ -1002,6 +1006,8 @@ int trx_bvh_build_aabbs(const float *aabbs, uint64_t n, uint32_t max_prims, int 
     bp.prim_cost = g_prim_cost;
     bp.reinsertion_batch_ratio = 0.f; // boxes of instances: see trx_flat_build
     bp.reinsertion_iterations = g_reinsert_iters;
+    bp.sah_bins = g_sah_bins;
+    bp.sweep_max = g_sweep_max;
     try {
         build_cwbvh_from_aabbs((const Aabb *)aabbs, n, bp, b->bvh);
     } catch (const std::exception &) {
@@ -1017,6 +1023,27 @@ int trx_set_build_costs(float traversal_cost, float prim_cost) {
     g_traversal_cost = traversal_cost;
     g_prim_cost = prim_cost;
     return TRX_OK;
+}
+
+int trx_set_build_preset(const char *name) {
+    // {bins, sweep, reinsertion ratio, iterations}: build time against tree quality, like the obvhs presets
+    struct Preset { const char *name; int bins; uint32_t sweep; float ratio; int iters; };
+    static const Preset presets[] = {
+        {"fastest_build", 8, 0, 0.0f, 0},     {"very_fast_build", 16, 8, 0.01f, 1}, {"fast_build", 16, 24, 0.02f, 2},
+        {"medium_build", 32, 48, 0.02f, 4},   {"slow_build", 32, 64, 0.05f, 6},     {"very_slow_build", 32, 64, 0.15f, 8},
+        {"", 32, 48, 0.02f, 4},
+    };
+    if (!name) return fail(TRX_ERR_INVALID, "preset is null");
+    for (const Preset &p : presets) {
+        if (std::strcmp(name, p.name) == 0) {
+            g_sah_bins = p.bins;
+            g_sweep_max = p.sweep;
+            g_reinsert_ratio = p.ratio;
+            g_reinsert_iters = p.iters;
+            return TRX_OK;
+        }
+    }
+    return fail(TRX_ERR_INVALID, "unknown preset '%s'", name);
 }
 
 int trx_set_build_reinsertion(float batch_ratio, int iterations) {
@@ -1055,6 +1082,8 @@ int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32
     bp.prim_cost = g_prim_cost;
     bp.reinsertion_batch_ratio = g_reinsert_ratio;
     bp.reinsertion_iterations = g_reinsert_iters;
+    bp.sah_bins = g_sah_bins;
+    bp.sweep_max = g_sweep_max;
     try {
         // without --tlas everything is flattened into the first object (src/main.rs:300-308)
         std::vector<uint64_t> counts;

@@ -62,15 +62,16 @@ struct Bvh2Builder {
     BigVec<uint32_t> idx;
     BigVec<Node2> nodes;
 
-    static constexpr int kBins = 32;
-
-    static constexpr uint32_t kSweepMax = 48;
+    static constexpr int kMaxBins = 32;
+    static constexpr uint32_t kMaxSweep = 64;
+    int kBins = 32;          // SAH bins per axis (<= kMaxBins)
+    uint32_t kSweepMax = 48; // ranges up to this size get the exact sweep (<= kMaxSweep)
 
     // Exact SAH for small ranges: for every axis sort by centroid and sweep all n-1 splits.
     uint32_t sweep_split(uint32_t begin, uint32_t end, const Aabb &bounds) {
         const uint32_t n = end - begin;
-        uint32_t order[3][kSweepMax];
-        float right_area[kSweepMax];
+        uint32_t order[3][kMaxSweep];
+        float right_area[kMaxSweep];
         float best_cost = kInf;
         int best_axis = -1;
         uint32_t best_k = 0;
@@ -121,8 +122,8 @@ struct Bvh2Builder {
             float lo = cb.mn[axis], hi = cb.mx[axis];
             if (!(hi > lo)) continue;
             float scale = (float)kBins / (hi - lo);
-            Aabb bb[kBins];
-            uint32_t bc[kBins];
+            Aabb bb[kMaxBins];
+            uint32_t bc[kMaxBins];
             for (int b = 0; b < kBins; b++) {
                 bb[b] = empty_box();
                 bc[b] = 0;
@@ -134,8 +135,8 @@ struct Bvh2Builder {
                 grow(bb[b], boxes[p]);
                 bc[b]++;
             }
-            float right_area[kBins];
-            uint32_t right_cnt[kBins];
+            float right_area[kMaxBins];
+            uint32_t right_cnt[kMaxBins];
             Aabb acc = empty_box();
             uint32_t cnt = 0;
             for (int b = kBins - 1; b > 0; b--) {
@@ -712,6 +713,8 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
     Bvh2Builder b2;
     b2.boxes = boxes;
     b2.cen.assign(centroids, centroids + 3 * n);
+    b2.kBins = std::max(2, std::min(params.sah_bins, (int)Bvh2Builder::kMaxBins));
+    b2.kSweepMax = std::min<uint32_t>(params.sweep_max, Bvh2Builder::kMaxSweep);
     const bool verbose = getenv("TRX_BUILD_VERBOSE") != nullptr && n > 100000;
     auto lap = [&](const char *what) {
         if (verbose)

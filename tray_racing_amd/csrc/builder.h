@@ -30,6 +30,8 @@ struct BuildParams {
     // per iteration (obvhs `reinsertion_batch_ratio`, src/main.rs:113-118); 0 = off
     float reinsertion_batch_ratio = 0.02f;
     int reinsertion_iterations = 4;
+    int sah_bins = 32;       // BVH2: SAH bins per axis (2..32)
+    uint32_t sweep_max = 48; // BVH2: ranges of at most this many primitives get the exact SAH sweep (<= 64)
     int threads = 0; // <= 0: hardware_concurrency
 };
 

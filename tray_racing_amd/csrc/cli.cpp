@@ -248,6 +248,7 @@ Stats render_input(const Options &o, const std::string &input) {
     const bool tlas = o.tlas && !o.flatten_blas; // src/main.rs:300-308
     if (o.verbose) std::printf("%u objects \"%s\"\ntriangles %llu\n", n_objects, st.name.c_str(), (unsigned long long)n_tris);
     check(trx_set_build_costs(o.collapse_traversal_cost, 0.3f), "build costs");
+    check(trx_set_build_preset(o.preset.c_str()), "preset"); // src/main.rs:563-570; "" = the flags below
     if (o.reinsertion_batch_ratio >= 0.f) {
         // obvhs: 0..1 is the candidate ratio of one pass, above 1 the whole set is evaluated several times
         float r = o.reinsertion_batch_ratio;

@@ -95,10 +95,12 @@ class FlatScene:
 
 
 def flat_build(verts, object_counts=None, use_tlas=False, max_prims_per_leaf=3, threads=0, traversal_cost=None,
-               prim_cost=None, reinsertion=None):
+               prim_cost=None, reinsertion=None, preset=None):
     """`reinsertion`: None keeps the process-wide setting; a float is the batch ratio (2 iterations),
     a (ratio, iterations) pair sets both (trx_set_build_reinsertion)."""
     lib = L.load()
+    if preset is not None:   # the reference's --preset names (trx_set_build_preset); "" = defaults
+        L.check(lib.trx_set_build_preset(preset.encode()))
     if traversal_cost is not None or prim_cost is not None:
         L.check(lib.trx_set_build_costs(traversal_cost or 1.0, prim_cost or 0.3))
     if reinsertion is not None:
