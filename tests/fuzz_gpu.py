@@ -1,0 +1,129 @@
+"""Randomised differential test: the HIP path against the oracle, bit for bit, over random scenes,
+cameras, image sizes, semantics, triangle formats, TLAS on/off, shards, batch launches and all three
+query kinds (primary, AO, explicit rays).  Test infrastructure (it drives the oracle); not collected by
+pytest — tests/test_gpu_parity.py runs a short fixed-seed slice of it.
+
+    python tests/fuzz_gpu.py --minutes 10 [--seed 1]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+SCENES = ("cornell", "kitchen", "bistro", "hairball", "san_miguel", "soup", "demoscene")
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def differs(got, want):
+    bt = np.flatnonzero(bits(got["t"]) != bits(want["t"]))
+    bp = np.flatnonzero(got["prim"] != want["prim"])
+    return (bt.size, bp.size, bt[:3].tolist(), bp[:3].tolist()) if bt.size or bp.size else None
+
+
+def one_case(T, O, rng, case):
+    import torch
+    from helpers import random_rays
+    from tray_racing_amd import dist as D
+    name = SCENES[int(rng.integers(len(SCENES)))]
+    n = int(rng.choice([1, 2, 3, 17, 300, 2500, 20000, 90000]))
+    if name in ("cornell",):
+        n = 0
+    seed = int(rng.integers(1, 1 << 30))
+    tlas = bool(rng.integers(2))
+    sem = int(rng.integers(8))
+    fmt = int(rng.choice([T.TRI_VERTS_36, T.TRI_VERTS_36, T.TRI_EDGES_36, T.TRI_F16_24]))
+    w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+    verts, counts = T.gen_scene(name, n, seed)
+    leaf = int(rng.integers(1, 4))
+    flat = T.flat_build(verts, counts, use_tlas=tlas, max_prims_per_leaf=leaf)
+    eye, look, fov = T.scene_camera(name)
+    pts = flat.tri_verts.reshape(-1, 3)
+    lo, hi = pts.min(0), pts.max(0)
+    if rng.integers(3):
+        eye = tuple((lo + rng.uniform(-0.2, 1.2, 3) * (hi - lo + 1e-3)).tolist())
+        look = tuple((lo + rng.uniform(0, 1, 3) * (hi - lo + 1e-3)).tolist())
+        fov = float(rng.uniform(20, 120))
+    view = T.view_from_camera(eye, look, fov, w, h)
+    ov = O.view_from_bytes(view)
+    desc = "case %d: %s n=%d seed=%d tlas=%s sem=%d fmt=%d %dx%d leaf<=%s" % (case, name, n, seed, tlas, sem, fmt, w, h, leaf)
+    if fmt == T.TRI_F16_24:
+        packed = T.pack_tris_f16(flat.tri_verts)
+        sc = T.Scene(flat, tri_format=fmt, tri_bytes=packed)
+        osc = O.Scene(flat.nodes, None, flat.instance_offsets, int(flat.tlas_start), tri_f16=packed)
+    elif fmt == T.TRI_EDGES_36:   # {v0, e1, e2} handed over as the oracle derives them
+        osc = O.Scene.from_flat(flat)
+        sc = T.Scene(flat, tri_format=fmt, tri_bytes=osc.tris.copy())
+    else:
+        sc = T.Scene(flat)
+        osc = O.Scene.from_flat(flat)
+    bad = []
+    kind = int(rng.integers(4))
+    try:
+        if kind == 0:      # primary + AO, host entry point
+            frame, eps = int(rng.integers(0, 5000)), float(rng.choice([0.01, 0.0001]))
+            prim, ao, _ = sc.trace_primary_ao(view, w, h, sem=sem, frame=frame, ao_eps=eps)
+            wp, _ = osc.trace_primary(ov, w, h, sem=sem)
+            wa, _ = osc.trace_ao(ov, w, h, wp, sem=sem, frame=frame, ao_eps=eps)
+            bad += [("primary", differs(prim, wp)), ("ao", differs(ao, wa))]
+        elif kind == 1:    # explicit rays
+            rays = random_rays(T, flat, int(rng.integers(1, 30000)), seed)
+            got, _ = sc.trace_rays(rays, sem=sem)
+            bad += [("rays", differs(got, osc.trace_rays(rays, sem=sem)[0]))]
+        elif kind == 2:    # tile shards, compact layout, gathered by hand
+            world = int(rng.integers(2, 9))
+            fg = D.FrameGather(w, h, 0, world, "cuda")
+            for r in range(world):
+                blk = fg.flat[r * fg.records:(r + 1) * fg.records]
+                sc.trace_primary_dev(view, w, h, blk.data_ptr(), sem=sem, shard=(r, world, 1))
+            sc.check()
+            bad += [("shards/%d" % world, differs(D.int64_to_hits(fg.assemble()), osc.trace_primary(ov, w, h, sem=sem)[0]))]
+        else:              # several frames in one launch, different cameras
+            m = int(rng.integers(2, 9))
+            views = [T.view_from_camera(tuple((np.array(eye) + 0.05 * f * (hi - lo)).tolist()), look, fov, w, h) for f in range(m)]
+            out = torch.empty(m * w * h, dtype=torch.int64, device="cuda")
+            for _ in range(2):
+                sc.trace_primary_batch_dev(views, w, h, out.data_ptr(), w * h, sem=sem)
+            sc.check()
+            for f in range(m):
+                want, _ = osc.trace_primary(O.view_from_bytes(views[f]), w, h, sem=sem)
+                bad += [("batch frame %d/%d" % (f, m), differs(D.int64_to_hits(out[f * w * h:(f + 1) * w * h]), want))]
+    finally:
+        sc.close()
+    bad = [(k, v) for k, v in bad if v]
+    return desc + " kind=%d" % kind, bad
+
+
+def run(minutes=1.0, seed=1, max_cases=1 << 30, verbose=True):
+    import tray_racing_amd as T
+    from oracle import binding as O
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + 60.0 * minutes
+    case, failures = 0, []
+    while time.time() < t_end and case < max_cases:
+        desc, bad = one_case(T, O, rng, case)
+        if bad:
+            failures.append((desc, bad))
+            print("MISMATCH", desc, bad, flush=True)
+        elif verbose and case % 20 == 0:
+            print("ok  ", desc, flush=True)
+        case += 1
+    print("%d cases, %d with mismatches" % (case, len(failures)), flush=True)
+    return case, failures
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=1.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    _, fails = run(a.minutes, a.seed)
+    sys.exit(1 if fails else 0)

@@ -516,6 +516,15 @@ def test_c_program_over_the_abi_matches_the_oracle(trx, orc, tmp_path):
     assert (got_p, got_a) == (fnv(prim), fnv(ao))
 
 
+def test_fixed_seed_slice_of_the_fuzzer(trx, orc):
+    """tests/fuzz_gpu.py: random scenes, cameras, sizes, semantics, triangle formats, TLAS, shards, batch launches
+    and query kinds against the oracle, bit for bit; a fixed-seed slice here, `python tests/fuzz_gpu.py --minutes N`
+    for longer runs."""
+    import fuzz_gpu
+    cases, failures = fuzz_gpu.run(minutes=3.0, seed=20260, max_cases=40, verbose=False)
+    assert cases == 40 and not failures, failures[:3]
+
+
 def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path):
     """bench.py's N > 1 path end to end on one GPU: two ranks (gloo, shard gather staged through
     host memory) trace their tile shards on device 0 in batches; the frame rank 0 ends up with is
