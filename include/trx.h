@@ -6,7 +6,9 @@
  * Moeller-Trumbore triangle tests, for primary and AO rays.
  *
  * Every entry point names the reference interface it replaces (paths relative
- * to the tray_racing checkout).  Plain pointers and sizes only; no C++ or
+ * to the tray_racing checkout; `query.hlsl` / `query_tlas.hlsl` are short for
+ * src/rt_gpu/rt_gpu_software_query.hlsl / rt_gpu_software_query_tlas.hlsl, other
+ * bare shader and .rs names live under src/rt_gpu/ or src/rt_cpu/).  Plain pointers and sizes only; no C++ or
  * torch types cross this boundary.  All functions return 0 on success or a
  * negative trx_status; the message is available from trx_last_error()
  * (thread-local).  Nothing here aborts: the Rust shim `expect()`s on the
