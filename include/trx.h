@@ -248,6 +248,13 @@ int trx_trace_ao_dev(trx_scene *scene, const trx_view *view, uint32_t width,
 int trx_trace_rays_dev(trx_scene *scene, const trx_ray *d_rays, uint64_t n_rays,
                        uint32_t semantics, trx_hit *d_hits, void *stream);
 
+/* Any-hit query — the reference's `intersects_bl_bvh` (query.hlsl:440-445; "Actual AO could use a faster
+ * anyhit query", src/rt_cpu/rt_cpu.rs:78-79): one byte per ray, 1 if some triangle is hit inside
+ * [tmin, tmax].  The traversal stops at the first accepted hit; until then it IS the closest-hit walk, so the
+ * answer equals `trx_trace_rays*`'s hit / no hit exactly. */
+int trx_trace_occluded_dev(trx_scene *scene, const trx_ray *d_rays, uint64_t n_rays,
+                           uint32_t semantics, uint8_t *d_flags, void *stream);
+
 /* Counting variant (PROFILE_RT): same traversal, also accumulates trx_stats.
  * Synchronous; d_hits may be NULL. */
 int trx_count_primary(trx_scene *scene, const trx_view *view, uint32_t width,
@@ -280,6 +287,9 @@ int trx_trace_primary_ao(trx_scene *scene, const trx_view *view, uint32_t width,
                          trx_hit *out_primary, trx_hit *out_ao, float *out_ms);
 int trx_trace_rays(trx_scene *scene, const trx_ray *rays, uint64_t n_rays,
                    uint32_t semantics, trx_hit *out_hits, float *out_ms);
+/* Host-buffer form of trx_trace_occluded_dev. */
+int trx_trace_occluded(trx_scene *scene, const trx_ray *rays, uint64_t n_rays, uint32_t semantics,
+                       uint8_t *out_flags, float *out_ms);
 /* Single-ray Traversable::traverse; a batch of one on the device. */
 int trx_traverse1(trx_scene *scene, const trx_ray *ray, uint32_t semantics,
                   trx_rayhit *out);

@@ -77,7 +77,11 @@ def one_case(T, O, rng, case):
         elif kind == 1:    # explicit rays
             rays = random_rays(T, flat, int(rng.integers(1, 30000)), seed)
             got, _ = sc.trace_rays(rays, sem=sem)
-            bad += [("rays", differs(got, osc.trace_rays(rays, sem=sem)[0]))]
+            want = osc.trace_rays(rays, sem=sem)[0]
+            bad += [("rays", differs(got, want))]
+            occ = sc.trace_occluded(rays, sem=sem)[0].astype(bool)   # any-hit: same hit / no hit
+            n_occ = int((occ != (want["prim"] != 0xffffffff)).sum())
+            bad += [("occluded", (n_occ,) if n_occ else None)]
         elif kind == 2:    # tile shards, compact layout, gathered by hand
             world = int(rng.integers(2, 9))
             fg = D.FrameGather(w, h, 0, world, "cuda")

@@ -252,6 +252,32 @@ def test_degenerate_triangles_and_ray_ranges(trx, orc):
     sc.close()
 
 
+def test_any_hit_query_equals_closest_hit_occupancy(trx, orc):
+    """trx_trace_occluded (intersects_bl_bvh, query.hlsl:440-445): stops at the first accepted triangle, and must
+    say exactly what the closest-hit query says about hit / no hit — for ranged rays, every semantics, TLAS or not."""
+    import torch
+    for name, n, tlas in (("kitchen", 30000, False), ("bistro", 60000, True), ("hairball", 50000, False)):
+        flat, _view, osc, _ov = make_scene(trx, orc, name, n, 32, 32, tlas=tlas)
+        sc = trx.Scene(flat)
+        rays = random_rays(trx, flat, 40000, 11)
+        for sem in (0, 3, 5, 6):
+            want = osc.trace_rays(rays, sem=sem)[0]["prim"] != trx.MISS_PRIM
+            flags, ms = sc.trace_occluded(rays, sem=sem)
+            assert ms > 0 and set(np.unique(flags)) <= {0, 1}
+            assert (flags.astype(bool) == want).all(), (name, sem, int((flags.astype(bool) != want).sum()))
+            assert 0.05 < want.mean() < 0.99
+        d_rays = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+        d_flags = torch.full((rays.shape[0] + 8,), 7, dtype=torch.uint8, device="cuda")
+        sc.trace_occluded_dev(d_rays.data_ptr(), rays.shape[0], d_flags.data_ptr(), sem=3)
+        sc.check()
+        assert (d_flags[:rays.shape[0]].cpu().numpy() == flags_for(sc, rays, 3)).all() and (d_flags[rays.shape[0]:] == 7).all()
+        sc.close()
+
+
+def flags_for(sc, rays, sem):
+    return sc.trace_occluded(rays, sem=sem)[0]
+
+
 def test_stack_spill_to_hbm_and_overflow_detection(trx, orc):
     """A hand-made tree drives the per-lane stack past the LDS part (12 entries) into the
     HBM spill; past 64 entries the kernel must flag the ray instead of corrupting memory."""

@@ -648,14 +648,15 @@ int trx_trace_ao_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h,
 }
 
 static int trace_rays_impl(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, trx_hit *d_hits,
-                           hipStream_t stream, bool count, SlotCounters **ctr) {
+                           hipStream_t stream, bool count, SlotCounters **ctr, bool any_hit = false) {
     // the work queue is 32-bit: split very large batches
     const uint64_t chunk = 1ull << 30;
     for (uint64_t off = 0; off < n; off += chunk) {
         TraceParams p;
         std::memset(&p, 0, sizeof(p));
         p.rays = d_rays + off;
-        p.out = d_hits + off;
+        p.out = any_hit ? reinterpret_cast<trx_hit *>(reinterpret_cast<uint8_t *>(d_hits) + off) : d_hits + off;
+        p.any_hit = any_hit ? 1u : 0u;
         p.n_items = (uint32_t)std::min(chunk, n - off);
         int rc = enqueue(s, p, kModeRays, sem, count, stream, ctr);
         if (rc) return rc;
@@ -667,6 +668,13 @@ int trx_trace_rays_dev(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t
     if (!s || (n && (!d_rays || !d_hits))) return fail(TRX_ERR_INVALID, "null argument");
     if (n == 0) return TRX_OK;
     return trace_rays_impl(s, d_rays, n, sem, d_hits, (hipStream_t)stream, false, nullptr);
+}
+
+int trx_trace_occluded_dev(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, uint8_t *d_flags, void *stream) {
+    if (!s || (n && (!d_rays || !d_flags))) return fail(TRX_ERR_INVALID, "null argument");
+    if (n == 0) return TRX_OK;
+    return trace_rays_impl(s, d_rays, n, sem, reinterpret_cast<trx_hit *>(d_flags), (hipStream_t)stream, false, nullptr,
+                           true);
 }
 
 static int finish_count(trx_scene *s, SlotCounters *ctr, trx_stats *stats) {
@@ -826,6 +834,24 @@ int trx_trace_rays(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t sem, 
     HIP_TRY(hipEventSynchronize(s->ev1));
     if (out_ms) HIP_TRY(hipEventElapsedTime(out_ms, s->ev0, s->ev1));
     if (out_hits) HIP_TRY(hipMemcpy(out_hits, s->d_scratch_a, n * sizeof(trx_hit), hipMemcpyDeviceToHost));
+    return trx_scene_check(s, nullptr);
+}
+
+int trx_trace_occluded(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t sem, uint8_t *out_flags, float *out_ms) {
+    if (!s || (n && !rays)) return fail(TRX_ERR_INVALID, "null argument");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu);
+    if (n == 0) return TRX_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = ensure_scratch(s, n, n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(s->d_scratch_rays, rays, n * sizeof(trx_ray), hipMemcpyHostToDevice));
+    HIP_TRY(hipEventRecord(s->ev0, nullptr));
+    rc = trx_trace_occluded_dev(s, s->d_scratch_rays, n, sem, reinterpret_cast<uint8_t *>(s->d_scratch_a), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s->ev1, nullptr));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    if (out_ms) HIP_TRY(hipEventElapsedTime(out_ms, s->ev0, s->ev1));
+    if (out_flags) HIP_TRY(hipMemcpy(out_flags, s->d_scratch_a, n, hipMemcpyDeviceToHost));
     return trx_scene_check(s, nullptr);
 }
 

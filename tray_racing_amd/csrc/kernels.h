@@ -87,6 +87,7 @@ struct TraceParams {
     unsigned long long *wave_times;  // diagnostics: [2*wave] start, [2*wave+1] end (wall_clock64), or null
     // frames per launch (image modes): frame f = local_tile / tiles_per_frame uses views[f] and writes its
     // records at out + f * frame_stride; one launch then balances n_frames x the tiles
+    uint32_t any_hit;     // explicit rays only: stop at the first accepted hit, write one byte (0/1) per ray
     uint32_t n_frames, tiles_per_frame, frame_stride;
     ViewDev views[kMaxBatchFrames];
 };

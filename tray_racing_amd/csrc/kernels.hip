@@ -701,7 +701,18 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     overflow = true;
                     done = true;
                 }
-                if (done) {
+                // any-hit query (intersects_bl_bvh, query.hlsl:440-445): the first accepted triangle settles it.
+                // Until a hit is accepted the walk is the closest-hit walk, so hit / no hit is the same answer.
+                if (MODE == kModeRays && P.any_hit != 0u && prim != TRX_INVALID) done = true;
+                if (done && MODE == kModeRays && P.any_hit != 0u) {
+                    reinterpret_cast<uint8_t *>(P.out)[out_index] = prim != TRX_INVALID ? 1u : 0u;
+                    if (COUNT) {
+                        c_rays++;
+                        c_hits += prim != TRX_INVALID;
+                    }
+                    c_over += overflow ? 1u : 0u;
+                    has_ray = false;
+                } else if (done) {
                     trx_hit h;
                     h.t = prim != TRX_INVALID ? t : __builtin_inff();
                     h.prim = prim;

@@ -201,6 +201,14 @@ class Scene:
         L.check(self._lib.trx_trace_rays(self._h, _ptr(rays), rays.shape[0], sem, _ptr(hits), C.byref(ms)))
         return hits, ms.value
 
+    def trace_occluded(self, rays, sem=L.SEM_HLSL):
+        """intersects_bl_bvh (query.hlsl:440-445) for a batch: uint8 flags, 1 = something is hit."""
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        flags = np.empty(rays.shape[0], dtype=np.uint8)
+        ms = C.c_float()
+        L.check(self._lib.trx_trace_occluded(self._h, _ptr(rays), rays.shape[0], sem, _ptr(flags), C.byref(ms)))
+        return flags, ms.value
+
     def traverse(self, origin, direction, tmin=0.0, tmax=3.4028234663852886e38, sem=L.SEM_HLSL):
         """Traversable::traverse (traversable/src/lib.rs:17-21) for one ray."""
         ray = L.Ray((C.c_float * 3)(*origin), tmin, (C.c_float * 3)(*direction), tmax)
@@ -240,6 +248,10 @@ class Scene:
     def trace_rays_dev(self, d_rays, n, d_hits, sem=L.SEM_HLSL, stream=0):
         L.check(self._lib.trx_trace_rays_dev(self._h, C.c_void_p(d_rays), n, sem, C.c_void_p(d_hits),
                                              C.c_void_p(stream)))
+
+    def trace_occluded_dev(self, d_rays, n, d_flags, sem=L.SEM_HLSL, stream=0):
+        L.check(self._lib.trx_trace_occluded_dev(self._h, C.c_void_p(d_rays), n, sem, C.c_void_p(d_flags),
+                                                 C.c_void_p(stream)))
 
     def check(self, stream=0):
         L.check(self._lib.trx_scene_check(self._h, C.c_void_p(stream)))
