@@ -320,6 +320,10 @@ def main():
         gpu = D.int64_to_hits(frame)
         parity = bool((gpu["t"].view(np.uint32) == hits["t"].view(np.uint32)).all() and
                       (gpu["prim"] == hits["prim"]).all())
+        # the reference's own CPU figure is a whole frame: ray generation + primary + one AO ray per hit pixel +
+        # shading (src/rt_cpu/rt_cpu.rs:35-92,98,113); two frames of that, with the GPU's primary + AO frame beside it
+        frame_s = min(osc.render_frame(ov, w, h, sem=args.sem, frame=f, ao_eps=0.01, threads=cores) for f in range(2))
+        gpu_frame_ms = min(scene.trace_primary_ao(view, w, h, sem=args.sem, frame=f, ao_eps=0.01)[2] for f in range(4))
         out["cpu_baseline"] = {
             "value": round(n_rays_total * n_frames / secs / 1e6, 3),
             "unit": "Mrays/s",
@@ -327,6 +331,8 @@ def main():
             "kind": "port",
             "sample": "%d full %dx%d frame(s) of the same workload, %.1f s, OpenMP over 8x8 tiles" % (
                 n_frames, w, h, secs),
+            "reference_style_frame_ms": round(frame_s * 1e3, 2),       # primary + AO + shade, wall clock
+            "gpu_primary_ao_frame_ms": round(gpu_frame_ms, 3),          # the same rays on the GPU (kernel time)
         }
         out["parity_vs_oracle_full_frame"] = parity
         if not parity:
