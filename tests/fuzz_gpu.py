@@ -29,19 +29,22 @@ def differs(got, want):
     return (bt.size, bp.size, bt[:3].tolist(), bp[:3].tolist()) if bt.size or bp.size else None
 
 
+BIG = False   # --big: few large cases (up to 1 M triangles, up to 1920x1080) instead of many small ones
+
+
 def one_case(T, O, rng, case):
     import torch
     from helpers import random_rays
     from tray_racing_amd import dist as D
     name = SCENES[int(rng.integers(len(SCENES)))]
-    n = int(rng.choice([1, 2, 3, 17, 300, 2500, 20000, 90000]))
+    n = int(rng.choice([200000, 500000, 1000000] if BIG else [1, 2, 3, 17, 300, 2500, 20000, 90000]))
     if name in ("cornell",):
         n = 0
     seed = int(rng.integers(1, 1 << 30))
     tlas = bool(rng.integers(2))
     sem = int(rng.integers(8))
     fmt = int(rng.choice([T.TRI_VERTS_36, T.TRI_VERTS_36, T.TRI_EDGES_36, T.TRI_F16_24]))
-    w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+    w, h = (int(rng.integers(300, 1921)), int(rng.integers(200, 1081))) if BIG else (int(rng.integers(1, 200)), int(rng.integers(1, 120)))
     verts, counts = T.gen_scene(name, n, seed)
     leaf = int(rng.integers(1, 4))
     flat = T.flat_build(verts, counts, use_tlas=tlas, max_prims_per_leaf=leaf)
@@ -75,7 +78,7 @@ def one_case(T, O, rng, case):
             wa, _ = osc.trace_ao(ov, w, h, wp, sem=sem, frame=frame, ao_eps=eps)
             bad += [("primary", differs(prim, wp)), ("ao", differs(ao, wa))]
         elif kind == 1:    # explicit rays
-            rays = random_rays(T, flat, int(rng.integers(1, 30000)), seed)
+            rays = random_rays(T, flat, int(rng.integers(1, 1500000 if BIG else 30000)), seed)
             got, _ = sc.trace_rays(rays, sem=sem)
             want = osc.trace_rays(rays, sem=sem)[0]
             bad += [("rays", differs(got, want))]
@@ -128,6 +131,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true")
     a = ap.parse_args()
+    BIG = a.big
     _, fails = run(a.minutes, a.seed)
     sys.exit(1 if fails else 0)
