@@ -17,9 +17,9 @@ KERNEL = "k_trace<0, false, 1, false>"
 
 
 def one(pattern):
-    f = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    f = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
     assert f, pattern
-    return f[0]
+    return f[-1]   # gpurun merges into gpurun_out/: older runs' files may still be there
 
 
 for name in ("default", "streams1"):
