@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--tris", type=int, default=0, help="0 = the scene's reference triangle count")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--preset", default="medium_build",
+                    help="builder preset (the reference's --preset names); BASELINE.json's config is medium_build")
     ap.add_argument("--sem", type=int, default=3, help="trx_semantics bits (3 = TRX_SEM_CPU)")
     ap.add_argument("--streams", type=int, default=0,
                     help="frames in flight; 0 = 4 for 1-2 GPUs, 8 beyond (a rank's shard shrinks with N, its "
@@ -121,7 +123,7 @@ def main():
     threads = max(1, usable_cores() // world)
     verts, counts = T.gen_scene(args.scene, args.tris, 1)
     t0 = time.time()
-    flat = T.flat_build(verts, counts, use_tlas=False, threads=threads)
+    flat = T.flat_build(verts, counts, use_tlas=False, threads=threads, preset=args.preset)
     build_s = time.time() - t0
     eye, look, fov = T.scene_camera(args.scene)
     view = T.view_from_camera(eye, look, fov, w, h)
@@ -270,7 +272,8 @@ def main():
                 "workload": "%s-class procedural stand-in, %d tris, %d CWBVH nodes, primary rays %dx%d "
                             "(BASELINE.json configs[2])" % (args.scene, flat.n_tris, flat.n_nodes, w, h),
                 "semantics": "TRX_SEM_CPU" if args.sem == 3 else "bits=%d" % args.sem,
-                "builder": "binned-SAH BVH2 -> reinsertion pass -> SAH-optimal BVH8 collapse (stands in for obvhs ploc_cwbvh)",
+                "builder": "binned-SAH BVH2 -> reinsertion pass -> SAH-optimal BVH8 collapse (stands in for obvhs "
+                           "ploc_cwbvh), preset %s" % args.preset,
                 "parallelism": ("one GPU owns every 8x8 tile" if world == 1 else
                                 "8x8 tiles round-robin over %d ranks; hit shards (8 B/ray) all-gathered in place, %d frames "
                                 "per collective, and de-interleaved to row-major frames on every rank" % (world, F)),

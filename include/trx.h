@@ -345,8 +345,15 @@ int trx_set_build_costs(float traversal_cost, float prim_cost);
 int trx_set_build_reinsertion(float batch_ratio, int iterations);
 /* The reference's --preset names (src/main.rs:125-131,563-570: "fastest_build" ... "very_slow_build", "" =
  * defaults) mapped onto this builder's knobs — SAH bins, exact-sweep threshold, reinsertion ratio and
- * iterations; "medium_build" is the default setting.  Process-wide, for subsequent builds. */
+ * iterations, pre-splitting (on from "slow_build"); "medium_build" is the default setting and "" restores it.
+ * Process-wide, for subsequent builds. */
 int trx_set_build_preset(const char *name);
+/* Pre-splitting (obvhs `pre_split`, the reference's --split, src/main.rs:572): triangles whose boxes are mostly
+ * empty are cut into several references with clipped, tighter boxes before the build, at most `extra_ratio` x
+ * n_tris extra references (0 = off, the reference's default).  Such triangles then appear more than once in
+ * the permuted triangle buffer of trx_flat (`tri_source` still names the input triangle).  Triangle builds
+ * only; process-wide, for subsequent builds. */
+int trx_set_build_split(float extra_ratio);
 void trx_bvh_destroy(trx_bvh *bvh);
 uint64_t trx_bvh_node_count(const trx_bvh *bvh);
 uint64_t trx_bvh_prim_count(const trx_bvh *bvh);
@@ -374,6 +381,8 @@ typedef struct trx_flat {
     uint32_t n_blas;
     double blas_build_s;
     double tlas_build_s;
+    float *tri_boxes;        /* n_tris * 6 floats (min xyz, max xyz): the box each triangle entry was built with —
+                              * its own, or the clipped part a pre-split reference covers (trx_set_build_split) */
 } trx_flat;
 int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects,
                    int use_tlas, uint32_t max_prims_per_leaf, int threads, trx_flat **out);

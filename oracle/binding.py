@@ -74,7 +74,7 @@ def load():
         "orc_render_frame": (C.c_double, [SP, VP, u32, u32, u32, u32, f, i, P]),
         "orc_brute_rays": (None, [P, u64, P, u64, u32, i, P]),
         "orc_brute_primary": (None, [P, u64, VP, u32, u32, u32, i, P]),
-        "orc_validate": (i, [SP, P, C.c_char_p, i]),
+        "orc_validate": (i, [SP, P, P, C.c_char_p, i]),
         "orc_count_primary_per_ray": (None, [SP, VP, u32, u32, u32, i, P, P]),
     }
     for name, (res, args) in sigs.items():
@@ -193,9 +193,12 @@ class Scene:
         ok = load().orc_intersect_tri(_ptr(o), _ptr(d), _ptr(tri), 0.0, _ptr(t), sem)
         return float(t[0]) if ok else None
 
-    def validate(self):
+    def validate(self, boxes=None):
+        """boxes: FlatScene.tri_boxes of a pre-split build (entries cover only part of their triangle)."""
         if self.verts is None:
             raise ValueError("validate needs vertex-format triangles")
         err = C.create_string_buffer(256)
-        rc = load().orc_validate(C.byref(self.c), _ptr(self.verts), err, 256)
+        if boxes is not None:
+            boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+        rc = load().orc_validate(C.byref(self.c), _ptr(self.verts), _ptr(boxes) if boxes is not None else None, err, 256)
         return rc, err.value.decode()

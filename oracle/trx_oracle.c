@@ -657,6 +657,7 @@ typedef struct {
 typedef struct {
     const orc_scene *s;
     const float *verts;
+    const float *boxes; /* optional: n_tris * 6, the box each primitive entry was built with */
     uint8_t *prim_seen;
     uint8_t *node_seen;
     char *err;
@@ -761,13 +762,21 @@ static boxd validate_node(vctx *c, uint32_t bvh_offset, uint32_t seg_end, uint32
                     }
                     if (c->prim_seen[prim]) vfail(c, "primitive %llu referenced twice%llu", prim, 0);
                     c->prim_seen[prim] = 1;
-                    const float *v = c->verts + 9 * prim;
-                    for (int a = 0; a < 3; a++)
+                    if (c->boxes) { /* pre-split builds: this entry stands for the part of its triangle inside its box */
+                        const float *b = c->boxes + 6 * prim;
                         for (int k = 0; k < 3; k++) {
-                            double x = v[3 * a + k];
-                            if (x < child.mn[k]) child.mn[k] = x;
-                            if (x > child.mx[k]) child.mx[k] = x;
+                            if (b[k] < child.mn[k]) child.mn[k] = b[k];
+                            if (b[3 + k] > child.mx[k]) child.mx[k] = b[3 + k];
                         }
+                    } else {
+                        const float *v = c->verts + 9 * prim;
+                        for (int a = 0; a < 3; a++)
+                            for (int k = 0; k < 3; k++) {
+                                double x = v[3 * a + k];
+                                if (x < child.mn[k]) child.mn[k] = x;
+                                if (x > child.mx[k]) child.mx[k] = x;
+                            }
+                    }
                 }
             }
         }
@@ -779,11 +788,12 @@ static boxd validate_node(vctx *c, uint32_t bvh_offset, uint32_t seg_end, uint32
     return total;
 }
 
-int orc_validate(const orc_scene *s, const float *verts, char *err, int err_len) {
+int orc_validate(const orc_scene *s, const float *verts, const float *boxes, char *err, int err_len) {
     vctx c;
     memset(&c, 0, sizeof(c));
     c.s = s;
     c.verts = verts;
+    c.boxes = boxes;
     c.err = err;
     c.err_len = err_len;
     c.prim_seen = (uint8_t *)calloc(s->n_tris + 1, 1);

@@ -127,7 +127,9 @@ void orc_brute_primary(const float *tris9, uint64_t n_tris, const orc_view *view
 /* structural check of a CWBVH against its triangles ("validate", src/cwbvh.rs:102-104).
  * verts: the permuted TRX_TRI_VERTS_36 triangles the nodes index.  Returns 0
  * when sound; otherwise a negative code and a message in err. */
-int orc_validate(const orc_scene *s, const float *verts, char *err, int err_len);
+/* boxes (optional, n_tris * 6 floats): per-primitive build boxes; given, leaf boxes must contain these instead of
+ * whole triangles (pre-split references cover part of a triangle) */
+int orc_validate(const orc_scene *s, const float *verts, const float *boxes, char *err, int err_len);
 
 #ifdef __cplusplus
 }

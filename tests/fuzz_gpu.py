@@ -47,7 +47,9 @@ def one_case(T, O, rng, case):
     w, h = (int(rng.integers(300, 1921)), int(rng.integers(200, 1081))) if BIG else (int(rng.integers(1, 200)), int(rng.integers(1, 120)))
     verts, counts = T.gen_scene(name, n, seed)
     leaf = int(rng.integers(1, 4))
-    flat = T.flat_build(verts, counts, use_tlas=tlas, max_prims_per_leaf=leaf)
+    split = float(rng.choice([0.0, 0.0, 0.3, 1.0]))
+    flat = T.flat_build(verts, counts, use_tlas=tlas, max_prims_per_leaf=leaf, split=split)
+    T.flat_build(verts[:1], split=0.0)
     eye, look, fov = T.scene_camera(name)
     pts = flat.tri_verts.reshape(-1, 3)
     lo, hi = pts.min(0), pts.max(0)
@@ -57,7 +59,7 @@ def one_case(T, O, rng, case):
         fov = float(rng.uniform(20, 120))
     view = T.view_from_camera(eye, look, fov, w, h)
     ov = O.view_from_bytes(view)
-    desc = "case %d: %s n=%d seed=%d tlas=%s sem=%d fmt=%d %dx%d leaf<=%s" % (case, name, n, seed, tlas, sem, fmt, w, h, leaf)
+    desc = "case %d: %s n=%d seed=%d tlas=%s sem=%d fmt=%d %dx%d leaf<=%s" % (case, name, n, seed, tlas, sem, fmt, w, h, leaf) + " split=%.1f" % split
     if fmt == T.TRI_F16_24:
         packed = T.pack_tris_f16(flat.tri_verts)
         sc = T.Scene(flat, tri_format=fmt, tri_bytes=packed)

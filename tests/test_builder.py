@@ -148,7 +148,7 @@ def test_build_presets(trx, orc):
         for preset in ("fastest_build", "very_fast_build", "fast_build", "medium_build", "slow_build", "very_slow_build"):
             flat = trx.flat_build(verts, counts, preset=preset)
             osc = orc.Scene.from_flat(flat)
-            assert osc.validate()[0] == 0, preset
+            assert osc.validate(boxes=flat.tri_boxes)[0] == 0, preset   # slow presets pre-split: entries are clipped
             got, st = osc.trace_primary(ov, 32, 20, sem=3)
             assert (got["t"] == osc.brute_primary(ov, 32, 20, sem=3)["t"]).all(), preset
             work[preset] = st.n_node
@@ -159,3 +159,47 @@ def test_build_presets(trx, orc):
     finally:
         trx.flat_build(verts[:1], preset="")
     assert work["very_slow_build"] < work["fastest_build"]   # the slow end buys fewer node visits
+
+
+def test_pre_split_references_cover_their_triangles(trx, orc):
+    """trx_set_build_split (obvhs pre_split, the reference's --split): big, mostly empty triangle boxes are cut
+    into clipped references.  Every reference box must lie inside its leaf box (validator), the references of a
+    triangle together must cover it (sampled), every triangle must still be there, and rays must see the same
+    geometry as brute force."""
+    verts, counts = trx.gen_scene("kitchen", 15000, 4)
+    try:
+        plain = trx.flat_build(verts, counts, split=0.0)
+        flat = trx.flat_build(verts, counts, split=0.5)
+        again = trx.flat_build(verts, counts, split=0.5, threads=1)
+    finally:
+        trx.flat_build(verts[:1], split=0.0)
+    n = verts.shape[0]
+    assert (flat.nodes == again.nodes).all() and (flat.tri_source == again.tri_source).all()
+    assert n < flat.n_tris <= int(1.5 * n) + 1 and plain.n_tris == n
+    assert set(flat.tri_source.tolist()) == set(range(n))
+    assert (flat.tri_verts == verts.reshape(-1, 9)[flat.tri_source]).all()      # entries repeat whole triangles
+    osc = orc.Scene.from_flat(flat)
+    assert osc.validate(boxes=flat.tri_boxes)[0] == 0
+    assert osc.validate()[0] != 0            # whole triangles no longer fit their leaf boxes: that is the point
+    # coverage: sample every split triangle, each sample must fall into one of its references' boxes
+    refs = {}
+    for k, src in enumerate(flat.tri_source.tolist()):
+        refs.setdefault(src, []).append(k)
+    split = [t for t, r in refs.items() if len(r) > 1]
+    assert len(split) > 100
+    g = np.array([(a, b, 1.0 - a - b) for a in np.linspace(0, 1, 9) for b in np.linspace(0, 1 - a, 9)], dtype=np.float64)
+    for t in split[:400]:
+        tri = verts.reshape(-1, 3, 3)[t].astype(np.float64)
+        pts = g @ tri
+        boxes = flat.tri_boxes[refs[t]].astype(np.float64)
+        inside = ((pts[:, None, :] >= boxes[None, :, 0:3] - 1e-9) & (pts[:, None, :] <= boxes[None, :, 3:6] + 1e-9)).all(2)
+        assert inside.any(1).all(), "triangle %d is not covered by its %d references" % (t, len(refs[t]))
+    # same geometry for rays: t as brute force finds it (up to the slab-rounding rays of any CWBVH), fewer tests
+    eye, look, fov = trx.scene_camera("kitchen")
+    ov = orc.view_from_bytes(trx.view_from_camera(eye, look, fov, 96, 54))
+    got, st = osc.trace_primary(ov, 96, 54, sem=3)
+    bf = osc.brute_primary(ov, 96, 54, sem=3)
+    differ = got["t"].view(np.uint32) != bf["t"].view(np.uint32)
+    assert differ.sum() <= 2 and (got["t"][differ] >= bf["t"][differ]).all()
+    _, st0 = orc.Scene.from_flat(plain).trace_primary(ov, 96, 54, sem=3)
+    assert st.n_tri < st0.n_tri

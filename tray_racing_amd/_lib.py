@@ -68,7 +68,7 @@ class Flat(C.Structure):
                 ("n_tris", C.c_uint64), ("instance_offsets", C.POINTER(C.c_uint32)), ("n_instances", C.c_uint32),
                 ("tlas_start", C.c_uint32), ("tri_source", C.POINTER(C.c_uint32)),
                 ("blas_tri_start", C.POINTER(C.c_uint32)), ("n_blas", C.c_uint32), ("blas_build_s", C.c_double),
-                ("tlas_build_s", C.c_double)]
+                ("tlas_build_s", C.c_double), ("tri_boxes", C.POINTER(C.c_float))]
 
 
 _P = C.c_void_p
@@ -111,6 +111,7 @@ SIGNATURES = {
     "trx_set_build_costs": (_i, [_f, _f]),
     "trx_set_build_reinsertion": (_i, [_f, _i]),
     "trx_set_build_preset": (_i, [C.c_char_p]),
+    "trx_set_build_split": (_i, [_f]),
     "trx_bvh_destroy": (None, [_P]),
     "trx_bvh_node_count": (_u64, [_P]),
     "trx_bvh_prim_count": (_u64, [_P]),

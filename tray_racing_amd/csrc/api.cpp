@@ -38,6 +38,7 @@ float g_reinsert_ratio = 0.02f;
 int g_reinsert_iters = 4;
 int g_sah_bins = 32;
 uint32_t g_sweep_max = 48;
+float g_pre_split = 0.0f;
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -1009,6 +1010,7 @@ int trx_bvh_build_tris(const float *verts, uint64_t n, uint32_t max_prims, int t
     bp.reinsertion_iterations = g_reinsert_iters;
     bp.sah_bins = g_sah_bins;
     bp.sweep_max = g_sweep_max;
+    bp.pre_split_ratio = g_pre_split;
     try {
         build_cwbvh_from_tris(verts, n, bp, b->bvh);
     } catch (const std::exception &) {
@@ -1034,6 +1036,7 @@ int trx_bvh_build_aabbs(const float *aabbs, uint64_t n, uint32_t max_prims, int 
     bp.reinsertion_iterations = g_reinsert_iters;
     bp.sah_bins = g_sah_bins;
     bp.sweep_max = g_sweep_max;
+    bp.pre_split_ratio = g_pre_split;
     try {
         build_cwbvh_from_aabbs((const Aabb *)aabbs, n, bp, b->bvh);
     } catch (const std::exception &) {
@@ -1051,13 +1054,20 @@ int trx_set_build_costs(float traversal_cost, float prim_cost) {
     return TRX_OK;
 }
 
+int trx_set_build_split(float extra_ratio) {
+    if (!(extra_ratio >= 0.f) || extra_ratio > 4.f) return fail(TRX_ERR_INVALID, "split: extra reference ratio in [0, 4]");
+    g_pre_split = extra_ratio;
+    return TRX_OK;
+}
+
 int trx_set_build_preset(const char *name) {
-    // {bins, sweep, reinsertion ratio, iterations}: build time against tree quality, like the obvhs presets
-    struct Preset { const char *name; int bins; uint32_t sweep; float ratio; int iters; };
+    // {bins, sweep, reinsertion ratio, iterations, pre-split}: build time against tree quality, like the obvhs
+    // presets (which switch pre_split on from slow_build upwards); "" restores the defaults
+    struct Preset { const char *name; int bins; uint32_t sweep; float ratio; int iters; float split; };
     static const Preset presets[] = {
-        {"fastest_build", 8, 0, 0.0f, 0},     {"very_fast_build", 16, 8, 0.01f, 1}, {"fast_build", 16, 24, 0.02f, 2},
-        {"medium_build", 32, 48, 0.02f, 4},   {"slow_build", 32, 64, 0.05f, 6},     {"very_slow_build", 32, 64, 0.15f, 8},
-        {"", 32, 48, 0.02f, 4},
+        {"fastest_build", 8, 0, 0.0f, 0, 0.0f},   {"very_fast_build", 16, 8, 0.01f, 1, 0.0f}, {"fast_build", 16, 24, 0.02f, 2, 0.0f},
+        {"medium_build", 32, 48, 0.02f, 4, 0.0f}, {"slow_build", 32, 64, 0.05f, 6, 0.3f},     {"very_slow_build", 32, 64, 0.15f, 8, 0.3f},
+        {"", 32, 48, 0.02f, 4, 0.0f},
     };
     if (!name) return fail(TRX_ERR_INVALID, "preset is null");
     for (const Preset &p : presets) {
@@ -1066,6 +1076,7 @@ int trx_set_build_preset(const char *name) {
             g_sweep_max = p.sweep;
             g_reinsert_ratio = p.ratio;
             g_reinsert_iters = p.iters;
+            g_pre_split = p.split;
             return TRX_OK;
         }
     }
@@ -1110,6 +1121,7 @@ int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32
     bp.reinsertion_iterations = g_reinsert_iters;
     bp.sah_bins = g_sah_bins;
     bp.sweep_max = g_sweep_max;
+    bp.pre_split_ratio = g_pre_split;
     try {
         // without --tlas everything is flattened into the first object (src/main.rs:300-308)
         std::vector<uint64_t> counts;
@@ -1123,7 +1135,7 @@ int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32
         std::vector<CwbvhNode> nodes;
         std::vector<uint32_t> blas_offset, blas_tri_start, tri_source;
         std::vector<Aabb> blas_aabb;
-        std::vector<float> tri_out;
+        std::vector<float> tri_out, box_out;
         tri_out.reserve(total * 9);
         tri_source.reserve(total);
         double blas_s = 0.0, tlas_s = 0.0;
@@ -1175,10 +1187,22 @@ int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32
             const uint32_t tri_offset = (uint32_t)(tri_out.size() / 9);
             blas_tri_start.push_back(tri_offset);
             // permute triangles into primitive_indices order (mod.rs:38-43)
-            for (uint32_t pi : bvh.primitive_indices) {
+            for (size_t k = 0; k < bvh.primitive_indices.size(); k++) {
+                const uint32_t pi = bvh.primitive_indices[k];
                 const float *v = verts + (first + pi) * 9;
                 tri_out.insert(tri_out.end(), v, v + 9);
                 tri_source.push_back((uint32_t)(first + pi));
+                // the box this entry was built with: the triangle's own, or its clipped part after pre-splitting
+                float bx[6];
+                if (!bvh.primitive_boxes.empty()) {
+                    for (int a = 0; a < 3; a++) { bx[a] = bvh.primitive_boxes[k].mn[a]; bx[3 + a] = bvh.primitive_boxes[k].mx[a]; }
+                } else {
+                    for (int a = 0; a < 3; a++) {
+                        bx[a] = std::min(v[a], std::min(v[3 + a], v[6 + a]));
+                        bx[3 + a] = std::max(v[a], std::max(v[3 + a], v[6 + a]));
+                    }
+                }
+                box_out.insert(box_out.end(), bx, bx + 6);
             }
             // global triangle buffer: offset primitive_base_idx (mod.rs:44-48)
             for (CwbvhNode &n : bvh.nodes) n.primitive_base_idx += tri_offset;
@@ -1223,11 +1247,12 @@ int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32
         f->instance_offsets = (uint32_t *)dup(inst.data(), inst.size() * 4);
         f->tlas_start = tlas_start;
         f->tri_source = (uint32_t *)dup(tri_source.data(), tri_source.size() * 4);
+        f->tri_boxes = (float *)dup(box_out.data(), box_out.size() * 4);
         f->n_blas = (uint32_t)counts.size();
         f->blas_tri_start = (uint32_t *)dup(blas_tri_start.data(), blas_tri_start.size() * 4);
         f->blas_build_s = blas_s;
         f->tlas_build_s = tlas_s;
-        if (!f->bvh_bytes || !f->tri_verts || !f->instance_offsets || !f->tri_source || !f->blas_tri_start) {
+        if (!f->bvh_bytes || !f->tri_verts || !f->instance_offsets || !f->tri_source || !f->blas_tri_start || !f->tri_boxes) {
             trx_flat_destroy(f);
             return fail(TRX_ERR_OOM, "host allocation failed");
         }
@@ -1245,6 +1270,7 @@ void trx_flat_destroy(trx_flat *f) {
     std::free(f->instance_offsets);
     std::free(f->tri_source);
     std::free(f->blas_tri_start);
+    std::free(f->tri_boxes);
     std::free(f);
 }
 

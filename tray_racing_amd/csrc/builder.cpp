@@ -698,6 +698,7 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
 
     out.nodes.clear();
     out.primitive_indices.clear();
+    out.primitive_boxes.clear();
     out.total_aabb = empty_box();
     if (n == 0) {
         // empty scene: one node with no children; every ray misses
@@ -753,7 +754,154 @@ void build_cwbvh_from_aabbs(const Aabb *boxes, uint64_t n, const BuildParams &pa
     build_from_boxes(boxes, cen.data(), n, params, out);
 }
 
+namespace {
+
+// ---- pre-splitting (obvhs `pre_split`, the reference's --split, src/main.rs:572) ---------------------
+// Early split clipping in the manner of Karras & Aila 2013: triangles whose boxes are mostly empty are
+// cut into several references, each with the tight box of the triangle clipped to its cell, and the BVH
+// is built over the references.  A triangle then appears once per reference in `primitive_indices`
+// (the caller's triangle buffer repeats it, like `bvh.primitive_indices.map(|i| tris[i])` in
+// src/rt_gpu/mod.rs:38-43).
+
+struct SplitRef {
+    Aabb box;
+    uint32_t tri;
+};
+
+// Box of the triangle clipped to `cell` (Sutherland-Hodgman against the six planes), padded by a few ulps:
+// clipped vertices are interpolated, so the padding keeps the references' union over the triangle.
+Aabb clip_tri_to_cell(const float *v, const Aabb &cell) {
+    double poly[16][3], tmp[16][3];
+    int np = 3;
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) poly[i][k] = v[3 * i + k];
+    for (int axis = 0; axis < 3 && np > 0; axis++) {
+        for (int side = 0; side < 2 && np > 0; side++) {
+            const double plane = side == 0 ? cell.mn[axis] : cell.mx[axis];
+            int nt = 0;
+            for (int i = 0; i < np; i++) {
+                const double *a = poly[i], *b = poly[(i + 1) % np];
+                const bool ina = side == 0 ? a[axis] >= plane : a[axis] <= plane;
+                const bool inb = side == 0 ? b[axis] >= plane : b[axis] <= plane;
+                if (ina) { for (int k = 0; k < 3; k++) tmp[nt][k] = a[k]; nt++; }
+                if (ina != inb) {
+                    const double t = (plane - a[axis]) / (b[axis] - a[axis]);
+                    for (int k = 0; k < 3; k++) tmp[nt][k] = a[k] + t * (b[k] - a[k]);
+                    tmp[nt][axis] = plane;
+                    nt++;
+                }
+            }
+            np = nt;
+            for (int i = 0; i < np; i++)
+                for (int k = 0; k < 3; k++) poly[i][k] = tmp[i][k];
+        }
+    }
+    Aabb out = empty_box();
+    for (int i = 0; i < np; i++) {
+        for (int k = 0; k < 3; k++) {
+            const float lo = std::nextafter((float)poly[i][k], -kInf), hi = std::nextafter((float)poly[i][k], kInf);
+            out.mn[k] = std::min(out.mn[k], std::nextafter(lo, -kInf));
+            out.mx[k] = std::max(out.mx[k], std::nextafter(hi, kInf));
+        }
+    }
+    for (int k = 0; k < 3; k++) { // never outside the cell
+        out.mn[k] = std::max(out.mn[k], cell.mn[k]);
+        out.mx[k] = std::min(out.mx[k], cell.mx[k]);
+    }
+    return out;
+}
+
+float tri_double_area(const float *v) {
+    const float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+    const float c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    return std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+}
+
+// Splits the emptiest boxes first until `budget` extra references are spent (deterministic: a heap keyed by
+// (emptiness, index)).  Cuts are at the spatial median of the box's longest axis.
+void pre_split(const float *verts, uint64_t n, float extra_ratio, std::vector<SplitRef> &refs) {
+    refs.resize(n);
+    // emptiness of a reference: half area of its box minus the area the triangle could account for
+    auto emptiness = [&](const SplitRef &r) {
+        return half_area(r.box) - 0.5f * tri_double_area(verts + 9 * (size_t)r.tri);
+    };
+    std::vector<std::pair<float, uint32_t>> heap;
+    double scene_area = 0.0;
+    Aabb scene = empty_box();
+    for (uint64_t i = 0; i < n; i++) {
+        const float *v = verts + 9 * i;
+        Aabb b = empty_box();
+        grow_pt(b, v);
+        grow_pt(b, v + 3);
+        grow_pt(b, v + 6);
+        refs[i] = SplitRef{b, (uint32_t)i};
+        grow(scene, b);
+    }
+    scene_area = half_area(scene);
+    const float floor_area = (float)(scene_area * 1e-7); // do not chase slivers
+    for (uint64_t i = 0; i < n; i++) {
+        const float e = emptiness(refs[i]);
+        if (e > floor_area) heap.emplace_back(e, (uint32_t)i);
+    }
+    auto less = [](const std::pair<float, uint32_t> &a, const std::pair<float, uint32_t> &b) {
+        return a.first < b.first || (a.first == b.first && a.second > b.second);
+    };
+    std::make_heap(heap.begin(), heap.end(), less);
+    uint64_t budget = (uint64_t)((double)n * extra_ratio);
+    while (budget > 0 && !heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), less);
+        const uint32_t ri = heap.back().second;
+        heap.pop_back();
+        const SplitRef r = refs[ri];
+        int axis = 0;
+        float ext[3] = {r.box.mx[0] - r.box.mn[0], r.box.mx[1] - r.box.mn[1], r.box.mx[2] - r.box.mn[2]};
+        if (ext[1] > ext[axis]) axis = 1;
+        if (ext[2] > ext[axis]) axis = 2;
+        const float mid = 0.5f * (r.box.mn[axis] + r.box.mx[axis]);
+        if (!(mid > r.box.mn[axis] && mid < r.box.mx[axis])) continue;
+        Aabb lc = r.box, rc = r.box;
+        lc.mx[axis] = mid;
+        rc.mn[axis] = mid;
+        const Aabb lb = clip_tri_to_cell(verts + 9 * (size_t)r.tri, lc), rb = clip_tri_to_cell(verts + 9 * (size_t)r.tri, rc);
+        const bool lok = lb.mn[0] <= lb.mx[0] && lb.mn[1] <= lb.mx[1] && lb.mn[2] <= lb.mx[2];
+        const bool rok = rb.mn[0] <= rb.mx[0] && rb.mn[1] <= rb.mx[1] && rb.mn[2] <= rb.mx[2];
+        if (!lok || !rok) continue; // the triangle lies in one half: nothing to gain from this cut
+        refs[ri].box = lb;
+        refs.push_back(SplitRef{rb, r.tri});
+        budget--;
+        for (uint32_t idx : {ri, (uint32_t)(refs.size() - 1)}) {
+            const float e = emptiness(refs[idx]) * 0.5f; // each half accounts for about half the triangle
+            if (e > floor_area) {
+                heap.emplace_back(e, idx);
+                std::push_heap(heap.begin(), heap.end(), less);
+            }
+        }
+    }
+}
+
+} // namespace
+
 void build_cwbvh_from_tris(const float *verts, uint64_t n, const BuildParams &params, CwBvh &out) {
+    if (params.pre_split_ratio > 0.f && n > 1) {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<SplitRef> refs;
+        pre_split(verts, n, params.pre_split_ratio, refs);
+        std::vector<Aabb> rboxes(refs.size());
+        std::vector<float> rcen(3 * refs.size());
+        for (size_t i = 0; i < refs.size(); i++) {
+            rboxes[i] = refs[i].box;
+            for (int k = 0; k < 3; k++) rcen[3 * i + k] = 0.5f * (refs[i].box.mn[k] + refs[i].box.mx[k]);
+        }
+        build_from_boxes(rboxes.data(), rcen.data(), refs.size(), params, out);
+        out.primitive_boxes.resize(out.primitive_indices.size());
+        for (size_t i = 0; i < out.primitive_indices.size(); i++) {
+            const SplitRef &r = refs[out.primitive_indices[i]];
+            out.primitive_boxes[i] = r.box;
+            out.primitive_indices[i] = r.tri; // a triangle may now appear more than once
+        }
+        out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return;
+    }
     std::vector<Aabb> boxes(n);
     std::vector<float> cen(3 * n);
     for (uint64_t i = 0; i < n; i++) {

@@ -17,6 +17,7 @@ namespace trx {
 struct CwBvh {
     std::vector<CwbvhNode> nodes;
     std::vector<uint32_t> primitive_indices;
+    std::vector<Aabb> primitive_boxes; // pre-split builds only: the (clipped) box each entry of primitive_indices was built with
     Aabb total_aabb;
     double build_seconds = 0.0;
     float sah_cost = 0.f; // collapse cost of the root / root area
@@ -30,6 +31,9 @@ struct BuildParams {
     // per iteration (obvhs `reinsertion_batch_ratio`, src/main.rs:113-118); 0 = off
     float reinsertion_batch_ratio = 0.02f;
     int reinsertion_iterations = 4;
+    // pre-splitting (obvhs pre_split / --split): up to this fraction of extra triangle references, spent on
+    // the triangles whose boxes are emptiest; 0 = off (the reference's default)
+    float pre_split_ratio = 0.0f;
     int sah_bins = 32;       // BVH2: SAH bins per axis (2..32)
     uint32_t sweep_max = 48; // BVH2: ranges of at most this many primitives get the exact SAH sweep (<= 64)
     int threads = 0; // <= 0: hardware_concurrency

@@ -34,6 +34,7 @@ struct Options { // src/main.rs:65-171 (flags this backend cannot honour are rej
     std::string preset;
     float reinsertion_batch_ratio = -1.0f; // -r; < 0: library default
     bool dry_run = false; // load + build only (no device needed)
+    bool split = false;   // --split: pre-splitting of large triangles
     int device = 0;
     unsigned semantics = TRX_SEM_HLSL; // the GPU path of the reference is the HLSL text
 };
@@ -137,7 +138,9 @@ Options parse_args(int argc, char **argv) {
         } else if (a == "--search-distance" || a == "--search-depth-threshold" || a == "--sort-precision" ||
                    a == "--post-collapse-reinsertion-batch-ratio-multiplier") {
             need(i); // PLOC parameters of the OBVHS builder: accepted, not used by the stand-in builder
-        } else if (a == "--split" || a == "--auto-tune" || a == "--disable-auto-tune-model-cache") {
+        } else if (a == "--split") {
+            o.split = true;
+        } else if (a == "--auto-tune" || a == "--disable-auto-tune-model-cache") {
             // accepted for command-line compatibility; no effect here
         } else {
             die("unknown argument: " + a);
@@ -248,11 +251,15 @@ Stats render_input(const Options &o, const std::string &input) {
     const bool tlas = o.tlas && !o.flatten_blas; // src/main.rs:300-308
     if (o.verbose) std::printf("%u objects \"%s\"\ntriangles %llu\n", n_objects, st.name.c_str(), (unsigned long long)n_tris);
     check(trx_set_build_costs(o.collapse_traversal_cost, 0.3f), "build costs");
-    check(trx_set_build_preset(o.preset.c_str()), "preset"); // src/main.rs:563-570; "" = the flags below
-    if (o.reinsertion_batch_ratio >= 0.f) {
-        // obvhs: 0..1 is the candidate ratio of one pass, above 1 the whole set is evaluated several times
-        float r = o.reinsertion_batch_ratio;
-        check(trx_set_build_reinsertion(r > 1.f ? 1.f : r, r > 1.f ? (int)std::ceil(r) : 1), "reinsertion");
+    // a named preset overrides the individual builder flags, "" leaves them in charge (src/main.rs:563-585)
+    check(trx_set_build_preset(o.preset.c_str()), "preset");
+    if (o.preset.empty()) {
+        check(trx_set_build_split(o.split ? 0.3f : 0.0f), "split"); // obvhs pre_split is a switch; 30 % extra references here
+        if (o.reinsertion_batch_ratio >= 0.f) {
+            // obvhs: 0..1 is the candidate ratio of one pass, above 1 the whole set is evaluated several times
+            float r = o.reinsertion_batch_ratio;
+            check(trx_set_build_reinsertion(r > 1.f ? 1.f : r, r > 1.f ? (int)std::ceil(r) : 1), "reinsertion");
+        }
     }
     trx_flat *flat = nullptr;
     check(trx_flat_build(verts, counts, n_objects, tlas ? 1 : 0, o.max_prims_per_leaf, 0, &flat), "build");

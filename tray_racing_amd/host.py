@@ -71,7 +71,7 @@ class FlatScene:
     """The buffers rt_gpu_software::start receives: bvh_bytes, tri_bytes, instance_bytes, tlas_start."""
 
     def __init__(self, nodes, tri_verts, instance_offsets, tlas_start, tri_source, blas_tri_start,
-                 blas_build_s=0.0, tlas_build_s=0.0):
+                 blas_build_s=0.0, tlas_build_s=0.0, tri_boxes=None):
         self.nodes = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 20)
         self.tri_verts = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
         self.instance_offsets = np.ascontiguousarray(instance_offsets, dtype=np.uint32)
@@ -80,6 +80,8 @@ class FlatScene:
         self.blas_tri_start = np.ascontiguousarray(blas_tri_start, dtype=np.uint32)
         self.blas_build_s = blas_build_s
         self.tlas_build_s = tlas_build_s
+        # box every triangle entry was built with (pre-split references cover only part of their triangle)
+        self.tri_boxes = None if tri_boxes is None else np.ascontiguousarray(tri_boxes, dtype=np.float32).reshape(-1, 6)
 
     @property
     def n_nodes(self):
@@ -95,12 +97,14 @@ class FlatScene:
 
 
 def flat_build(verts, object_counts=None, use_tlas=False, max_prims_per_leaf=3, threads=0, traversal_cost=None,
-               prim_cost=None, reinsertion=None, preset=None):
+               prim_cost=None, reinsertion=None, preset=None, split=None):
     """`reinsertion`: None keeps the process-wide setting; a float is the batch ratio (2 iterations),
     a (ratio, iterations) pair sets both (trx_set_build_reinsertion)."""
     lib = L.load()
     if preset is not None:   # the reference's --preset names (trx_set_build_preset); "" = defaults
         L.check(lib.trx_set_build_preset(preset.encode()))
+    if split is not None:    # pre-splitting: extra triangle references as a fraction of n (trx_set_build_split)
+        L.check(lib.trx_set_build_split(float(split)))
     if traversal_cost is not None or prim_cost is not None:
         L.check(lib.trx_set_build_costs(traversal_cost or 1.0, prim_cost or 0.3))
     if reinsertion is not None:
@@ -122,7 +126,8 @@ def flat_build(verts, object_counts=None, use_tlas=False, max_prims_per_leaf=3, 
         inst = np.ctypeslib.as_array(f.instance_offsets, shape=(max(f.n_instances, 1),))[: f.n_instances].copy()
         src = np.ctypeslib.as_array(f.tri_source, shape=(max(f.n_tris, 1),))[: f.n_tris].copy()
         bts = np.ctypeslib.as_array(f.blas_tri_start, shape=(f.n_blas + 1,)).copy()
-        return FlatScene(nodes, tris, inst, f.tlas_start, src, bts, f.blas_build_s, f.tlas_build_s)
+        boxes = np.ctypeslib.as_array(f.tri_boxes, shape=(max(f.n_tris, 1), 6))[: f.n_tris].copy()
+        return FlatScene(nodes, tris, inst, f.tlas_start, src, bts, f.blas_build_s, f.tlas_build_s, boxes)
     finally:
         lib.trx_flat_destroy(fp)
 
