@@ -388,6 +388,25 @@ int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32
                    int use_tlas, uint32_t max_prims_per_leaf, int threads, trx_flat **out);
 void trx_flat_destroy(trx_flat *flat);
 
+/* The reference's BvhBuildParams (src/main.rs:571-585), field for field, for callers that carry one around.
+ * The stand-in builder honours pre_split, reinsertion_batch_ratio, max_prims_per_leaf and
+ * collapse_traversal_cost; ploc_search_distance, search_depth_threshold and
+ * post_collapse_reinsertion_batch_ratio_multiplier belong to OBVHS' PLOC stage and are accepted as they are;
+ * sort_precision must be 64 or 128 ("Unsupported sort precision", src/main.rs:576-580). */
+typedef struct trx_build_params {
+    uint32_t pre_split;                 /* --split */
+    uint32_t ploc_search_distance;      /* --search-distance */
+    uint32_t search_depth_threshold;    /* --search-depth-threshold */
+    float reinsertion_batch_ratio;      /* -r */
+    uint32_t sort_precision;            /* --sort-precision: 64 | 128 */
+    uint32_t max_prims_per_leaf;        /* --max-prims-per-leaf: 1..3 for CWBVH */
+    float post_collapse_reinsertion_batch_ratio_multiplier;
+    float collapse_traversal_cost;      /* --collapse-traversal-cost */
+} trx_build_params;
+void trx_build_params_default(trx_build_params *params); /* the reference's command-line defaults */
+int trx_flat_build_params(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects,
+                          int use_tlas, const trx_build_params *params, int threads, trx_flat **out);
+
 /* ---- host side: scenes ----------------------------------------------------
  * The reference's assets are absent: seeded procedural
  * stand-ins with the triangle counts of README.md:27-34.  name is one of

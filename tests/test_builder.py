@@ -203,3 +203,24 @@ def test_pre_split_references_cover_their_triangles(trx, orc):
     assert differ.sum() <= 2 and (got["t"][differ] >= bf["t"][differ]).all()
     _, st0 = orc.Scene.from_flat(plain).trace_primary(ov, 96, 54, sem=3)
     assert st.n_tri < st0.n_tri
+
+
+def test_build_params_struct_mirrors_the_reference(trx, orc):
+    """trx_build_params = BvhBuildParams (src/main.rs:571-585): one build with the caller's params, the
+    process-wide settings untouched afterwards; the reference's own argument errors are kept."""
+    verts, counts = trx.gen_scene("kitchen", 8000, 1)
+    before = trx.flat_build(verts, counts)
+    bp = trx.build_params()
+    assert (bp.pre_split, bp.ploc_search_distance, bp.search_depth_threshold, bp.sort_precision, bp.max_prims_per_leaf) == \
+        (0, 14, 2, 64, 3)                                                       # src/main.rs:85-124
+    assert abs(bp.reinsertion_batch_ratio - 0.15) < 1e-7 and bp.collapse_traversal_cost == 1.0
+    a = trx.flat_build_params(verts, counts, bp)
+    assert a.n_tris == 8000 and orc.Scene.from_flat(a).validate()[0] == 0
+    b = trx.flat_build_params(verts, counts, trx.build_params(pre_split=1, reinsertion_batch_ratio=0.0, max_prims_per_leaf=2,
+                                                              collapse_traversal_cost=2.0), use_tlas=True)
+    assert b.n_tris > 8000 and b.has_tlas and orc.Scene.from_flat(b).validate(boxes=b.tri_boxes)[0] == 0
+    with pytest.raises(trx.TrxError, match="Unsupported sort precision"):         # src/main.rs:576-580
+        trx.flat_build_params(verts, counts, trx.build_params(sort_precision=32))
+    with pytest.raises(trx.TrxError, match="maximum of 3 primitives"):            # src/main.rs:176-178
+        trx.flat_build_params(verts, counts, trx.build_params(max_prims_per_leaf=8))
+    assert (trx.flat_build(verts, counts).nodes == before.nodes).all()

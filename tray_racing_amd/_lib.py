@@ -71,6 +71,13 @@ class Flat(C.Structure):
                 ("tlas_build_s", C.c_double), ("tri_boxes", C.POINTER(C.c_float))]
 
 
+class BuildParams(C.Structure):
+    """trx_build_params = the reference's BvhBuildParams (src/main.rs:571-585)."""
+    _fields_ = [("pre_split", C.c_uint32), ("ploc_search_distance", C.c_uint32), ("search_depth_threshold", C.c_uint32),
+                ("reinsertion_batch_ratio", C.c_float), ("sort_precision", C.c_uint32), ("max_prims_per_leaf", C.c_uint32),
+                ("post_collapse_reinsertion_batch_ratio_multiplier", C.c_float), ("collapse_traversal_cost", C.c_float)]
+
+
 _P = C.c_void_p
 _u32, _u64, _i, _f = C.c_uint32, C.c_uint64, C.c_int, C.c_float
 
@@ -120,6 +127,8 @@ SIGNATURES = {
     "trx_bvh_total_aabb": (None, [_P, C.POINTER(_f)]),
     "trx_bvh_build_seconds": (C.c_double, [_P]),
     "trx_flat_build": (_i, [_P, _P, _u32, _i, _u32, _i, C.POINTER(C.POINTER(Flat))]),
+    "trx_flat_build_params": (_i, [_P, _P, _u32, _i, C.POINTER(BuildParams), _i, C.POINTER(C.POINTER(Flat))]),
+    "trx_build_params_default": (None, [C.POINTER(BuildParams)]),
     "trx_flat_destroy": (None, [C.POINTER(Flat)]),
     "trx_gen_scene": (_i, [C.c_char_p, _u64, _u64, C.POINTER(C.POINTER(_f)), C.POINTER(_u64),
                            C.POINTER(C.POINTER(_u64)), C.POINTER(_u32)]),

@@ -1103,6 +1103,45 @@ void trx_bvh_total_aabb(const trx_bvh *b, float out6[6]) {
 }
 double trx_bvh_build_seconds(const trx_bvh *b) { return b ? b->bvh.build_seconds : 0.0; }
 
+// BvhBuildParams of the reference (src/main.rs:571-585) applied for one build, then the process-wide settings
+// are put back; the stand-in builder has no PLOC stage, so the three PLOC fields only have to be sane.
+int trx_flat_build_params(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects, int use_tlas,
+                          const trx_build_params *bp, int threads, trx_flat **out) {
+    if (!bp) return fail(TRX_ERR_INVALID, "build params are null");
+    if (bp->sort_precision != 64 && bp->sort_precision != 128) return fail(TRX_ERR_INVALID, "Unsupported sort precision");
+    if (!(bp->reinsertion_batch_ratio >= 0.f) || !(bp->collapse_traversal_cost > 0.f))
+        return fail(TRX_ERR_INVALID, "reinsertion_batch_ratio >= 0 and collapse_traversal_cost > 0 required");
+    static std::mutex params_mu; // the settings below are process-wide
+    std::lock_guard<std::mutex> lock(params_mu);
+    const float old_cost = g_traversal_cost, old_ratio = g_reinsert_ratio, old_split = g_pre_split;
+    const int old_iters = g_reinsert_iters;
+    g_traversal_cost = bp->collapse_traversal_cost;
+    // obvhs: 0..1 is the candidate ratio of one pass, above 1 the whole set is evaluated several times
+    g_reinsert_ratio = std::min(bp->reinsertion_batch_ratio, 1.0f);
+    g_reinsert_iters = bp->reinsertion_batch_ratio > 1.f ? (int)std::ceil(bp->reinsertion_batch_ratio)
+                       : bp->reinsertion_batch_ratio > 0.f ? std::max(1, g_reinsert_iters) : 0;
+    g_pre_split = bp->pre_split ? 0.3f : 0.0f;
+    const int rc = trx_flat_build(verts, object_tri_counts, n_objects, use_tlas, bp->max_prims_per_leaf, threads, out);
+    g_traversal_cost = old_cost;
+    g_reinsert_ratio = old_ratio;
+    g_reinsert_iters = old_iters;
+    g_pre_split = old_split;
+    return rc;
+}
+
+void trx_build_params_default(trx_build_params *bp) {
+    if (!bp) return;
+    // the defaults of the reference's command line (src/main.rs:85-124,158-163)
+    bp->pre_split = 0;
+    bp->ploc_search_distance = 14;
+    bp->search_depth_threshold = 2;
+    bp->reinsertion_batch_ratio = 0.15f;
+    bp->sort_precision = 64;
+    bp->max_prims_per_leaf = 3;
+    bp->post_collapse_reinsertion_batch_ratio_multiplier = 0.0f;
+    bp->collapse_traversal_cost = 1.0f;
+}
+
 // cwbvh_gpu_runner, src/rt_gpu/mod.rs:16-112
 int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects, int use_tlas,
                    uint32_t max_prims, int threads, trx_flat **out) {

@@ -119,6 +119,10 @@ def flat_build(verts, object_counts=None, use_tlas=False, max_prims_per_leaf=3, 
     fp = C.POINTER(L.Flat)()
     L.check(lib.trx_flat_build(_ptr(verts), _ptr(counts), counts.size, 1 if use_tlas else 0, max_prims_per_leaf,
                                threads, C.byref(fp)))
+    return _take_flat(lib, fp)
+
+
+def _take_flat(lib, fp):
     f = fp.contents
     try:
         nodes = np.frombuffer((C.c_uint8 * (f.n_nodes * 80)).from_address(f.bvh_bytes), dtype=np.uint32).copy()
@@ -130,6 +134,29 @@ def flat_build(verts, object_counts=None, use_tlas=False, max_prims_per_leaf=3, 
         return FlatScene(nodes, tris, inst, f.tlas_start, src, bts, f.blas_build_s, f.tlas_build_s, boxes)
     finally:
         lib.trx_flat_destroy(fp)
+
+
+def build_params(**fields):
+    """trx_build_params with the reference's command-line defaults (src/main.rs:85-124), fields overridden by name."""
+    lib = L.load()
+    bp = L.BuildParams()
+    lib.trx_build_params_default(C.byref(bp))
+    for k, v in fields.items():
+        if not hasattr(bp, k):
+            raise AttributeError("BvhBuildParams has no field %r" % k)
+        setattr(bp, k, v)
+    return bp
+
+
+def flat_build_params(verts, object_counts, params, use_tlas=False, threads=0):
+    """cwbvh_gpu_runner's build half driven by a BvhBuildParams (src/main.rs:571-585) instead of process-wide knobs."""
+    lib = L.load()
+    verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
+    counts = np.ascontiguousarray(object_counts if object_counts is not None else [verts.shape[0]], dtype=np.uint64)
+    fp = C.POINTER(L.Flat)()
+    L.check(lib.trx_flat_build_params(_ptr(verts), _ptr(counts), counts.size, 1 if use_tlas else 0, C.byref(params), threads,
+                                      C.byref(fp)))
+    return _take_flat(lib, fp)
 
 
 def pack_tris_f16(tri_verts):
