@@ -308,6 +308,19 @@ int trx_debug_wave_timeline(trx_scene *scene, const trx_view *view, uint32_t wid
                             uint32_t semantics, uint64_t *out_times, uint32_t max_waves,
                             uint32_t *out_waves);
 
+/* Diagnostics: 8 words per wave: start, end (as above), then — only in libraries built with -DTRX_STAMPS,
+ * zero otherwise — shader cycles spent in {refill, node fetch, node test, triangle phase, pop / bookkeeping}
+ * and the number of loop trips. */
+int trx_debug_wave_phases(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                          uint32_t semantics, uint64_t *out_records, uint32_t max_waves,
+                          uint32_t *out_waves);
+
+/* Diagnostics (counting kernel): over the triangle phases of one primary frame, out_hist[0..15] = histogram of the
+ * largest per-lane triangle count of the wave (15 = 15 or more), out_hist[16..31] = histogram of the wave's
+ * (ray, triangle) pair total in units of 8, rounded up. */
+int trx_debug_tri_histogram(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                            uint32_t semantics, uint32_t out_hist[32]);
+
 /* Diagnostics: per 8x8 tile (row-major tile id) the wall-clock cost of the tile in a normal frame
  * (100 MHz ticks) and its wave-level iteration counts from a counting frame:
  * (node steps << 16) | triangle rounds.  n_tiles = ceil(w/8) * ceil(h/8). */

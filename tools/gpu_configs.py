@@ -8,6 +8,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tray_racing_amd as T  # noqa: E402
 
+T.load().trx_set_kernel_variant(int(os.environ.get("TRX_VARIANT", "0"), 0))  # tuning aid
+
 
 def bench_ao(sc, view, w, h, frames, sem=3):
     best_p, best_f = 1e9, 1e9

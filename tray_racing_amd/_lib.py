@@ -112,6 +112,8 @@ SIGNATURES = {
     "trx_set_kernel_variant": (_u32, [_u32]),
     "trx_debug_tile_profile": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, _P, _u32]),
     "trx_debug_wave_timeline": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, _u32, C.POINTER(_u32)]),
+    "trx_debug_tri_histogram": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P]),
+    "trx_debug_wave_phases": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, _u32, C.POINTER(_u32)]),
     "trx_shard_tiles": (_u32, [_u32, _u32, Shard]),
     "trx_bvh_build_tris": (_i, [_P, _u64, _u32, _i, C.POINTER(_P)]),
     "trx_bvh_build_aabbs": (_i, [_P, _u64, _u32, _i, C.POINTER(_P)]),

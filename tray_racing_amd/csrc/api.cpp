@@ -32,13 +32,36 @@ using namespace trx;
 namespace {
 
 thread_local std::string g_err;
-uint32_t g_variant = 0;
-float g_traversal_cost = 1.0f, g_prim_cost = 0.3f;
-float g_reinsert_ratio = 0.02f;
-int g_reinsert_iters = 4;
-int g_sah_bins = 32;
-uint32_t g_sweep_max = 48;
-float g_pre_split = 0.0f;
+std::atomic<uint32_t> g_variant{0}; // tuning aid, read once per launch
+// Builder settings for subsequent builds (trx_set_build_*): process-wide, guarded by g_build_mu; a build takes
+// a snapshot when it starts, so concurrent builds and setters do not race.
+struct BuildSettings {
+    float traversal_cost = 1.0f, prim_cost = 0.3f;
+    float reinsert_ratio = 0.02f;
+    int reinsert_iters = 4;
+    int sah_bins = 32;
+    uint32_t sweep_max = 48;
+    float pre_split = 0.0f;
+};
+BuildSettings g_build;
+std::mutex g_build_mu;
+BuildSettings build_settings() {
+    std::lock_guard<std::mutex> lock(g_build_mu);
+    return g_build;
+}
+BuildParams to_build_params(const BuildSettings &b, uint32_t max_prims, int threads) {
+    BuildParams bp;
+    bp.max_prims_per_leaf = max_prims;
+    bp.threads = threads;
+    bp.traversal_cost = b.traversal_cost;
+    bp.prim_cost = b.prim_cost;
+    bp.reinsertion_batch_ratio = b.reinsert_ratio;
+    bp.reinsertion_iterations = b.reinsert_iters;
+    bp.sah_bins = b.sah_bins;
+    bp.sweep_max = b.sweep_max;
+    bp.pre_split_ratio = b.pre_split;
+    return bp;
+}
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -64,6 +87,7 @@ constexpr uint32_t kDefaultWavesPerBlock = 1;
 struct Slot {
     SlotCounters *ctr = nullptr;
     uint2 *spill = nullptr;
+    uint32_t spill_waves = 0;  // waves the spill area is sized for
     hipEvent_t done = nullptr; // everything enqueued for this slot has finished
     bool used = false;
     hipStream_t last_stream = nullptr; // stream of the last launch on this slot
@@ -265,14 +289,38 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     }
     Slot &slot = s->slots[pick];
     const bool same_stream = slot.used && slot.last_stream == stream;
+    const uint32_t variant = g_variant.load(std::memory_order_relaxed);
+    // tuning overrides (trx_set_kernel_variant): bits 8..15 waves per CU, bits 16..19 waves per workgroup
+    uint32_t wpb = (variant >> 16) & 0xfu;
+    if (wpb != 1 && wpb != 2 && wpb != 4) wpb = kDefaultWavesPerBlock;
+    const uint32_t per_cu = (variant >> 8) & 0xffu;
+    int grid = per_cu ? (int)(std::min(per_cu, 32u) * (uint32_t)s->cu_count) : s->grid;
+    grid = std::max((int)wpb, grid / (int)wpb * (int)wpb);
     if (!slot.ctr) {
-        HIP_TRY(hipMalloc(&slot.ctr, sizeof(SlotCounters)));
-        HIP_TRY(hipMemset(slot.ctr, 0, sizeof(SlotCounters)));
-        // sized for the largest grid a tuning override can ask for (32 waves per CU)
-        HIP_TRY(hipMalloc(&slot.spill, (size_t)s->cu_count * 32 * kSpillStack * kWave * sizeof(uint2)));
-        HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+        // all or nothing: a slot is either fully usable or untouched
+        SlotCounters *ctr = nullptr;
+        hipEvent_t done = nullptr;
+        HIP_TRY(hipMalloc(&ctr, sizeof(SlotCounters)));
+        hipError_t e = hipMemset(ctr, 0, sizeof(SlotCounters));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipFree(ctr);
+            return fail(TRX_ERR_NO_DEVICE, "launch slot set-up failed: %s", hipGetErrorString(e));
+        }
+        slot.ctr = ctr;
+        slot.done = done;
     }
     if (slot.used && !same_stream) HIP_TRY(hipStreamWaitEvent(stream, slot.done, 0));
+    if (slot.spill_waves < (uint32_t)grid) {
+        // stack spill area (entries kLdsStack.. of every lane), sized for the grid actually launched; growing it
+        // waits for the slot's previous kernel, which may still be writing the old one
+        if (slot.used) HIP_TRY(hipEventSynchronize(slot.done));
+        if (slot.spill) (void)hipFree(slot.spill);
+        slot.spill = nullptr;
+        slot.spill_waves = 0;
+        HIP_TRY(hipMalloc(&slot.spill, (size_t)grid * kSpillStack * kWave * sizeof(uint2)));
+        slot.spill_waves = (uint32_t)grid;
+    }
     slot.last_stream = stream;
     slot.last_use = ++s->launches;
     p.nodes = s->d_nodes;
@@ -282,28 +330,25 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.ctr = slot.ctr;
     p.spill = slot.spill;
     p.tie_first = (sem & TRX_SEM_TIE_FIRST) ? 1u : 0u;
-    uint32_t refill = g_variant & 0x7fu;
+    uint32_t refill = variant & 0x7fu;
     // coherent primary rays: refill a wave only when its whole tile is done (mixing tiles costs more
     // coherence than idle lanes cost); incoherent rays (AO, explicit batches): replace finished rays
     // once 20 lanes idle (bistro-class AO pass 1.72 -> 1.16 ms, kitchen-class 0.75 -> 0.46 ms)
     p.refill_idle = refill ? std::min(refill, 64u) : (mode == kModePrimary ? 64u : 20u);
     if (p.n_frames > 1) p.refill_idle = 64u; // the kernel takes the frame of a wave from its (whole) tile
-    p.variant = g_variant;
+    p.variant = variant;
     {   // tuning: variant bits 25..28 = compaction threshold (0 = default, 15 = never)
-        const uint32_t c = (g_variant >> 25) & 0xfu;
+        const uint32_t c = (variant >> 25) & 0xfu;
         p.tri_compact_min = c == 0u ? 2u : c == 15u ? 0xffffffffu : c;
+        // tuning: variant bits 29..31 = per-lane rounds one cooperative round is worth (0 = default 2; 7 = always cooperative)
+        const uint32_t r = (variant >> 29) & 0x7u;
+        p.tri_coop_ratio = r == 0u ? 2u : r == 7u ? 0u : r;
     }
-    // tuning overrides (trx_set_kernel_variant): bits 8..15 waves per CU, bits 16..19 waves per workgroup
-    uint32_t wpb = (g_variant >> 16) & 0xfu;
-    if (wpb != 1 && wpb != 2 && wpb != 4) wpb = kDefaultWavesPerBlock;
-    uint32_t per_cu = (g_variant >> 8) & 0xffu;
-    int grid = per_cu ? (int)(std::min(per_cu, 32u) * (uint32_t)s->cu_count) : s->grid;
-    grid = std::max((int)wpb, grid / (int)wpb * (int)wpb);
     p.waves_per_block = wpb;
     p.wave_times = s->d_wave_times;
-    p.single_queue = (g_variant >> 21) & 1u;
+    p.single_queue = (variant >> 21) & 1u;
     // tile order feedback (image modes, whole-tile refills only)
-    const bool lpt = mode != kModeRays && p.refill_idle == 64u && !((g_variant >> 20) & 1u);
+    const bool lpt = mode != kModeRays && p.refill_idle == 64u && !((variant >> 20) & 1u);
     const uint32_t n_tiles = (p.n_items + 63u) >> 6;
     uint64_t key = 0;
     if (lpt) {
@@ -340,7 +385,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         // measured on bistro-class 1080p: {32,8,2} 0.566 ms, {64,16,4} 0.572, {128,32,8} 0.585, none 0.630
         static const uint32_t cuts[8][3] = {{32, 8, 2}, {0, 0, 0}, {256, 64, 16}, {64, 16, 4}, {512, 128, 32},
                                             {128, 0, 0}, {128, 32, 8}, {1024, 256, 64}};
-        const uint32_t *c = cuts[(g_variant >> 22) & 7u];
+        const uint32_t *c = cuts[(variant >> 22) & 7u];
         for (int i = 0; i < 3; i++) p.prio_cut[i] = c[i] ? n_tiles / c[i] : 0u;
     }
     if (s->dbg_cost) { // diagnostics: cold tile order, costs / iteration counts into the caller's buffers
@@ -430,9 +475,7 @@ uint32_t trx_shard_tiles(uint32_t w, uint32_t h, trx_shard shard) {
 }
 
 uint32_t trx_set_kernel_variant(uint32_t variant) {
-    uint32_t old = g_variant;
-    g_variant = variant;
-    return old;
+    return g_variant.exchange(variant);
 }
 
 int trx_scene_create(const void *bvh_bytes, uint64_t n_nodes, const void *tri_bytes, uint64_t n_tris,
@@ -678,7 +721,7 @@ int trx_trace_occluded_dev(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint
                            true);
 }
 
-static int finish_count(trx_scene *s, SlotCounters *ctr, trx_stats *stats) {
+static int finish_count(trx_scene *s, SlotCounters *ctr, trx_stats *stats, uint32_t *hist = nullptr) {
     HIP_TRY(hipEventRecord(s->ev1, nullptr));
     HIP_TRY(hipEventSynchronize(s->ev1));
     SlotCounters c;
@@ -688,6 +731,12 @@ static int finish_count(trx_scene *s, SlotCounters *ctr, trx_stats *stats) {
     z.n_wave_node = z.n_wave_tri = 0;
     z.max_stack = 0;
     z.overflow = 0;
+    std::memset(z.hist_max, 0, sizeof(z.hist_max));
+    std::memset(z.hist_total, 0, sizeof(z.hist_total));
+    if (hist) {
+        std::memcpy(hist, c.hist_max, sizeof(c.hist_max));
+        std::memcpy(hist + 16, c.hist_total, sizeof(c.hist_total));
+    }
     HIP_TRY(hipMemcpy(ctr, &z, sizeof(z), hipMemcpyHostToDevice));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
@@ -717,7 +766,8 @@ int trx_count_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h
     int rc = image_params(p, view, w, h, shard);
     if (rc) return rc;
     if (!d_hits) {
-        rc = ensure_scratch(s, (uint64_t)w * h, 0);
+        // the shard layout addresses local_tile * 64 + k: whole tiles, also where the image ends mid-tile
+        rc = ensure_scratch(s, std::max<uint64_t>((uint64_t)w * h, (uint64_t)p.n_items), 0);
         if (rc) return rc;
         d_hits = s->d_scratch_a;
     }
@@ -728,6 +778,25 @@ int trx_count_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h
     rc = enqueue(s, p, kModePrimary, sem, true, nullptr, &ctr);
     if (rc) return rc;
     return finish_count(s, ctr, stats);
+}
+
+int trx_debug_tri_histogram(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint32_t out_hist[32]) {
+    if (!s || !out_hist) return fail(TRX_ERR_INVALID, "null argument");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu);
+    HIP_TRY(hipSetDevice(s->device));
+    TraceParams p;
+    std::memset(&p, 0, sizeof(p));
+    int rc = image_params(p, view, w, h, trx_shard{0, 1, 0, 0});
+    if (rc) return rc;
+    rc = ensure_scratch(s, (uint64_t)w * h, 0);
+    if (rc) return rc;
+    p.out = s->d_scratch_a;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipEventRecord(s->ev0, nullptr));
+    SlotCounters *ctr = nullptr;
+    rc = enqueue(s, p, kModePrimary, sem, true, nullptr, &ctr);
+    if (rc) return rc;
+    return finish_count(s, ctr, nullptr, out_hist);
 }
 
 int trx_count_ao(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,
@@ -961,35 +1030,46 @@ int trx_debug_tile_profile(trx_scene *s, const trx_view *view, uint32_t w, uint3
     return TRX_OK;
 }
 
-// Diagnostics: per-wave [start, end] wall-clock stamps (100 MHz ticks) of one primary frame.
-int trx_debug_wave_timeline(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem,
-                            uint64_t *out_times, uint32_t max_waves, uint32_t *out_waves) {
-    if (!s || !out_times || !out_waves) return fail(TRX_ERR_INVALID, "null argument");
+// Diagnostics: per-wave records of one primary frame: [start, end] wall-clock stamps (100 MHz ticks) and, in
+// TRX_STAMPS builds, the shader cycles spent in {refill, node fetch, node test, triangle phase, pop} + loop trips.
+static int wave_records(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint64_t *out,
+                        uint32_t fields, uint32_t max_waves, uint32_t *out_waves) {
+    if (!s || !out || !out_waves) return fail(TRX_ERR_INVALID, "null argument");
     std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure_scratch(s, (uint64_t)w * h, 0);
     if (rc) return rc;
     const size_t n = (size_t)s->cu_count * 32;
+    const size_t words = n * kWaveTimeStride;
     HIP_TRY(hipDeviceSynchronize());
-    if (!s->d_wave_times) HIP_TRY(hipMalloc(&s->d_wave_times, n * 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(s->d_wave_times, 0, n * 2 * sizeof(unsigned long long)));
+    if (!s->d_wave_times) HIP_TRY(hipMalloc(&s->d_wave_times, words * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(s->d_wave_times, 0, words * sizeof(unsigned long long)));
     rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, nullptr);
     hipError_t e = hipDeviceSynchronize();
-    std::vector<unsigned long long> host(n * 2);
-    if (e == hipSuccess) e = hipMemcpy(host.data(), s->d_wave_times, n * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> host(words);
+    if (e == hipSuccess) e = hipMemcpy(host.data(), s->d_wave_times, words * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(s->d_wave_times);
     s->d_wave_times = nullptr;
     if (rc) return rc;
     if (e != hipSuccess) return fail(TRX_ERR_NO_DEVICE, "timeline read-back failed: %s", hipGetErrorString(e));
     uint32_t k = 0;
     for (size_t i = 0; i < n && k < max_waves; i++)
-        if (host[2 * i]) {
-            out_times[2 * k] = host[2 * i];
-            out_times[2 * k + 1] = host[2 * i + 1];
+        if (host[kWaveTimeStride * i]) {
+            for (uint32_t f = 0; f < fields; f++) out[(size_t)fields * k + f] = host[kWaveTimeStride * i + f];
             k++;
         }
     *out_waves = k;
     return TRX_OK;
+}
+
+int trx_debug_wave_timeline(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem,
+                            uint64_t *out_times, uint32_t max_waves, uint32_t *out_waves) {
+    return wave_records(s, view, w, h, sem, out_times, 2, max_waves, out_waves);
+}
+
+int trx_debug_wave_phases(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem,
+                          uint64_t *out_records, uint32_t max_waves, uint32_t *out_waves) {
+    return wave_records(s, view, w, h, sem, out_records, (uint32_t)kWaveTimeStride, max_waves, out_waves);
 }
 
 // ---- host side: builder ----------------------------------------------------------------------
@@ -1001,16 +1081,7 @@ int trx_bvh_build_tris(const float *verts, uint64_t n, uint32_t max_prims, int t
     if (n >= 0x7fffffffull) return fail(TRX_ERR_INVALID, "too many primitives");
     trx_bvh *b = new (std::nothrow) trx_bvh();
     if (!b) return fail(TRX_ERR_OOM, "host allocation failed");
-    BuildParams bp;
-    bp.max_prims_per_leaf = max_prims;
-    bp.threads = threads;
-    bp.traversal_cost = g_traversal_cost;
-    bp.prim_cost = g_prim_cost;
-    bp.reinsertion_batch_ratio = g_reinsert_ratio;
-    bp.reinsertion_iterations = g_reinsert_iters;
-    bp.sah_bins = g_sah_bins;
-    bp.sweep_max = g_sweep_max;
-    bp.pre_split_ratio = g_pre_split;
+    const BuildParams bp = to_build_params(build_settings(), max_prims, threads);
     try {
         build_cwbvh_from_tris(verts, n, bp, b->bvh);
     } catch (const std::exception &) {
@@ -1027,16 +1098,8 @@ int trx_bvh_build_aabbs(const float *aabbs, uint64_t n, uint32_t max_prims, int 
     if (n >= 0x7fffffffull) return fail(TRX_ERR_INVALID, "too many primitives");
     trx_bvh *b = new (std::nothrow) trx_bvh();
     if (!b) return fail(TRX_ERR_OOM, "host allocation failed");
-    BuildParams bp;
-    bp.max_prims_per_leaf = max_prims;
-    bp.threads = threads;
-    bp.traversal_cost = g_traversal_cost;
-    bp.prim_cost = g_prim_cost;
+    BuildParams bp = to_build_params(build_settings(), max_prims, threads);
     bp.reinsertion_batch_ratio = 0.f; // boxes of instances: see trx_flat_build
-    bp.reinsertion_iterations = g_reinsert_iters;
-    bp.sah_bins = g_sah_bins;
-    bp.sweep_max = g_sweep_max;
-    bp.pre_split_ratio = g_pre_split;
     try {
         build_cwbvh_from_aabbs((const Aabb *)aabbs, n, bp, b->bvh);
     } catch (const std::exception &) {
@@ -1049,14 +1112,16 @@ int trx_bvh_build_aabbs(const float *aabbs, uint64_t n, uint32_t max_prims, int 
 
 int trx_set_build_costs(float traversal_cost, float prim_cost) {
     if (!(traversal_cost > 0.f) || !(prim_cost > 0.f)) return fail(TRX_ERR_INVALID, "costs must be positive");
-    g_traversal_cost = traversal_cost;
-    g_prim_cost = prim_cost;
+    std::lock_guard<std::mutex> lock(g_build_mu);
+    g_build.traversal_cost = traversal_cost;
+    g_build.prim_cost = prim_cost;
     return TRX_OK;
 }
 
 int trx_set_build_split(float extra_ratio) {
     if (!(extra_ratio >= 0.f) || extra_ratio > 4.f) return fail(TRX_ERR_INVALID, "split: extra reference ratio in [0, 4]");
-    g_pre_split = extra_ratio;
+    std::lock_guard<std::mutex> lock(g_build_mu);
+    g_build.pre_split = extra_ratio;
     return TRX_OK;
 }
 
@@ -1072,11 +1137,12 @@ int trx_set_build_preset(const char *name) {
     if (!name) return fail(TRX_ERR_INVALID, "preset is null");
     for (const Preset &p : presets) {
         if (std::strcmp(name, p.name) == 0) {
-            g_sah_bins = p.bins;
-            g_sweep_max = p.sweep;
-            g_reinsert_ratio = p.ratio;
-            g_reinsert_iters = p.iters;
-            g_pre_split = p.split;
+            std::lock_guard<std::mutex> lock(g_build_mu);
+            g_build.sah_bins = p.bins;
+            g_build.sweep_max = p.sweep;
+            g_build.reinsert_ratio = p.ratio;
+            g_build.reinsert_iters = p.iters;
+            g_build.pre_split = p.split;
             return TRX_OK;
         }
     }
@@ -1086,8 +1152,9 @@ int trx_set_build_preset(const char *name) {
 int trx_set_build_reinsertion(float batch_ratio, int iterations) {
     if (!(batch_ratio >= 0.f) || batch_ratio > 1.f || iterations < 0)
         return fail(TRX_ERR_INVALID, "reinsertion: ratio in [0,1], iterations >= 0");
-    g_reinsert_ratio = batch_ratio;
-    g_reinsert_iters = iterations;
+    std::lock_guard<std::mutex> lock(g_build_mu);
+    g_build.reinsert_ratio = batch_ratio;
+    g_build.reinsert_iters = iterations;
     return TRX_OK;
 }
 
@@ -1103,6 +1170,9 @@ void trx_bvh_total_aabb(const trx_bvh *b, float out6[6]) {
 }
 double trx_bvh_build_seconds(const trx_bvh *b) { return b ? b->bvh.build_seconds : 0.0; }
 
+static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects, int use_tlas,
+                           uint32_t max_prims, int threads, const BuildSettings &settings, trx_flat **out);
+
 // BvhBuildParams of the reference (src/main.rs:571-585) applied for one build, then the process-wide settings
 // are put back; the stand-in builder has no PLOC stage, so the three PLOC fields only have to be sane.
 int trx_flat_build_params(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects, int use_tlas,
@@ -1111,22 +1181,14 @@ int trx_flat_build_params(const float *verts, const uint64_t *object_tri_counts,
     if (bp->sort_precision != 64 && bp->sort_precision != 128) return fail(TRX_ERR_INVALID, "Unsupported sort precision");
     if (!(bp->reinsertion_batch_ratio >= 0.f) || !(bp->collapse_traversal_cost > 0.f))
         return fail(TRX_ERR_INVALID, "reinsertion_batch_ratio >= 0 and collapse_traversal_cost > 0 required");
-    static std::mutex params_mu; // the settings below are process-wide
-    std::lock_guard<std::mutex> lock(params_mu);
-    const float old_cost = g_traversal_cost, old_ratio = g_reinsert_ratio, old_split = g_pre_split;
-    const int old_iters = g_reinsert_iters;
-    g_traversal_cost = bp->collapse_traversal_cost;
+    BuildSettings b = build_settings(); // bins / sweep threshold stay those of the current preset
+    b.traversal_cost = bp->collapse_traversal_cost;
     // obvhs: 0..1 is the candidate ratio of one pass, above 1 the whole set is evaluated several times
-    g_reinsert_ratio = std::min(bp->reinsertion_batch_ratio, 1.0f);
-    g_reinsert_iters = bp->reinsertion_batch_ratio > 1.f ? (int)std::ceil(bp->reinsertion_batch_ratio)
-                       : bp->reinsertion_batch_ratio > 0.f ? std::max(1, g_reinsert_iters) : 0;
-    g_pre_split = bp->pre_split ? 0.3f : 0.0f;
-    const int rc = trx_flat_build(verts, object_tri_counts, n_objects, use_tlas, bp->max_prims_per_leaf, threads, out);
-    g_traversal_cost = old_cost;
-    g_reinsert_ratio = old_ratio;
-    g_reinsert_iters = old_iters;
-    g_pre_split = old_split;
-    return rc;
+    b.reinsert_ratio = std::min(bp->reinsertion_batch_ratio, 1.0f);
+    b.reinsert_iters = bp->reinsertion_batch_ratio > 1.f ? (int)std::ceil(bp->reinsertion_batch_ratio)
+                       : bp->reinsertion_batch_ratio > 0.f ? std::max(1, b.reinsert_iters) : 0;
+    b.pre_split = bp->pre_split ? 0.3f : 0.0f;
+    return flat_build_impl(verts, object_tri_counts, n_objects, use_tlas, bp->max_prims_per_leaf, threads, b, out);
 }
 
 void trx_build_params_default(trx_build_params *bp) {
@@ -1145,22 +1207,18 @@ void trx_build_params_default(trx_build_params *bp) {
 // cwbvh_gpu_runner, src/rt_gpu/mod.rs:16-112
 int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects, int use_tlas,
                    uint32_t max_prims, int threads, trx_flat **out) {
+    return flat_build_impl(verts, object_tri_counts, n_objects, use_tlas, max_prims, threads, build_settings(), out);
+}
+
+static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects, int use_tlas,
+                           uint32_t max_prims, int threads, const BuildSettings &settings, trx_flat **out) {
     if (!out || !object_tri_counts || n_objects == 0) return fail(TRX_ERR_INVALID, "null argument");
     if (max_prims < 1 || max_prims > 3) return fail(TRX_ERR_INVALID, "CWBVH only supports a maximum of 3 primitives per leaf.");
     uint64_t total = 0;
     for (uint32_t i = 0; i < n_objects; i++) total += object_tri_counts[i];
     if (total && !verts) return fail(TRX_ERR_INVALID, "verts is null");
     if (total >= 0x7fffffffull) return fail(TRX_ERR_INVALID, "too many triangles");
-    BuildParams bp;
-    bp.max_prims_per_leaf = max_prims;
-    bp.threads = threads;
-    bp.traversal_cost = g_traversal_cost;
-    bp.prim_cost = g_prim_cost;
-    bp.reinsertion_batch_ratio = g_reinsert_ratio;
-    bp.reinsertion_iterations = g_reinsert_iters;
-    bp.sah_bins = g_sah_bins;
-    bp.sweep_max = g_sweep_max;
-    bp.pre_split_ratio = g_pre_split;
+    const BuildParams bp = to_build_params(settings, max_prims, threads);
     try {
         // without --tlas everything is flattened into the first object (src/main.rs:300-308)
         std::vector<uint64_t> counts;

@@ -23,6 +23,7 @@ constexpr int kSpillStack = 64 - TRX_LDS_STACK; // further entries per lane in H
 // LDS per wave: stack + ray table (2 x float4 per lane) + triangle-phase tables (group, result, prefix, heads)
 constexpr int kLptPend = 32; // tile-list appends a wave parks in LDS before issuing them together
 constexpr int kLdsBytesPerWave = TRX_LDS_STACK * kWave * 8 + kWave * 32 + kWave * 8 + kWave * 8 + kWave * 4 + kWave * 4 + kLptPend * 8;
+constexpr int kWaveTimeStride = 8; // diagnostics record per wave: start, end, then (TRX_STAMPS builds) phase cycles
 constexpr uint32_t kMaxSteps = 1u << 22; // per-ray iteration cap: every wave reaches an exit
 
 enum TraceMode : int { kModePrimary = 0, kModeAo = 1, kModeRays = 2 };
@@ -51,6 +52,9 @@ struct SlotCounters {
     unsigned int max_stack;
     unsigned int pad2;
     unsigned long long n_wave_node, n_wave_tri; // wave-level node / triangle step executions
+    // COUNT kernels: per triangle phase, histogram of the largest per-lane triangle count (0..15+) and of the
+    // wave's pair total in units of 8 (0..15+)
+    unsigned int hist_max[16], hist_total[16];
 };
 
 struct TraceParams {
@@ -81,10 +85,11 @@ struct TraceParams {
     float ao_eps;
     uint32_t tie_first;
     uint32_t refill_idle; // refill the wave when at least this many lanes are idle (1..64)
-    uint32_t tri_compact_min; // spread the wave's triangle tests over all lanes when a lane owns this many
+    uint32_t tri_compact_min; // consider spreading the wave's triangle tests over all lanes when a lane owns this many
+    uint32_t tri_coop_ratio;  // ... and do it when the largest per-lane count exceeds this x the cooperative rounds
     uint32_t variant;
     uint32_t waves_per_block;        // 1, 2 or 4
-    unsigned long long *wave_times;  // diagnostics: [2*wave] start, [2*wave+1] end (wall_clock64), or null
+    unsigned long long *wave_times;  // diagnostics: [8*wave] start, [8*wave+1] end (wall_clock64), [+2..7] phase cycles in TRX_STAMPS builds; or null
     // frames per launch (image modes): frame f = local_tile / tiles_per_frame uses views[f] and writes its
     // records at out + f * frame_stride; one launch then balances n_frames x the tiles
     uint32_t any_hit;     // explicit rays only: stop at the first accepted hit, write one byte (0/1) per ray

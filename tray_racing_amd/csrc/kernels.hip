@@ -29,6 +29,20 @@
 
 #pragma clang fp contract(off)
 
+// TRX_STAMPS (diagnostic builds only): per-wave cycle accounting of the loop's phases.  Every stamp
+// drains the memory counters first, so a phase owns the latency of what it issued.
+#ifdef TRX_STAMPS
+#define TRX_STAMP(acc)                                                  \
+    do {                                                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        acc += now_ - stamp_prev;                                       \
+        stamp_prev = now_;                                              \
+    } while (0)
+#else
+#define TRX_STAMP(acc) do { } while (0)
+#endif
+
 namespace trx {
 namespace {
 
@@ -289,7 +303,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint2 *const lds_pend = reinterpret_cast<uint2 *>(lds_head + kWave);                   // [kLptPend] {tile, list} to append
     uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave) + lane;
     const bool tie_first = P.tie_first != 0;
-    if (P.wave_times && lane == 0) P.wave_times[2 * wave_global] = wall_clock64();
+    if (P.wave_times && lane == 0) P.wave_times[kWaveTimeStride * wave_global] = wall_clock64();
+#ifdef TRX_STAMPS
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+    unsigned long long k_refill = 0, k_fetch = 0, k_test = 0, k_tri = 0, k_pop = 0, k_iters = 0;
+#endif
 
     // per-lane ray slot
     bool has_ray = false;
@@ -350,6 +368,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 
     bool exhausted = false; // wave-uniform
     for (;;) {
+        TRX_STAMP(k_pop);
         // ---- refill idle lanes from the queues --------------------------------------------
         const unsigned long long idle = __ballot(!has_ray);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -539,6 +558,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 }
             }
         }
+        TRX_STAMP(k_refill);
         if (__ballot(has_ray) == 0ull) {
             if (exhausted) break;
             continue;
@@ -570,6 +590,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     if (TLAS) node_index += bvh_off;
                     const uint4 *np = P.nodes + (size_t)node_index * 5;
                     const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                    TRX_STAMP(k_fetch);
                     if (COUNT) {
                         c_node++;
                         if (lane_rank(__ballot(1)) == 0) c_wnode++;
@@ -608,6 +629,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 }
             }
 
+            TRX_STAMP(k_test);
             // ---- triangle phase ---------------------------------------------------------
             // Each lane owns cnt triangle tests (the hit leaves of its node, highest bit first).
             // Few per lane: every owner tests its own, one round per triangle.  Otherwise the
@@ -616,7 +638,29 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             // results in order, so a ray's triangle sequence (and its tie rule) is unchanged.
             const uint32_t cnt = (uint32_t)__popc(tri.y);
             if (__ballot(cnt != 0u) != 0ull) {
-                if (__ballot(cnt >= P.tri_compact_min) == 0ull) {
+                if (COUNT) {
+                    uint32_t mx = cnt, sum = cnt;
+                    for (int off = 32; off > 0; off >>= 1) {
+                        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+                        sum += (uint32_t)__shfl_xor((int)sum, off);
+                    }
+                    if (lane == 0) {
+                        atomicAdd(&P.ctr->hist_max[min(mx, 15u)], 1u);
+                        atomicAdd(&P.ctr->hist_total[min((sum + 7u) >> 3, 15u)], 1u);
+                    }
+                }
+                // Cooperative rounds cost about three per-lane rounds of VALU work (scans, owner look-up, the LDS
+                // hand-offs), so they only pay when the wave's triangles sit in few lanes: 64 coherent rays testing
+                // the same two triangles are 128 pairs = 2 cooperative rounds, but also just 2 per-lane rounds.
+                bool coop = false;
+                uint32_t incl = 0u, total = 0u;
+                if (__ballot(cnt >= P.tri_compact_min) != 0ull) {
+                    incl = wave_scan_add(cnt);
+                    total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    const uint32_t mx = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_max(cnt), 63);
+                    coop = mx > P.tri_coop_ratio * ((total + 63u) >> 6);
+                }
+                if (!coop) {
                     while (tri.y != 0u) {
                         const uint32_t local = 31u - (uint32_t)__clz((int)tri.y);
                         tri.y &= ~(1u << local);
@@ -633,9 +677,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         if (intersect_tri(r, a, b, c4, t, tie_first)) prim = gidx;
                     }
                 } else {
-                    const uint32_t incl = wave_scan_add(cnt);
                     const uint32_t excl = incl - cnt;
-                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     lds_grp[lane] = tri;
                     lds_pref[lane] = excl;
                     if (COUNT) c_tri += cnt;
@@ -681,6 +723,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 }
             }
 
+            TRX_STAMP(k_tri);
+#ifdef TRX_STAMPS
+            k_iters++;
+#endif
             if (act) {
                 bool done = false;
                 if ((cur.y & 0xff000000u) == 0u) {
@@ -726,6 +772,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 }
             }
             const uint32_t alive = (uint32_t)__popcll(__ballot(has_ray));
+            TRX_STAMP(k_pop);
             if (alive == 0u || (!exhausted && alive <= keep)) break;
         }
     }
@@ -744,7 +791,13 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     }
     if (lane == 0) {
         // the last wave out re-arms the queue for the next launch on this slot
-        if (P.wave_times) P.wave_times[2 * wave_global + 1] = wall_clock64();
+        if (P.wave_times) {
+            P.wave_times[kWaveTimeStride * wave_global + 1] = wall_clock64();
+#ifdef TRX_STAMPS
+            unsigned long long *wt = P.wave_times + kWaveTimeStride * wave_global;
+            wt[2] = k_refill; wt[3] = k_fetch; wt[4] = k_test; wt[5] = k_tri; wt[6] = k_pop; wt[7] = k_iters;
+#endif
+        }
         const unsigned int ticket = atomicAdd(&P.ctr->waves_done, 1u);
         if (ticket == gridDim.x * (blockDim.x / kWave) - 1u) {
             for (int q = 0; q < 8; q++) atomicExch(&P.ctr->heads[q].taken, 0u);
