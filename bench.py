@@ -1,42 +1,55 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s, primary rays, bistro-class scene, 1920x1080, CWBVH, N x MI355X.
 
-A step is one pass of the hot path over one 1920x1080 frame of primary rays
-(2,073,600 rays generated in-kernel; scene resident in HBM before the timed
-region).  With N > 1 (one process per GPU under torch.distributed.run) the
-frame's 8x8 tiles are dealt round-robin to the ranks (tile % N == rank), each
-rank traces its tiles straight into its block of a gather buffer and ONE in-place
-all-gather (RCCL) per batch of `--gather-batch` frames brings the hit records to
-every rank, which de-interleaves them into row-major frames (all inside the
-timed region).  Total work is fixed as N grows: "scaling": "strong".
+A step is one pass of the hot path over one 1920x1080 frame of primary rays (2,073,600 rays generated
+in-kernel; scene resident in HBM before the timed region).
 
-Frames are independent units of work, so `--streams` frames are kept in flight
-(frame k on HIP stream k % streams with its own buffers): the tail of a frame —
-a few slow tiles, ~0.4 ms on this scene however many GPUs share it — overlaps
-the next frames instead of idling the GPU.  The `roofline` object is measured
-in a separate leg with ONE frame in flight (the kernel's own speed);
-`in_flight_kernel_ms` is the average launch duration while frames overlap.
+N = 1 measures what SURVEY.md 8(d) defines, the way the reference measures its GPU path
+(src/rt_gpu/rt_gpu_software.rs:289-302,339-344,376): ONE frame in flight — the K timed launches go back to back
+on one HIP stream, each bracketed by a hipEvent pair on that stream — after the warm-up launches.  `value` is
+rays * K / wall-clock of the timed region; `kernel_ms_mean` / `kernel_ms_min` are the per-launch event times
+(their mean times K is the timed region, up to launch gaps).  Beside it, as separate legs that never enter
+`value`: the reference's own protocol (3 passes x [3 discarded + 20 timed frames], min and mean), the first
+frame of a geometry (tile order not yet learnt: `cold_order_ms`), the literal-HLSL arithmetic
+(`sem_hlsl_ms`), frames overlapped on 4 streams (`pipelined_mrays`), a measured HBM copy ceiling, live
+rocprofv3 counter passes of the same workload (child processes) and the CPU port on the host cores.
 
-The reference's Bistro asset is absent (assets/large_obj is git-ignored), so
-the workload is the seeded procedural bistro-class stand-in with Bistro's
-triangle count (3,872,303) and the camera of assets/scenes/bistro.ron.
+N > 1 (one process per GPU under torch.distributed.run): the frame's 8x8 tiles are dealt round-robin to the
+ranks (tile % N == rank), each rank traces its tiles straight into its block of a gather buffer and ONE
+in-place all-gather (RCCL) per batch of `--gather-batch` frames brings the hit records to every rank, which
+de-interleaves them into row-major frames — all inside the timed region.  Total work is fixed as N grows:
+"scaling": "strong".  Per-phase times (trace / gather / assemble) are reported per frame.
+
+The reference's Bistro asset is absent (assets/large_obj is git-ignored), so the workload is the seeded
+procedural bistro-class stand-in with Bistro's triangle count (3,872,303) and the camera of
+assets/scenes/bistro.ron.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
-# concurrent kernels from several HIP streams need as many hardware queues (read at HIP init)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# read by the HIP / HSA runtimes when they initialise, so set before anything touches the GPU
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")          # concurrent kernels from several streams (pipelined leg)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL / cross-process sharing on this driver
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); 6.29 TB/s measured there
 TRI_BYTES = 48         # device triangle record actually fetched per test
 NODE_BYTES = 80
 HIT_BYTES = 8
+SIMDS = 1024           # 256 CUs x 4 SIMD-32
+CLOCK_GHZ = 2.4        # max engine clock
+VALU_CYCLES = 2.0      # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (same guide, "Wave scheduling")
+VARIANT_COLD = 1 << 20  # trx_set_kernel_variant: tile-order feedback off
 
 
 def baseline_metric():
@@ -44,7 +57,7 @@ def baseline_metric():
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:  # noqa: BLE001
-        return "Mrays/s primary rays, Bistro 1920\u00d71080 CWBVH, 1/2/4/8 MI355X"
+        return "Mrays/s primary rays, Bistro 1920×1080 CWBVH, 1/2/4/8 MI355X"
 
 
 def usable_cores():
@@ -72,21 +85,77 @@ def parse():
                     help="builder preset (the reference's --preset names); BASELINE.json's config is medium_build")
     ap.add_argument("--sem", type=int, default=3, help="trx_semantics bits (3 = TRX_SEM_CPU)")
     ap.add_argument("--streams", type=int, default=0,
-                    help="frames in flight; 0 = 4 for 1-2 GPUs, 8 beyond (a rank's shard shrinks with N, its "
-                         "slowest tile does not); 1 = strictly one frame at a time")
+                    help="frames in flight inside the timed region; 0 = 1 on one GPU (the SURVEY 8(d) metric), 4 for "
+                         "2 GPUs, 8 beyond (a rank's shard shrinks with N, its slowest tile does not)")
     ap.add_argument("--gather-batch", type=int, default=0,
                     help="N > 1: frames completed by one all-gather; 0 = 8 (a 1080p frame is only 2 MB per rank at N = 8)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="frames submitted per kernel launch (1..8); 0 = 1 on one GPU, the gather batch beyond")
-    ap.add_argument("--roofline-launches", type=int, default=40, help="un-overlapped launches timed for `roofline`")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (child processes)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (cold order, HLSL, pipelined, HBM copy)")
     ap.add_argument("--sim-shards", type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the shard gather through host memory (lets N ranks share one GPU in tests)")
     ap.add_argument("--dump-frame", default="", help="rank 0 writes the last timed frame (int64 {t, prim} records, "
                                                       ".npy) here, with the scene's flat buffers next to it (tests)")
     return ap.parse_args()
+
+
+# ---- live counters: rocprofv3 --pmc over a child process that replays the same scene -------------------------
+
+PMC_GROUPS = [
+    "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES",
+    "FETCH_SIZE",
+    "WRITE_SIZE",
+]
+
+
+def pmc_passes(scene_npz, frames=10, timeout_s=150):
+    """One rocprofv3 --pmc pass per counter group (separate passes, --kernel-trace only beside them), averaged
+    per launch of the traversal kernel.  Returns ({counter: value per launch}, kernel_ms under the profiler)
+    or (None, reason)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out, dur = {}, []
+    tmp = tempfile.mkdtemp(prefix="trx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for i, grp in enumerate(PMC_GROUPS):
+            d = os.path.join(tmp, "g%d" % i)
+            cmd = [exe, "--kernel-trace", "--pmc"] + grp.split() + ["--output-format", "csv", "-d", d, "--",
+                                                                     sys.executable, os.path.join(ROOT, "tools", "pmc_child.py"),
+                                                                     scene_npz, str(frames)]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 pass %d timed out" % i
+            if r.returncode != 0:
+                return None, "rocprofv3 pass %d rc %d: %s" % (i, r.returncode, r.stderr[-200:])
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "rocprofv3 pass %d wrote no counter csv" % i
+            tot, seen = {}, {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if "k_trace<0" not in row["Kernel_Name"]:
+                        continue
+                    c = tot.setdefault(row["Counter_Name"], [0.0, 0])
+                    c[0] += float(row["Counter_Value"])
+                    c[1] += 1
+                    seen[row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
+            # the first dispatches are warm-up (cold tile order); every dispatch counts the same instructions, so
+            # averaging over all of them is exact for instruction counts and a slight over-estimate for bytes
+            for k, (s, n) in tot.items():
+                out[k] = s / max(n, 1)
+            if i == 0 and seen:
+                v = sorted(seen.values())
+                dur = v[: max(1, len(v) // 2)]  # the faster half = the steady state
+        return out, (sum(dur) / len(dur) if dur else None)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -113,7 +182,6 @@ def main():
         raise SystemExit("no HIP device %d (libtrx.so has no CPU fallback)" % local_rank)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -129,7 +197,8 @@ def main():
     view = T.view_from_camera(eye, look, fov, w, h)
     scene = T.Scene(flat, device=local_rank)
 
-    n_streams = args.streams if args.streams > 0 else (4 if max(world, args.sim_shards) <= 2 else 8)
+    shards = max(world, args.sim_shards)
+    n_streams = args.streams if args.streams > 0 else (1 if shards == 1 else 4 if shards == 2 else 8)
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
     shard_img = (rank, world, 0)
     shard_cmp = (rank, world, 1)
@@ -153,10 +222,12 @@ def main():
     if world == 1 and L_launch > 1:
         frames = [torch.empty(L_launch * n_rays_total, dtype=torch.int64, device="cuda") for _ in range(n_streams)]
 
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
     def trace(s, ptr, shard, n, stride):
         """n frames in one launch (n == 1: the plain entry point), bracketed by events on the launching stream."""
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0, ev1 = ev(), ev()
         ev0.record(s)
         if n == 1:
             scene.trace_primary_dev(view, w, h, ptr, sem=args.sem, shard=shard, stream=s.cuda_stream)
@@ -165,8 +236,8 @@ def main():
         ev1.record(s)
         return ev0, ev1, n
 
-    def run_frames(n, events):
-        """Enqueue n frames (nothing here waits on the GPU)."""
+    def run_frames(n, events, phases=None):
+        """Enqueue n frames on the chosen streams (nothing here waits on the GPU)."""
         done = 0
         if world == 1:
             while done < n:
@@ -187,6 +258,8 @@ def main():
                 for f0 in range(0, m, L_launch):
                     mm = min(L_launch, m - f0)
                     events.append(trace(s, fg.slot(f0, m).data_ptr(), shard_cmp, mm, fg.records))
+                e_g0, e_g1, e_a1 = ev(), ev(), ev()
+                e_g0.record(s)
                 if args.dist_backend == "nccl":
                     work = fg.gather(m=m, async_op=True)         # the one collective: 8 B/ray, m frames at once
                     work.wait()                                   # stream s (not the host) waits for it
@@ -196,7 +269,11 @@ def main():
                     host = torch.empty(world * nrec, dtype=torch.int64)
                     dist.all_gather_into_tensor(host, fg.flat[rank * nrec:(rank + 1) * nrec].cpu())
                     fg.flat[: world * nrec].copy_(host)
+                e_g1.record(s)
                 fg.assemble(frames[j][: m * n_rays_total], m=m)
+                e_a1.record(s)
+                if phases is not None:
+                    phases.append((e_g0, e_g1, e_a1, m))
             state["last"] = frames[j][(m - 1) * n_rays_total: m * n_rays_total]
             state["batch"] += 1
             done += m
@@ -209,37 +286,22 @@ def main():
 
     if world > 1:  # gather indices for every batch size the loops below will meet, built outside the timed region
         fgs[0].prepare(min(F, args.steps), args.steps % F, min(F, max(args.warmup, 1)), args.warmup % F)
-    # set-up, like the scene upload: every stream's launch slot sees the frame geometry once, so that the
-    # tile-order feedback is in its steady state whatever --warmup is
+    # set-up, like the scene upload: every stream's launch slot sees the frame geometry once (its first frame
+    # runs in natural tile order and measures the tiles: reported separately as cold_order_ms)
     sync_all()
     run_frames(n_streams * (1 if world == 1 else F), [])
     sync_all()
     run_frames(args.warmup, [])
     sync_all()
     t0 = time.perf_counter()
-    events = []
-    run_frames(args.steps, events)
+    events, phases = [], []
+    run_frames(args.steps, events, phases)
     sync_all()
     elapsed = time.perf_counter() - t0
     for s in streams:
         scene.check(s.cuda_stream)
     frame = state["last"]
-    in_flight_ms = sum(a.elapsed_time(b) for a, b, _ in events) / len(events)   # per launch
-
-    # roofline leg: the same launch with ONE frame in flight, hipEvents on the launching stream
-    s0 = streams[0]
-    single = []
-    with torch.cuda.stream(s0):
-        for _ in range(max(1, args.roofline_launches)):
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev0.record(s0)
-            scene.trace_primary_dev(view, w, h, (frames[0] if world == 1 else fgs[0].slot(0, 1)).data_ptr(), sem=args.sem,
-                                    shard=(shard_img if world == 1 else shard_cmp), stream=s0.cuda_stream)
-            ev1.record(s0)
-            single.append((ev0, ev1))
-    sync_all()
-    kernel_ms = sum(a.elapsed_time(b) for a, b in single) / len(single)
+    launch_ms = [a.elapsed_time(b) / n for a, b, n in events]   # per frame of each launch
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
@@ -247,18 +309,138 @@ def main():
         elapsed = float(tmax[0])
     rays_per_step = st.n_rays if args.sim_shards > 1 else n_rays_total
     value = rays_per_step * args.steps / elapsed / 1e6
+    kernel_ms = sum(launch_ms) / len(launch_ms)
 
     out = None
+    legs = {}
+    if rank == 0 and world == 1 and args.sim_shards == 1 and not args.no_legs:
+        s0 = streams[0]
+        # (a) the reference's protocol: 3 passes x [3 discarded + 20 frames], hipEvent pair per frame, min and mean
+        passes = [scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
+        legs["reference_protocol"] = {
+            "passes": 3, "discarded_frames": 3, "frames": 20,
+            "min_ms": round(sum(p[0] for p in passes) / 3, 4), "mean_ms": round(sum(p[1] for p in passes) / 3, 4),
+            "mrays_at_min": round(n_rays_total / (sum(p[0] for p in passes) / 3) / 1e3, 1),
+        }
+        # (b) tile-order feedback off: what the first frame of a geometry (or a caller that never repeats one) gets
+        lib.trx_set_kernel_variant(VARIANT_COLD)
+        cmin, cmean = scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20)
+        lib.trx_set_kernel_variant(0)
+        legs["cold_order_ms"] = {"min": round(cmin, 4), "mean": round(cmean, 4)}
+        # (c) the literal HLSL arithmetic (per-node IEEE divides, tt <= t)
+        hmin, hmean = scene.bench_primary(view, w, h, sem=0, warmup=3, frames=20)
+        legs["sem_hlsl_ms"] = {"min": round(hmin, 4), "mean": round(hmean, 4)}
+        # (d) frames overlapped on 4 streams (independent frames; the tail of one overlaps the next)
+        ps = [torch.cuda.Stream() for _ in range(4)]
+        pbuf = [torch.empty(n_rays_total, dtype=torch.int64, device="cuda") for _ in ps]
+
+        def pipelined(n):
+            for k in range(n):
+                with torch.cuda.stream(ps[k % 4]):
+                    scene.trace_primary_dev(view, w, h, pbuf[k % 4].data_ptr(), sem=args.sem, stream=ps[k % 4].cuda_stream)
+        pipelined(16)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        pipelined(200)
+        torch.cuda.synchronize()
+        legs["pipelined_mrays"] = round(n_rays_total * 200 / (time.perf_counter() - tp) / 1e6, 1)
+        legs["pipelined_frames_in_flight"] = 4
+        # (e) measured HBM ceiling: device-to-device copy of 2 GiB (1 GiB read + 1 GiB written per pass)
+        n64 = (1 << 30) // 8
+        src = torch.empty(n64, dtype=torch.int64, device="cuda").fill_(1)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        legs["hbm_copy_gbs"] = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del src, dst
+        # (f) compulsory footprint: distinct nodes / triangles one frame touches
+        fn, ft = scene.footprint(view, w, h, sem=args.sem)
+        legs["footprint"] = {"nodes": fn, "tris": ft, "bytes": NODE_BYTES * fn + TRI_BYTES * ft + HIT_BYTES * n_rays_total}
+        del s0
+
+    pmc, pmc_src, pmc_ms = None, None, None
+    if rank == 0 and world == 1 and args.sim_shards == 1:
+        if not args.no_pmc:
+            npz = os.path.join(tempfile.gettempdir(), "trx_bench_scene_%d.npz" % os.getpid())
+            np.savez(npz, nodes=flat.nodes, tri_verts=flat.tri_verts, instance_offsets=flat.instance_offsets,
+                     tlas_start=np.uint32(flat.tlas_start), view=np.frombuffer(bytes(view), dtype=np.uint8),
+                     width=np.uint32(w), height=np.uint32(h), sem=np.uint32(args.sem))
+            try:
+                pmc, pmc_ms = pmc_passes(npz)
+                pmc_src = "live: rocprofv3 --pmc child passes of this workload" if pmc else "live passes failed (%s)" % pmc_ms
+            finally:
+                try:
+                    os.remove(npz)
+                except OSError:
+                    pass
+        if not pmc:
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath) and args.scene == "bistro" and (w, h) == (1920, 1080):
+                try:
+                    tj = json.load(open(tpath))
+                    pmc = {"SQ_INSTS_VALU": tj.get("valu_wave_insts_per_launch"),
+                           "_hbm_bytes": tj.get("hbm_bytes_per_launch")}
+                    pmc_src = "profiles/traffic.json (committed rocprofv3 passes, not this run)" + (
+                        "; " + pmc_src if pmc_src else "")
+                except Exception:  # noqa: BLE001
+                    pmc = None
+
     if rank == 0:
-        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic, valu_insts = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.scene == "bistro" and (w, h) == (1920, 1080):
-            try:  # PMC counters cannot be read live; these come from the committed rocprofv3 --pmc passes
-                tj = json.load(open(tpath))
-                traffic, valu_insts = tj.get("hbm_bytes_per_launch"), tj.get("valu_wave_insts_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+        req_gbs = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        valu = None
+        if pmc:
+            if pmc.get("_hbm_bytes") is not None:
+                traffic = pmc["_hbm_bytes"]
+            elif "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                # rocprofv3 reports KiB; gfx950 FETCH_SIZE tallies 128-B requests at 64 B: doubled (guide, HBM section)
+                traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
+            valu = pmc.get("SQ_INSTS_VALU")
+        peak_ginstr = SIMDS * CLOCK_GHZ / VALU_CYCLES
+        ach_ginstr = (valu / (kernel_ms * 1e-3) / 1e9) if valu else None
+        roof = {
+            # the kernel is bound by vector-instruction issue, not by bytes: achieved = VALU
+            # wave-instructions per second (SQ_INSTS_VALU per launch / this run's kernel time), peak = one wave64
+            # instruction per 2 cycles per SIMD-32 x 1024 SIMDs x 2.4 GHz
+            "bound": "valu",
+            "achieved": round(ach_ginstr, 1) if ach_ginstr else None,
+            "peak": round(peak_ginstr, 1),
+            "unit": "Ginstr/s",
+            "frac": round(ach_ginstr / peak_ginstr, 4) if ach_ginstr else None,
+            "traffic": traffic,   # HBM bytes per launch from FETCH_SIZE (doubled) + WRITE_SIZE
+            "source": pmc_src,
+            "kernel_ms": round(kernel_ms, 4),
+            "valu_wave_insts_per_launch": int(valu) if valu else None,
+        }
+        if pmc and "SQ_WAVE_CYCLES" in pmc:
+            wc = pmc["SQ_WAVE_CYCLES"]
+            roof["wave_cycle_split"] = {k: round(pmc[c] / wc, 3) for k, c in (
+                ("issuing", "SQ_ACTIVE_INST_ANY"), ("issuing_valu", "SQ_ACTIVE_INST_VALU"), ("waitcnt", "SQ_WAIT_ANY"),
+                ("issue_stall", "SQ_WAIT_INST_ANY")) if c in pmc}
+            roof["kernel_ms_under_profiler"] = round(pmc_ms, 4) if pmc_ms else None
+        hbm = {
+            # SURVEY 8(d)'s requested-bytes figure: what the rays ask for, mostly served by L1 / L2 / Infinity Cache
+            "bound": "hbm",
+            "achieved": round(req_gbs, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(req_gbs / HBM_PEAK_GBS, 4),
+            "peak_measured": legs.get("hbm_copy_gbs"),
+            "bytes_per_launch": int(launch_bytes),
+            "compulsory_bytes": legs.get("footprint", {}).get("bytes"),
+            "traffic": traffic,
+            "hbm_gbs_measured": round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None,
+            "nodes_per_ray": round(st.n_node / max(st.n_rays, 1), 3),
+            "tris_per_ray": round(st.n_tri / max(st.n_rays, 1), 3),
+            "note": "algorithmic (requested) bytes = 80 x node fetches + 48 x triangle tests + 8 x rays; this figure "
+                    "can exceed the HBM peak because coherent rays share cache lines",
+        }
         out = {
             "metric": baseline_metric(),
             "value": round(value, 2),
@@ -281,30 +463,30 @@ def main():
                 "parallelism": ("one GPU owns every 8x8 tile" if world == 1 else
                                 "8x8 tiles round-robin over %d ranks; hit shards (8 B/ray) all-gathered in place, %d frames "
                                 "per collective, and de-interleaved to row-major frames on every rank" % (world, F)),
-                "frames_in_flight": n_streams,   # kernels in flight (one per stream)
+                "frames_in_flight": n_streams,   # kernels in flight inside the timed region (one per stream)
                 "frames_per_launch": L_launch,
                 "frames_per_gather": F,
                 "build_seconds": round(build_s, 2),
+                "tile_order": "learnt from the previous frame on the same stream (static camera, as the reference "
+                              "benches); first-frame figure in legs.cold_order_ms",
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "kernel_ms": round(kernel_ms, 4),
-                "launches": len(single),
-                "frames_in_flight": 1,
-                "in_flight_kernel_ms": round(in_flight_ms, 4),
-                "bytes_per_launch": int(launch_bytes),
-                "nodes_per_ray": round(st.n_node / max(st.n_rays, 1), 3),
-                "tris_per_ray": round(st.n_tri / max(st.n_rays, 1), 3),
-                "valu_issue_frac": (round(valu_insts * 2.0 / (1024 * 2.4e9 * kernel_ms * 1e-3), 3) if valu_insts else None),
-                "note": "algorithmic (requested) bytes; coherent rays are served by L1/L2/Infinity Cache, "
-                        "see `traffic` (measured HBM bytes per launch) and DESIGN.md section 4",
-            },
+            "kernel_ms_mean": round(kernel_ms, 4),
+            "kernel_ms_min": round(min(launch_ms), 4),
+            "timed_region_ms": round(elapsed * 1e3, 3),
+            "roofline": roof,
+            "roofline_hbm": hbm,
+            "legs": legs,
         }
+        if world > 1 and phases:
+            torch.cuda.synchronize()
+            nf = sum(p[3] for p in phases)
+            out["phases_ms_per_frame"] = {
+                "trace": round(kernel_ms, 4),
+                "gather": round(sum(a.elapsed_time(b) for a, b, _, _ in phases) / nf, 4),
+                "assemble": round(sum(b.elapsed_time(c) for _, b, c, _ in phases) / nf, 4),
+                "collective_world_size": dist.get_world_size(),
+                "backend": dist.get_backend(),
+            }
 
     if rank == 0 and args.dump_frame:
         np.save(args.dump_frame, frame.detach().cpu().numpy())

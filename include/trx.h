@@ -315,6 +315,11 @@ int trx_debug_wave_phases(trx_scene *scene, const trx_view *view, uint32_t width
                           uint32_t semantics, uint64_t *out_records, uint32_t max_waves,
                           uint32_t *out_waves);
 
+/* Diagnostics (counting kernel): the compulsory footprint of one primary frame — how many distinct nodes were
+ * fetched and distinct triangles tested (80 * nodes + 48 * tris + 8 * rays bytes). */
+int trx_debug_footprint(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                        uint32_t semantics, uint64_t *out_nodes_touched, uint64_t *out_tris_touched);
+
 /* Diagnostics (counting kernel): over the triangle phases of one primary frame, out_hist[0..15] = histogram of the
  * largest per-lane triangle count of the wave (15 = 15 or more), out_hist[16..31] = histogram of the wave's
  * (ray, triangle) pair total in units of 8, rounded up. */

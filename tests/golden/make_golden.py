@@ -10,8 +10,10 @@ and the expected outputs, so the tests do not depend on the builder or on
 
 The `ref_*` fixtures are built from the two small OBJ assets the reference ships
 (assets/obj/cornell_box.obj, assets/obj/box.obj) with the cameras of their .ron scene
-files: they can only be regenerated where /root/reference is mounted; the fixtures
-themselves (CWBVH + f32 triangles + expected hits) travel.
+files.  The reference's licences do not cover its assets (README.md:99), so these
+fixtures hold NO geometry: only the asset's name, SHA-256 digests of the rebuilt
+buffers, the view and the expected hit buffers.  Tests rebuild the inputs from the
+mounted reference checkout and skip where it is absent.
 
 Run from the repo root:  python tests/golden/make_golden.py [name-substring ...]
 """
@@ -72,12 +74,20 @@ def ron_camera(path):
     return vec("eye"), vec("look_at"), float(re.search(r"fov:\s*([-0-9.]+)", txt).group(1))
 
 
-def save(name, flat, view, w, h, extra):
+def save(name, flat, view, w, h, extra, asset=None, use_tlas=False):
     if ONLY and not any(o in name for o in ONLY):
         return
     osc = O.Scene.from_flat(flat)
-    out = dict(nodes=flat.nodes, tri_verts=flat.tri_verts, instance_offsets=flat.instance_offsets,
-               tlas_start=np.uint32(flat.tlas_start), width=np.uint32(w), height=np.uint32(h))
+    if asset is None:
+        out = dict(nodes=flat.nodes, tri_verts=flat.tri_verts, instance_offsets=flat.instance_offsets,
+                   tlas_start=np.uint32(flat.tlas_start), width=np.uint32(w), height=np.uint32(h))
+    else:
+        # built from one of the reference's OBJ assets: the licences do not cover assets (README.md:99), so the
+        # geometry stays out of the repository; the fixture names the asset and pins the rebuilt buffers by digest
+        import hashlib
+        sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+        out = dict(asset=asset, use_tlas=np.uint32(use_tlas), n_tris=np.uint64(flat.n_tris), n_nodes=np.uint64(flat.n_nodes),
+                   tri_sha256=sha(flat.tri_verts), nodes_sha256=sha(flat.nodes), width=np.uint32(w), height=np.uint32(h))
     if view is not None:
         ov = O.view_from_bytes(view)
         out["view"] = view_bytes(view)
@@ -154,11 +164,11 @@ def main():
         verts, counts = T.load_meshs(os.path.join(REF_ASSETS, "obj", "cornell_box.obj"))
         eye, look, fov = ron_camera(os.path.join(REF_ASSETS, "scenes", "cornell_box.ron"))
         flat = T.flat_build(verts, counts)
-        save("ref_cornell_box_64", flat, T.view_from_camera(eye, look, fov, 64, 64), 64, 64, None)
+        save("ref_cornell_box_64", flat, T.view_from_camera(eye, look, fov, 64, 64), 64, 64, None, asset="cornell_box.obj")
         verts, counts = T.load_meshs(os.path.join(REF_ASSETS, "obj", "box.obj"))
         eye, look, fov = ron_camera(os.path.join(REF_ASSETS, "scenes", "box.ron"))
         flat = T.flat_build(verts, counts, use_tlas=True)
-        save("ref_box_tlas_48", flat, T.view_from_camera(eye, look, fov, 48, 48), 48, 48, None)
+        save("ref_box_tlas_48", flat, T.view_from_camera(eye, look, fov, 48, 48), 48, 48, None, asset="box.obj", use_tlas=True)
     else:
         print("reference assets not mounted: ref_* fixtures left as they are")
 

@@ -14,6 +14,31 @@ def make_scene(T, O, name, n, w, h, tlas=False, seed=1):
     return flat, view, osc, O.view_from_bytes(view)
 
 
+REF_ASSETS = "/root/reference/assets"
+
+
+def golden_inputs(T, g):
+    """(nodes, tri_verts, instance_offsets, tlas_start) of a golden fixture.  Fixtures made from the reference's own
+    OBJ assets carry no geometry ("MIT & Apache 2.0 Licenses don't apply to assets", README.md:99): only the asset's
+    name, the expected outputs and SHA-256 digests of the buffers; their inputs are rebuilt from the mounted
+    reference checkout (deterministic loader + builder) and checked against the digests, or the test is skipped."""
+    import hashlib
+    import os
+
+    import pytest
+    if "nodes" in g.files:
+        return g["nodes"], g["tri_verts"], g["instance_offsets"], int(g["tlas_start"])
+    path = os.path.join(REF_ASSETS, "obj", str(g["asset"]))
+    if not os.path.exists(path):
+        pytest.skip("fixture built from %s: the reference checkout is not mounted here" % g["asset"])
+    verts, counts = T.load_meshs(path)
+    flat = T.flat_build(verts, counts, use_tlas=bool(g["use_tlas"]))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(flat.tri_verts) == str(g["tri_sha256"]), "loader / builder no longer reproduce the fixture's triangles"
+    assert sha(flat.nodes) == str(g["nodes_sha256"]), "builder output changed: regenerate tests/golden (make_golden.py ref_)"
+    return flat.nodes, flat.tri_verts, flat.instance_offsets, flat.tlas_start
+
+
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 

@@ -9,7 +9,7 @@ import threading
 import numpy as np
 import pytest
 
-from helpers import (ALL_SEMS, F32_MAX, assert_hits_equal, bits, deep_chain_scene, make_scene, random_rays)
+from helpers import (ALL_SEMS, F32_MAX, assert_hits_equal, bits, deep_chain_scene, golden_inputs, make_scene, random_rays)
 
 pytestmark = pytest.mark.gpu
 
@@ -27,8 +27,8 @@ def need_gpu(trx):
 
 class GoldenFlat:
     def __init__(self, trx, g):
-        self.flat = trx.FlatScene(g["nodes"], g["tri_verts"], g["instance_offsets"], int(g["tlas_start"]),
-                                  np.arange(g["tri_verts"].shape[0]), [0, g["tri_verts"].shape[0]])
+        nodes, tri_verts, inst, tlas_start = golden_inputs(trx, g)
+        self.flat = trx.FlatScene(nodes, tri_verts, inst, tlas_start, np.arange(tri_verts.shape[0]), [0, tri_verts.shape[0]])
 
 
 def load_view(trx, raw):
@@ -568,7 +568,7 @@ def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
            "--warmup", "2", "--tris", "150000", "--width", "256", "--height", "136", "--dist-backend", "gloo",
-           "--dump-frame", dump, "--streams", "2", "--roofline-launches", "2", "--gather-batch", "4"]
+           "--dump-frame", dump, "--streams", "2", "--gather-batch", "4"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -576,6 +576,8 @@ def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path):
     assert d["n_gpus"] == 2 and d["value"] > 0
     assert d["scaling"] == "strong" and d["config"]["frames_in_flight"] == 2
     assert d["config"]["frames_per_gather"] == 4   # 6 timed frames = one full batch + a partial one
+    ph = d["phases_ms_per_frame"]                    # per-phase times of the N > 1 loop
+    assert ph["collective_world_size"] == 2 and ph["trace"] > 0 and ph["gather"] > 0 and ph["assemble"] > 0
     g = np.load(dump + ".scene.npz")
     osc = orc.Scene(g["nodes"], g["tri_verts"], g["instance_offsets"], int(g["tlas_start"]))
     want, _ = osc.trace_primary(orc.view_from_bytes(g["view"].tobytes()), int(g["width"]), int(g["height"]), sem=3)

@@ -7,14 +7,16 @@ import os
 import numpy as np
 import pytest
 
-from helpers import ALL_SEMS, F32_MAX, assert_hits_equal, bits, make_scene, random_rays
+from helpers import ALL_SEMS, F32_MAX, assert_hits_equal, bits, golden_inputs, make_scene, random_rays
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def load_golden(O, name):
+    import tray_racing_amd as T
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    osc = O.Scene(g["nodes"], g["tri_verts"], g["instance_offsets"], int(g["tlas_start"]))
+    nodes, tri_verts, inst, tlas_start = golden_inputs(T, g)
+    osc = O.Scene(nodes, tri_verts, inst, tlas_start)
     return g, osc
 
 

@@ -112,6 +112,7 @@ SIGNATURES = {
     "trx_set_kernel_variant": (_u32, [_u32]),
     "trx_debug_tile_profile": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, _P, _u32]),
     "trx_debug_wave_timeline": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, _u32, C.POINTER(_u32)]),
+    "trx_debug_footprint": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "trx_debug_tri_histogram": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P]),
     "trx_debug_wave_phases": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, _u32, C.POINTER(_u32)]),
     "trx_shard_tiles": (_u32, [_u32, _u32, Shard]),

@@ -205,7 +205,7 @@ float half_to_float(uint16_t h) {
     return f;
 }
 
-// Any accepted input format -> 48-byte device record {v0, e1 = v0 - v1, e2 = v2 - v0}.
+// Any accepted input format -> 48-byte device record {v0, e1 = v0 - v1, e2 = v2 - v0, ng = e1 x e2 in the w lanes}.
 void convert_tris(const void *src, uint64_t n, uint32_t fmt, TriDev *dst) {
     const uint8_t *b = (const uint8_t *)src;
     for (uint64_t i = 0; i < n; i++) {
@@ -235,6 +235,9 @@ void convert_tris(const void *src, uint64_t n, uint32_t fmt, TriDev *dst) {
                 }
             }
         }
+        t.ngx = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1];
+        t.ngy = t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2];
+        t.ngz = t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0];
         dst[i] = t;
     }
 }
@@ -778,6 +781,43 @@ int trx_count_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h
     rc = enqueue(s, p, kModePrimary, sem, true, nullptr, &ctr);
     if (rc) return rc;
     return finish_count(s, ctr, stats);
+}
+
+// Compulsory footprint of one primary frame: distinct nodes fetched and distinct triangles tested.
+int trx_debug_footprint(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint64_t *out_nodes,
+                        uint64_t *out_tris) {
+    if (!s || !out_nodes || !out_tris) return fail(TRX_ERR_INVALID, "null argument");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu);
+    HIP_TRY(hipSetDevice(s->device));
+    TraceParams p;
+    std::memset(&p, 0, sizeof(p));
+    int rc = image_params(p, view, w, h, trx_shard{0, 1, 0, 0});
+    if (rc) return rc;
+    rc = ensure_scratch(s, (uint64_t)w * h, 0);
+    if (rc) return rc;
+    p.out = s->d_scratch_a;
+    const size_t nb = s->n_nodes, tb = std::max<uint64_t>(s->n_tris, 1);
+    uint8_t *d_marks = nullptr;
+    HIP_TRY(hipMalloc(&d_marks, nb + tb));
+    hipError_t e = hipMemset(d_marks, 0, nb + tb);
+    p.touch_nodes = d_marks;
+    p.touch_tris = d_marks + nb;
+    SlotCounters *ctr = nullptr;
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipEventRecord(s->ev0, nullptr);
+    if (e == hipSuccess) rc = enqueue(s, p, kModePrimary, sem, true, nullptr, &ctr);
+    if (e == hipSuccess && !rc) rc = finish_count(s, ctr, nullptr);
+    std::vector<uint8_t> host(nb + tb);
+    if (e == hipSuccess && !rc) e = hipMemcpy(host.data(), d_marks, nb + tb, hipMemcpyDeviceToHost);
+    (void)hipFree(d_marks);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(TRX_ERR_NO_DEVICE, "footprint pass failed: %s", hipGetErrorString(e));
+    uint64_t n = 0, t = 0;
+    for (size_t i = 0; i < nb; i++) n += host[i] != 0;
+    for (size_t i = 0; i < s->n_tris; i++) t += host[nb + i] != 0;
+    *out_nodes = n;
+    *out_tris = t;
+    return TRX_OK;
 }
 
 int trx_debug_tri_histogram(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint32_t out_hist[32]) {

@@ -29,14 +29,17 @@ static_assert(sizeof(CwbvhNode) == 80, "CWBVH node must be 80 bytes");
 
 // Device triangle record: 48 B = 3 x float4 so one triangle is three
 // global_load_dwordx4.  e1 = v0 - v1, e2 = v2 - v0 (the sign convention used
-// inside intersect_ray_tri, query.hlsl:91-93).  Padding lanes are zero.
+// inside intersect_ray_tri, query.hlsl:91-93).  The w lanes carry ng = cross(e1, e2)
+// (query.hlsl:93), which does not depend on the ray: computed once at upload with the
+// kernel's own operation order (separate multiplies and subtract, no contraction), so
+// the value is bit-identical to recomputing it per test as the HLSL does.
 struct TriDev {
     float v0[3];
-    float pad0;
+    float ngx;
     float e1[3];
-    float pad1;
+    float ngy;
     float e2[3];
-    float pad2;
+    float ngz;
 };
 static_assert(sizeof(TriDev) == 48, "device triangle must be 48 bytes");
 

@@ -80,6 +80,7 @@ struct TraceParams {
     uint32_t lpt_cap;
     uint32_t *cost;         // diagnostics: per-tile cost (wall-clock ticks), or null
     uint32_t prio_cut[3];   // chunks below these (heaviest-first) indices run at s_setprio 3 / 2 / 1
+    uint8_t *touch_nodes, *touch_tris; // diagnostics (COUNT kernels): byte set per node fetched / triangle tested, or null
     uint32_t *tile_iters;   // diagnostics (COUNT kernels): per tile (node steps << 16) | triangle rounds
     uint32_t frame;
     float ao_eps;

@@ -26,6 +26,9 @@
 #ifndef TRX_NODE_UNROLL
 #define TRX_NODE_UNROLL 2
 #endif
+#ifndef TRX_TRI_PAIRS
+#define TRX_TRI_PAIRS 1 // per-lane triangle rounds test two triangles at once with packed f32 math
+#endif
 
 #pragma clang fp contract(off)
 
@@ -141,14 +144,13 @@ __device__ __forceinline__ uint32_t node_intersect(const Ray &r, float max_dista
     return hit_mask;
 }
 
-// TriDev = {v0, e1 = v0 - v1, e2 = v2 - v0} as three float4.
+// TriDev = {v0, e1 = v0 - v1, e2 = v2 - v0} as three float4; ng = cross(e1, e2) (query.hlsl:93) rides in the
+// w lanes, evaluated at upload exactly as written there.
 __device__ __forceinline__ bool intersect_tri(const Ray &r, const float4 a, const float4 b, const float4 c4,
                                               float &t, bool tie_first) {
     const float e1x = b.x, e1y = b.y, e1z = b.z;
     const float e2x = c4.x, e2y = c4.y, e2z = c4.z;
-    const float ngx = e1y * e2z - e1z * e2y;
-    const float ngy = e1z * e2x - e1x * e2z;
-    const float ngz = e1x * e2y - e1y * e2x;
+    const float ngx = a.w, ngy = b.w, ngz = c4.w;
     const float cx = a.x - r.ox, cy = a.y - r.oy, cz = a.z - r.oz;
     const float rx = r.dy * cz - r.dz * cy;
     const float ry = r.dz * cx - r.dx * cz;
@@ -167,6 +169,34 @@ __device__ __forceinline__ bool intersect_tri(const Ray &r, const float4 a, cons
         }
     }
     return false;
+}
+
+// Two triangles against one ray with packed f32 math (v_pk_mul_f32 / v_pk_add_f32 are two IEEE operations
+// each): component k of every value is exactly what intersect_tri computes for triangle k.  Returns tt
+// (untested against t) and whether the barycentric / determinant test accepted it.
+__device__ __forceinline__ void intersect_tri2(const Ray &r, const float4 a0, const float4 b0, const float4 c0,
+                                               const float4 a1, const float4 b1, const float4 c1, f32x2 &tt, bool &ok0,
+                                               bool &ok1) {
+    const f32x2 e1x = {b0.x, b1.x}, e1y = {b0.y, b1.y}, e1z = {b0.z, b1.z};
+    const f32x2 e2x = {c0.x, c1.x}, e2y = {c0.y, c1.y}, e2z = {c0.z, c1.z};
+    const f32x2 ngx = {a0.w, a1.w}, ngy = {b0.w, b1.w}, ngz = {c0.w, c1.w};
+    const f32x2 ox = {r.ox, r.ox}, oy = {r.oy, r.oy}, oz = {r.oz, r.oz};
+    const f32x2 dx = {r.dx, r.dx}, dy = {r.dy, r.dy}, dz = {r.dz, r.dz};
+    const f32x2 cx = f32x2{a0.x, a1.x} - ox, cy = f32x2{a0.y, a1.y} - oy, cz = f32x2{a0.z, a1.z} - oz;
+    const f32x2 rx = dy * cz - dz * cy;
+    const f32x2 ry = dz * cx - dx * cz;
+    const f32x2 rz = dx * cy - dy * cx;
+    const f32x2 det = (ngx * dx + ngy * dy) + ngz * dz;
+    const f32x2 inv_det = {1.0f / det.x, 1.0f / det.y};
+    const f32x2 u = ((rx * e2x + ry * e2y) + rz * e2z) * inv_det;
+    const f32x2 v = ((rx * e1x + ry * e1y) + rz * e1z) * inv_det;
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 w = one - u - v;
+    tt = ((ngx * cx + ngy * cy) + ngz * cz) * inv_det;
+    const uint32_t h0 = __float_as_uint(u.x) | __float_as_uint(v.x) | __float_as_uint(w.x);
+    const uint32_t h1 = __float_as_uint(u.y) | __float_as_uint(v.y) | __float_as_uint(w.y);
+    ok0 = inv_det.x != 0.0f && (h0 & 0x80000000u) == 0;
+    ok1 = inv_det.y != 0.0f && (h1 & 0x80000000u) == 0;
 }
 
 __device__ __forceinline__ void finish_ray_dir(Ray &r, float dx, float dy, float dz) {
@@ -498,10 +528,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             if (ph.t < TRX_F32_MAX && ph.prim != TRX_INVALID) {
                                 // normal of the hit triangle, flipped toward the viewer
                                 const float4 *tp = P.tris + (size_t)ph.prim * 3;
-                                const float4 b = tp[1], c4 = tp[2];
-                                float nx = b.y * c4.z - b.z * c4.y;
-                                float ny = b.z * c4.x - b.x * c4.z;
-                                float nz = b.x * c4.y - b.y * c4.x;
+                                float nx = tp[0].w, ny = tp[1].w, nz = tp[2].w; // cross(e1, e2)
                                 const float ninv = 1.0f / sqrtf(dot3(nx, ny, nz, nx, ny, nz));
                                 nx *= ninv; ny *= ninv; nz *= ninv;
                                 const float nd = (nx * -dx + ny * -dy) + nz * -dz;
@@ -594,6 +621,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     if (COUNT) {
                         c_node++;
                         if (lane_rank(__ballot(1)) == 0) c_wnode++;
+                        if (P.touch_nodes) P.touch_nodes[node_index] = 1;
                     }
                     const uint32_t hitmask = node_intersect<NODE>(r, t, n0, n1, n2, n3, n4);
                     cur.x = n1.x;
@@ -661,6 +689,37 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     coop = mx > P.tri_coop_ratio * ((total + 63u) >> 6);
                 }
                 if (!coop) {
+#if TRX_TRI_PAIRS
+                    // per-lane rounds, two triangles at a time (highest bit first, committed in that order)
+                    while (tri.y != 0u) {
+                        const uint32_t l0 = 31u - (uint32_t)__clz((int)tri.y);
+                        tri.y &= ~(1u << l0);
+                        const bool two = tri.y != 0u;
+                        const uint32_t l1 = two ? 31u - (uint32_t)__clz((int)tri.y) : l0;
+                        tri.y &= ~(1u << l1);
+                        const uint32_t g0 = tri.x + l0, g1 = tri.x + l1;
+                        const float4 *tp0 = P.tris + (size_t)g0 * 3, *tp1 = P.tris + (size_t)g1 * 3;
+                        float4 a0 = tp0[0], b0 = tp0[1], c0 = tp0[2], a1 = tp1[0], b1 = tp1[1], c1 = tp1[2];
+                        asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w), "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(c0.x), "+v"(c0.y), "+v"(c0.z), "+v"(c0.w));
+                        asm volatile("" : "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w), "+v"(c1.x), "+v"(c1.y), "+v"(c1.z), "+v"(c1.w));
+                        if (COUNT) {
+                            c_tri += two ? 2u : 1u;
+                            if (lane_rank(__ballot(1)) == 0) c_wtri++;
+                            if (P.touch_tris) P.touch_tris[g0] = P.touch_tris[g1] = 1;
+                        }
+                        f32x2 tt;
+                        bool ok0, ok1;
+                        intersect_tri2(r, a0, b0, c0, a1, b1, c1, tt, ok0, ok1);
+                        if (ok0 && tt.x >= r.tmin && (tie_first ? (tt.x < t) : (tt.x <= t))) {
+                            t = tt.x;
+                            prim = g0;
+                        }
+                        if (two && ok1 && tt.y >= r.tmin && (tie_first ? (tt.y < t) : (tt.y <= t))) {
+                            t = tt.y;
+                            prim = g1;
+                        }
+                    }
+#else
                     while (tri.y != 0u) {
                         const uint32_t local = 31u - (uint32_t)__clz((int)tri.y);
                         tri.y &= ~(1u << local);
@@ -669,13 +728,15 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         float4 a = tp[0], b = tp[1], c4 = tp[2];
                         // keep the three 16-byte loads together: left alone the compiler sinks the v0
                         // load behind the determinant, serialising two memory latencies per triangle
-                        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c4.x), "+v"(c4.y), "+v"(c4.z));
+                        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c4.x), "+v"(c4.y), "+v"(c4.z), "+v"(c4.w));
                         if (COUNT) {
                             c_tri++;
                             if (lane_rank(__ballot(1)) == 0) c_wtri++;
+                            if (P.touch_tris) P.touch_tris[gidx] = 1;
                         }
                         if (intersect_tri(r, a, b, c4, t, tie_first)) prim = gidx;
                     }
+#endif
                 } else {
                     const uint32_t excl = incl - cnt;
                     lds_grp[lane] = tri;
@@ -697,10 +758,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             uint32_t m = grp.y;
                             for (uint32_t j = g - lds_pref[ol]; j > 0u; j--) m &= ~(1u << (31u - (uint32_t)__clz((int)m)));
                             const uint32_t gidx = grp.x + (31u - (uint32_t)__clz((int)m));
+                            if (COUNT && P.touch_tris) P.touch_tris[gidx] = 1;
                             const float4 *tp = P.tris + (size_t)gidx * 3;
                             float4 a = tp[0], b = tp[1], c4 = tp[2];
                             const float4 ro = lds_ray[2u * ol], rd = lds_ray[2u * ol + 1u];
-                            asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c4.x), "+v"(c4.y), "+v"(c4.z));
+                            asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c4.x), "+v"(c4.y), "+v"(c4.z), "+v"(c4.w));
                             Ray orr;
                             orr.ox = ro.x; orr.oy = ro.y; orr.oz = ro.z; orr.tmin = ro.w;
                             orr.dx = rd.x; orr.dy = rd.y; orr.dz = rd.z;

@@ -254,6 +254,12 @@ class Scene:
                                             C.byref(st)))
         return st
 
+    def footprint(self, view, width, height, sem=L.SEM_HLSL):
+        """(distinct nodes fetched, distinct triangles tested) by one primary frame."""
+        n, t = C.c_uint64(), C.c_uint64()
+        L.check(self._lib.trx_debug_footprint(self._h, C.byref(view), width, height, sem, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
     def bench_primary(self, view, width, height, sem=L.SEM_HLSL, warmup=1, frames=20):
         mn, mean = C.c_float(), C.c_float()
         L.check(self._lib.trx_bench_primary(self._h, C.byref(view), width, height, sem, warmup, frames, C.byref(mn),
