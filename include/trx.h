@@ -193,7 +193,8 @@ int trx_scene_create(const void *bvh_bytes, uint64_t n_nodes,
                      const uint32_t *instance_offsets, uint32_t n_instances,
                      uint32_t tlas_start, int device, trx_scene **out);
 void trx_scene_destroy(trx_scene *scene);
-/* Bytes resident in HBM for this scene (nodes + 48-byte triangles + instances). */
+/* Bytes resident in HBM for this scene: nodes + 48-byte triangles + instances + what the launch slots used so far
+ * hold (stack spill areas sized for the launched grids, tile-order lists). */
 uint64_t trx_scene_device_bytes(const trx_scene *scene);
 int trx_scene_device(const trx_scene *scene);
 
@@ -272,7 +273,12 @@ int trx_scene_check(trx_scene *scene, void *stream);
 
 /* Re-entrancy: the *_dev entry points and trx_traverse1 may be called concurrently on one scene
  * (launch slots); the synchronous entry points below, trx_count_* and trx_bench_primary share
- * per-scene scratch buffers and are serialised by a per-scene lock. */
+ * per-scene scratch buffers and are serialised by a per-scene lock.
+ * Process-wide settings: the builder knobs (trx_set_build_*) live behind one mutex and every build works on
+ * the snapshot it took when it started, so setters and builds may run concurrently (a setter only affects
+ * builds that start after it returns); trx_flat_build_params never touches them.  trx_set_kernel_variant is a
+ * single atomic word read once per launch — a tuning aid: concurrent launches may see either value, results are
+ * identical under every value. */
 
 /* ---- tracing: host-buffer convenience (synchronous) --------------------------
  * What rt_gpu_software::start returns to its caller is a time in ms
@@ -290,7 +296,11 @@ int trx_trace_rays(trx_scene *scene, const trx_ray *rays, uint64_t n_rays,
 /* Host-buffer form of trx_trace_occluded_dev. */
 int trx_trace_occluded(trx_scene *scene, const trx_ray *rays, uint64_t n_rays, uint32_t semantics,
                        uint8_t *out_flags, float *out_ms);
-/* Single-ray Traversable::traverse; a batch of one on the device. */
+/* Single-ray Traversable::traverse; a batch of one on the device.  primitive_id indexes the PERMUTED triangle
+ * list of the hit BLAS (primitive_indices order), exactly like the reference, whose scene structs store their
+ * triangles in that order (src/rt_cpu/mod.rs:38-43) and index them with RayHit.primitive_id
+ * (src/cwbvh.rs:151-160,177-186); trx_flat.tri_source[blas_tri_start[g] + primitive_id] names the input
+ * triangle (with pre-splitting several entries can name the same one). */
 int trx_traverse1(trx_scene *scene, const trx_ray *ray, uint32_t semantics,
                   trx_rayhit *out);
 

@@ -135,3 +135,53 @@ def test_header_is_plain_c_and_the_library_links_from_c(trx, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stderr)
     assert out.stdout.startswith("objects 5 triangles")
+
+
+def _c_prototypes():
+    """name -> number of parameters, for every function include/trx.h declares."""
+    text = open(os.path.join(ROOT, "include", "trx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(trx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return protos, text
+
+
+def _c_struct_fields(text, name):
+    m = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S)
+    assert m, name
+    n = 0
+    for decl in m.group(1).split(";"):
+        decl = decl.strip()
+        if decl:
+            n += 1   # one declarator per field in this header (arrays count as one field, as in the Rust struct)
+    return n
+
+
+def test_integration_md_matches_the_header():
+    """The Rust binding shown in INTEGRATION.md cannot be compiled here (no Rust toolchain), so it is checked
+    mechanically: every function of its extern "C" block exists in include/trx.h with the same number of
+    parameters, every trx_* type it uses is declared in the document, and every #[repr(C)] struct it declares has
+    as many fields as the header's struct."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rust = "\n".join(re.findall(r"```rust\n(.*?)```", md, flags=re.S))
+    protos, header = _c_prototypes()
+    ext = re.search(r'extern "C" \{(.*?)\n\}', rust, flags=re.S).group(1)
+    ext = re.sub(r"//[^\n]*", "", ext)
+    fns = re.findall(r"pub fn (trx_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", ext, flags=re.S)
+    assert len(fns) >= 15
+    for name, args in fns:
+        assert name in protos, "%s is not declared in include/trx.h" % name
+        n = 0 if not args.strip() else args.count(":")
+        assert n == protos[name], "%s: %d parameters in INTEGRATION.md, %d in trx.h" % (name, n, protos[name])
+    structs = dict(re.findall(r"pub struct (trx_[a-z0-9_]+)\s*\{(.*?)\}", rust, flags=re.S))
+    used = set(re.findall(r"\b(trx_[a-z0-9_]+)\b", re.sub(r"pub fn trx_[a-z0-9_]+", "", ext)))
+    assert used <= set(structs), "types used but not declared in INTEGRATION.md: %s" % sorted(used - set(structs))
+    for name, body in structs.items():
+        if "_private" in body:
+            continue   # opaque handle
+        assert body.count(":") - body.count("::") * 2 == _c_struct_fields(header, name), name
+    # every call the shim makes through ffi:: is bound
+    called = set(re.findall(r"ffi::(trx_[a-z0-9_]+)\s*\(", rust))
+    assert called <= {n for n, _ in fns}, sorted(called - {n for n, _ in fns})

@@ -214,6 +214,24 @@ def test_image_sizes_not_multiple_of_8(trx, orc, w, h):
     sc.close()
 
 
+def test_counting_pass_into_internal_scratch_with_a_shard_layout(trx, orc):
+    """trx_count_primary with d_hits == NULL writes into the scene's scratch buffer; in the compact shard layout
+    that is whole tiles (local_tile * 64 + k), more records than w * h when the image ends mid-tile (9 x 9:
+    4 tiles = 256 records for 81 pixels).  Counters must still equal the oracle's for every shard."""
+    w, h = 9, 9
+    flat, view, osc, ov = make_scene(trx, orc, "cornell", 0, w, h)
+    sc = trx.Scene(flat)
+    _, want = osc.trace_primary(ov, w, h, sem=3)
+    for world in (1, 2, 3):
+        n_node = n_tri = n_rays = 0
+        for r in range(world):
+            st = sc.count_primary(view, w, h, sem=3, shard=(r, world, 1))
+            n_node, n_tri, n_rays = n_node + st.n_node, n_tri + st.n_tri, n_rays + st.n_rays
+        assert (n_rays, n_node, n_tri) == (w * h, want.n_node, want.n_tri)
+    sc.check()
+    sc.close()
+
+
 # ---- edge cases -------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 5])

@@ -298,7 +298,11 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     if (wpb != 1 && wpb != 2 && wpb != 4) wpb = kDefaultWavesPerBlock;
     const uint32_t per_cu = (variant >> 8) & 0xffu;
     int grid = per_cu ? (int)(std::min(per_cu, 32u) * (uint32_t)s->cu_count) : s->grid;
-    grid = std::max((int)wpb, grid / (int)wpb * (int)wpb);
+    // no more waves than chunks of work: a batch of one ray (trx_traverse1) is a one-wave launch with a
+    // one-wave spill area
+    const uint64_t n_chunks = ((uint64_t)p.n_items + 63u) >> 6;
+    if ((uint64_t)grid > n_chunks) grid = (int)std::max<uint64_t>(n_chunks, 1);
+    grid = std::max((int)wpb, (grid + (int)wpb - 1) / (int)wpb * (int)wpb);
     if (!slot.ctr) {
         // all or nothing: a slot is either fully usable or untouched
         SlotCounters *ctr = nullptr;
@@ -570,7 +574,15 @@ void trx_scene_destroy(trx_scene *s) {
 
 uint64_t trx_scene_device_bytes(const trx_scene *s) {
     if (!s) return 0;
-    return s->n_nodes * TRX_NODE_BYTES + s->n_tris * sizeof(TriDev) + (uint64_t)s->n_inst * 4;
+    uint64_t bytes = s->n_nodes * TRX_NODE_BYTES + s->n_tris * sizeof(TriDev) + (uint64_t)s->n_inst * 4;
+    // launch slots claimed so far: stack spill areas and tile-order lists
+    std::lock_guard<std::mutex> lock(const_cast<trx_scene *>(s)->mu);
+    for (const Slot &sl : s->slots) {
+        bytes += (uint64_t)sl.spill_waves * kSpillStack * kWave * sizeof(uint2);
+        if (sl.lpt) bytes += 2ull * (16 * kLptShards + (uint64_t)16 * kLptShards * (sl.lpt_capacity / 2 + 64)) * sizeof(uint32_t);
+        if (sl.ctr) bytes += sizeof(SlotCounters);
+    }
+    return bytes;
 }
 int trx_scene_device(const trx_scene *s) { return s ? s->device : -1; }
 
@@ -965,29 +977,62 @@ int trx_trace_occluded(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t s
     return trx_scene_check(s, nullptr);
 }
 
+namespace {
+// One stream + one {ray, hit} device pair per calling thread and device: a thread's successive single-ray
+// queries reuse them (and therefore one launch slot), concurrent threads never share them (Traversable: Sync).
+struct ThreadRayLane {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    trx_ray *d_ray = nullptr;
+    trx_hit *d_hit = nullptr;
+};
+struct ThreadRayLanes {
+    std::vector<ThreadRayLane> lanes;
+    ~ThreadRayLanes() {
+        for (ThreadRayLane &l : lanes) {
+            if (hipSetDevice(l.device) != hipSuccess) continue;
+            if (l.stream) (void)hipStreamDestroy(l.stream);
+            if (l.d_ray) (void)hipFree(l.d_ray);
+            if (l.d_hit) (void)hipFree(l.d_hit);
+        }
+    }
+};
+thread_local ThreadRayLanes t_ray_lanes;
+
+int thread_ray_lane(int device, ThreadRayLane **out) {
+    for (ThreadRayLane &l : t_ray_lanes.lanes)
+        if (l.device == device) {
+            *out = &l;
+            return TRX_OK;
+        }
+    ThreadRayLane l;
+    l.device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    hipError_t e = hipMalloc(&l.d_ray, sizeof(trx_ray));
+    if (e == hipSuccess) e = hipMalloc(&l.d_hit, sizeof(trx_hit));
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(l.stream);
+        if (l.d_ray) (void)hipFree(l.d_ray);
+        return fail(TRX_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    t_ray_lanes.lanes.push_back(l);
+    *out = &t_ray_lanes.lanes.back();
+    return TRX_OK;
+}
+} // namespace
+
 int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *out) {
     if (!s || !ray || !out) return fail(TRX_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(s->device));
-    // private buffers so concurrent callers do not share scratch (Traversable: Sync)
-    trx_ray *d_ray = nullptr;
-    trx_hit *d_hit = nullptr;
-    HIP_TRY(hipMalloc(&d_ray, sizeof(trx_ray)));
-    hipError_t e = hipMalloc(&d_hit, sizeof(trx_hit));
-    if (e != hipSuccess) {
-        (void)hipFree(d_ray);
-        return fail(TRX_ERR_OOM, "hipMalloc failed");
-    }
-    hipStream_t st = nullptr;
+    ThreadRayLane *lane = nullptr;
+    int rc = thread_ray_lane(s->device, &lane);
+    if (rc) return rc;
+    hipStream_t st = lane->stream;
     trx_hit h{};
-    int rc = TRX_OK;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "stream create failed");
-    if (!rc && hipMemcpyAsync(d_ray, ray, sizeof(trx_ray), hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "copy failed");
-    if (!rc) rc = trace_rays_impl(s, d_ray, 1, sem, d_hit, st, false, nullptr);
-    if (!rc && hipMemcpyAsync(&h, d_hit, sizeof(trx_hit), hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "copy failed");
+    if (hipMemcpyAsync(lane->d_ray, ray, sizeof(trx_ray), hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "copy failed");
+    if (!rc) rc = trace_rays_impl(s, lane->d_ray, 1, sem, lane->d_hit, st, false, nullptr);
+    if (!rc && hipMemcpyAsync(&h, lane->d_hit, sizeof(trx_hit), hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "copy failed");
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "sync failed");
-    if (st) (void)hipStreamDestroy(st);
-    (void)hipFree(d_ray);
-    (void)hipFree(d_hit);
     if (rc) return rc;
     out->t = h.t;
     out->instance_id = 0xFFFFFFFFu;
