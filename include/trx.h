@@ -204,6 +204,23 @@ int trx_scene_device(const trx_scene *scene);
  * (src/cwbvh.rs:151-160). */
 int trx_scene_set_geometry_ranges(trx_scene *scene, const uint32_t *blas_tri_start, uint32_t n_blas);
 
+/* ---- instance transforms (TLAS scenes) ----------------------------------------
+ * The reference's TLAS path carries no transforms yet: "TODO transform ray according to the mesh transform"
+ * (src/rt_gpu/rt_gpu_software_query_tlas.hlsl:409,433), "TODO Reset Ray to untransformed version" (:484), and
+ * Traversable::get_instance_transform returns Mat4::default() (traversable/src/lib.rs:25-27, src/cwbvh.rs:163-165).
+ * Here an instance is a TLAS primitive (entry k of instance_offsets): it may place its BLAS anywhere, and several
+ * instances may share one BLAS.  object_to_world: n_instances column-major 4x4 affine matrices (glam Mat4 layout,
+ * last row 0 0 0 1) in instance_offsets order; NULL / 0 restores identity.  On BLAS entry the ray is taken into
+ * object space by the inverse (computed in double, rounded once to f32; origin as a point, direction as a vector,
+ * NOT renormalised, so hit.t stays in world units); on exit the world ray is restored.  The TLAS node boxes handed
+ * to trx_scene_create must bound the TRANSFORMED instances (trx_flat_build_instanced does that).  With no
+ * transforms set the kernels behave exactly as before. */
+int trx_scene_set_instance_transforms(trx_scene *scene, const float *object_to_world, uint32_t n_instances);
+/* Traversable::get_instance_transform: the matrix given above, or identity. */
+int trx_scene_get_instance_transform(const trx_scene *scene, uint32_t instance_id, float out_object_to_world[16]);
+/* The world-to-object rows the kernels use: 3 rows of {m0 m1 m2 t}; x' = ((m0*x + m1*y) + m2*z) + t. */
+int trx_scene_get_instance_world_to_object(const trx_scene *scene, uint32_t instance_id, float out_rows[12]);
+
 /* ---- camera ---------------------------------------------------------------
  * ViewUniform::from_camera (src/main.rs:602-616): proj_inv =
  * inverse(perspective_infinite_reverse_rh(fov_deg->rad, w/h, 0.01)),
@@ -222,6 +239,11 @@ int trx_view_from_camera(const float eye[3], const float look_at[3], float fov_d
 int trx_trace_primary_dev(trx_scene *scene, const trx_view *view, uint32_t width,
                           uint32_t height, trx_shard shard, uint32_t semantics,
                           trx_hit *d_hits, void *stream);
+
+/* The same with the instance (TLAS primitive index, RayHit.instance_id; 0xFFFFFFFF for a miss or a scene without
+ * TLAS) each hit was found in: d_inst has one u32 per record, indexed like d_hits; may be NULL. */
+int trx_trace_primary_inst_dev(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                               trx_shard shard, uint32_t semantics, trx_hit *d_hits, uint32_t *d_inst, void *stream);
 
 /* n_frames (1..TRX_MAX_BATCH_FRAMES) primary frames in ONE launch: frame f is traced with views[f] and its
  * records go to d_hits + f * frame_stride (in trx_hit records; frame_stride >= one frame's records for the
@@ -244,10 +266,21 @@ int trx_trace_ao_dev(trx_scene *scene, const trx_view *view, uint32_t width,
                      uint32_t height, trx_shard shard, uint32_t semantics, uint32_t frame,
                      float ao_eps, const trx_hit *d_primary, trx_hit *d_ao, void *stream);
 
+/* AO pass with instance ids: d_primary_inst (from trx_trace_primary_inst_dev) is REQUIRED when the scene has
+ * instance transforms — the hit triangle's normal lives in object space and is taken to world space by the
+ * transpose of the instance's world-to-object matrix; d_ao_inst may be NULL. */
+int trx_trace_ao_inst_dev(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height, trx_shard shard,
+                          uint32_t semantics, uint32_t frame, float ao_eps, const trx_hit *d_primary,
+                          const uint32_t *d_primary_inst, trx_hit *d_ao, uint32_t *d_ao_inst, void *stream);
+
 /* Batch form of Traversable::traverse (traversable/src/lib.rs:13-28):
  * n explicit rays -> n hits. */
 int trx_trace_rays_dev(trx_scene *scene, const trx_ray *d_rays, uint64_t n_rays,
                        uint32_t semantics, trx_hit *d_hits, void *stream);
+
+/* ... with the instance of every hit (d_inst: n u32, may be NULL). */
+int trx_trace_rays_inst_dev(trx_scene *scene, const trx_ray *d_rays, uint64_t n_rays, uint32_t semantics,
+                            trx_hit *d_hits, uint32_t *d_inst, void *stream);
 
 /* Any-hit query — the reference's `intersects_bl_bvh` (query.hlsl:440-445; "Actual AO could use a faster
  * anyhit query", src/rt_cpu/rt_cpu.rs:78-79): one byte per ray, 1 if some triangle is hit inside
@@ -293,6 +326,13 @@ int trx_trace_primary_ao(trx_scene *scene, const trx_view *view, uint32_t width,
                          trx_hit *out_primary, trx_hit *out_ao, float *out_ms);
 int trx_trace_rays(trx_scene *scene, const trx_ray *rays, uint64_t n_rays,
                    uint32_t semantics, trx_hit *out_hits, float *out_ms);
+/* The same with RayHit.instance_id per hit (u32 arrays, any of them may be NULL; all 0xFFFFFFFF without a TLAS).
+ * These are the forms to use on scenes with instance transforms: the AO pass is fed the primary pass's ids. */
+int trx_trace_primary_ao_inst(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                              uint32_t semantics, uint32_t frame, float ao_eps, trx_hit *out_primary,
+                              uint32_t *out_primary_inst, trx_hit *out_ao, uint32_t *out_ao_inst, float *out_ms);
+int trx_trace_rays_inst(trx_scene *scene, const trx_ray *rays, uint64_t n_rays, uint32_t semantics,
+                        trx_hit *out_hits, uint32_t *out_inst, float *out_ms);
 /* Host-buffer form of trx_trace_occluded_dev. */
 int trx_trace_occluded(trx_scene *scene, const trx_ray *rays, uint64_t n_rays, uint32_t semantics,
                        uint8_t *out_flags, float *out_ms);
@@ -411,10 +451,21 @@ typedef struct trx_flat {
     double tlas_build_s;
     float *tri_boxes;        /* n_tris * 6 floats (min xyz, max xyz): the box each triangle entry was built with —
                               * its own, or the clipped part a pre-split reference covers (trx_set_build_split) */
+    uint32_t *instance_source;   /* n_instances: which of the caller's objects (trx_flat_build) or instances
+                                  * (trx_flat_build_instanced) TLAS primitive k is */
+    float *instance_transforms;  /* n_instances * 16 (object-to-world, column-major) in TLAS-primitive order, ready for
+                                  * trx_scene_set_instance_transforms; NULL when no transforms were given */
 } trx_flat;
 int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects,
                    int use_tlas, uint32_t max_prims_per_leaf, int threads, trx_flat **out);
 void trx_flat_destroy(trx_flat *flat);
+/* One BLAS per object and a TLAS over n_instances INSTANCES of them (true instancing: several instances may name
+ * the same object).  instance_object[k] = object of instance k; instance_object_to_world = n_instances column-major
+ * affine 4x4 matrices (NULL = all identity).  TLAS boxes bound the transformed BLAS boxes.  The result's
+ * instance_offsets / instance_transforms / instance_source are in TLAS-primitive order. */
+int trx_flat_build_instanced(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects,
+                             const uint32_t *instance_object, const float *instance_object_to_world,
+                             uint32_t n_instances, uint32_t max_prims_per_leaf, int threads, trx_flat **out);
 
 /* The reference's BvhBuildParams (src/main.rs:571-585), field for field, for callers that carry one around.
  * The stand-in builder honours pre_split, reinsertion_batch_ratio, max_prims_per_leaf and

@@ -27,7 +27,8 @@ class View(C.Structure):
 
 class SceneC(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_uint64), ("tris", C.c_void_p), ("n_tris", C.c_uint64),
-                ("instance_offsets", C.c_void_p), ("n_instances", C.c_uint32), ("tlas_start", C.c_uint32)]
+                ("instance_offsets", C.c_void_p), ("n_instances", C.c_uint32), ("tlas_start", C.c_uint32),
+                ("instance_w2o", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -71,6 +72,13 @@ def load():
         "orc_trace_primary": (None, [SP, VP, u32, u32, u32, u32, u32, i, P, STP]),
         "orc_trace_ao": (None, [SP, VP, u32, u32, u32, u32, u32, u32, f, i, P, P, STP]),
         "orc_trace_rays": (None, [SP, P, u64, u32, i, P, STP]),
+        "orc_traverse_inst": (HitC, [SP, P, P, f, f, u32, STP, P]),
+        "orc_ao_ray_inst": (i, [SP, VP, u32, u32, u32, u32, HitC, u32, u32, f, P, P]),
+        "orc_xform_point": (None, [P, P, P]),
+        "orc_xform_dir": (None, [P, P, P]),
+        "orc_trace_primary_inst": (None, [SP, VP, u32, u32, u32, u32, u32, i, P, P, STP]),
+        "orc_trace_ao_inst": (None, [SP, VP, u32, u32, u32, u32, u32, u32, f, i, P, P, P, P, STP]),
+        "orc_trace_rays_inst": (None, [SP, P, u64, u32, i, P, P, STP]),
         "orc_render_frame": (C.c_double, [SP, VP, u32, u32, u32, u32, f, i, P]),
         "orc_brute_rays": (None, [P, u64, P, u64, u32, i, P]),
         "orc_brute_primary": (None, [P, u64, VP, u32, u32, u32, i, P]),
@@ -107,7 +115,7 @@ def view_from_bytes(raw):
 class Scene:
     """Oracle scene over the flat buffers (nodes [n,20] u32, tri_verts [n,9] f32)."""
 
-    def __init__(self, nodes, tri_verts=None, instance_offsets=None, tlas_start=0, tri_f16=None):
+    def __init__(self, nodes, tri_verts=None, instance_offsets=None, tlas_start=0, tri_f16=None, instance_w2o=None):
         lib = load()
         self.nodes = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 20)
         if tri_f16 is not None:
@@ -120,8 +128,12 @@ class Scene:
             self.tris = np.empty_like(self.verts)
             lib.orc_tris_from_verts(_ptr(self.verts), self.verts.shape[0], _ptr(self.tris))
         self.inst = np.ascontiguousarray(instance_offsets if instance_offsets is not None else [], dtype=np.uint32)
+        # world-to-object 3x4 (row-major, 12 floats) per TLAS primitive, or None = identity
+        self.w2o = None if instance_w2o is None else np.ascontiguousarray(instance_w2o, dtype=np.float32).reshape(-1, 12)
+        assert self.w2o is None or self.w2o.shape[0] == self.inst.size
         self.c = SceneC(_ptr(self.nodes), self.nodes.shape[0], _ptr(self.tris), self.tris.shape[0],
-                        _ptr(self.inst) if self.inst.size else None, self.inst.size, int(tlas_start))
+                        _ptr(self.inst) if self.inst.size else None, self.inst.size, int(tlas_start),
+                        _ptr(self.w2o) if self.w2o is not None else None)
 
     @classmethod
     def from_flat(cls, flat):
@@ -149,6 +161,34 @@ class Scene:
         load().orc_trace_rays(C.byref(self.c), _ptr(rays), rays.shape[0], sem, threads, _ptr(hits), C.byref(st))
         return hits, st
 
+    def trace_primary_inst(self, view, w, h, sem=SEM_HLSL, shard=(0, 1), threads=0):
+        """(hits, instance ids, stats): instance = TLAS primitive index the hit was found in (0xFFFFFFFF = none)."""
+        hits = np.zeros(w * h, dtype=HIT_DTYPE)
+        inst = np.full(w * h, 0xFFFFFFFF, dtype=np.uint32)
+        st = Stats()
+        load().orc_trace_primary_inst(C.byref(self.c), C.byref(view), w, h, shard[0], shard[1], sem, threads, _ptr(hits),
+                                      _ptr(inst), C.byref(st))
+        return hits, inst, st
+
+    def trace_ao_inst(self, view, w, h, primary, primary_inst, sem=SEM_HLSL, frame=0, ao_eps=0.01, shard=(0, 1), threads=0):
+        primary = np.ascontiguousarray(primary, dtype=HIT_DTYPE)
+        primary_inst = np.ascontiguousarray(primary_inst, dtype=np.uint32)
+        ao = np.zeros(w * h, dtype=HIT_DTYPE)
+        inst = np.full(w * h, 0xFFFFFFFF, dtype=np.uint32)
+        st = Stats()
+        load().orc_trace_ao_inst(C.byref(self.c), C.byref(view), w, h, shard[0], shard[1], sem, frame, ao_eps, threads,
+                                 _ptr(primary), _ptr(primary_inst), _ptr(ao), _ptr(inst), C.byref(st))
+        return ao, inst, st
+
+    def trace_rays_inst(self, rays, sem=SEM_HLSL, threads=0):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
+        inst = np.full(rays.shape[0], 0xFFFFFFFF, dtype=np.uint32)
+        st = Stats()
+        load().orc_trace_rays_inst(C.byref(self.c), _ptr(rays), rays.shape[0], sem, threads, _ptr(hits), _ptr(inst),
+                                   C.byref(st))
+        return hits, inst, st
+
     def count_per_ray(self, view, w, h, sem=SEM_HLSL, threads=0):
         nn = np.zeros(w * h, dtype=np.uint16)
         nt = np.zeros(w * h, dtype=np.uint16)
@@ -168,6 +208,17 @@ class Scene:
         hits = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
         load().orc_brute_rays(_ptr(self.tris), self.tris.shape[0], _ptr(rays), rays.shape[0], sem, threads,
                               _ptr(hits))
+        return hits
+
+    def brute_rays_over(self, tri_verts, rays, sem=SEM_HLSL, threads=0):
+        """Brute force over an arbitrary triangle list (n x 9 vertices), e.g. world-space copies of instances."""
+        lib = load()
+        v = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
+        tris = np.empty_like(v)
+        lib.orc_tris_from_verts(_ptr(v), v.shape[0], _ptr(tris))
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
+        lib.orc_brute_rays(_ptr(tris), tris.shape[0], _ptr(rays), rays.shape[0], sem, threads, _ptr(hits))
         return hits
 
     def primary_rays(self, view, w, h):

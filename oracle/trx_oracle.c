@@ -244,14 +244,35 @@ void orc_sincos(float theta, float *s, float *c) {
 
 /* AO ray of src/rt_cpu/rt_cpu.rs:61-76 / src/rt_gpu/rt_gpu_software.hlsl:105-121.
  * Returns 0 when the primary ray missed. */
+void orc_xform_point(const float m[12], const float p[3], float out[3]) {
+    for (int r = 0; r < 3; r++) out[r] = ((m[4 * r] * p[0] + m[4 * r + 1] * p[1]) + m[4 * r + 2] * p[2]) + m[4 * r + 3];
+}
+void orc_xform_dir(const float m[12], const float v[3], float out[3]) {
+    for (int r = 0; r < 3; r++) out[r] = (m[4 * r] * v[0] + m[4 * r + 1] * v[1]) + m[4 * r + 2] * v[2];
+}
+
 int orc_ao_ray(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h, uint32_t px,
                uint32_t py, orc_hit primary, uint32_t frame, float ao_eps, float o[3], float d[3]) {
+    return orc_ao_ray_inst(s, view, w, h, px, py, primary, INVALID, frame, ao_eps, o, d);
+}
+
+int orc_ao_ray_inst(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h, uint32_t px, uint32_t py,
+                    orc_hit primary, uint32_t primary_inst, uint32_t frame, float ao_eps, float o[3], float d[3]) {
     if (!(primary.t < F32_MAX) || primary.prim == INVALID) return 0;
     float ro[3], rd[3];
     orc_primary_ray(view, w, h, px, py, ro, rd);
     const float *tri = s->tris + 9 * (uint64_t)primary.prim;
     float n[3];
     cross3(tri + 3, tri + 6, n); /* ng = e1 x e2, compute_normal() = ng.normalize() */
+    if (s->instance_w2o && primary_inst != INVALID) {
+        /* object-space normal -> world: transpose of world-to-object (= inverse transpose of object-to-world) */
+        const float *m = s->instance_w2o + 12 * (uint64_t)primary_inst;
+        float nw[3];
+        for (int c = 0; c < 3; c++) nw[c] = (m[c] * n[0] + m[4 + c] * n[1]) + m[8 + c] * n[2];
+        n[0] = nw[0];
+        n[1] = nw[1];
+        n[2] = nw[2];
+    }
     normalize3(n);
     float nd = (n[0] * -rd[0] + n[1] * -rd[1]) + n[2] * -rd[2];
     float sg = copysignf(1.0f, nd); /* f32::signum: rt_cpu.rs:65 */
@@ -381,18 +402,24 @@ static inline uint32_t firstbithigh(uint32_t x) { return 31u - (uint32_t)__built
 
 orc_hit orc_traverse(const orc_scene *s, const float o[3], const float d_in[3], float tmin, float tmax,
                      uint32_t sem, orc_stats *st) {
-    float d[3], inv_d[3];
+    return orc_traverse_inst(s, o, d_in, tmin, tmax, sem, st, NULL);
+}
+
+orc_hit orc_traverse_inst(const orc_scene *s, const float o_in[3], const float d_in[3], float tmin, float tmax,
+                          uint32_t sem, orc_stats *st, uint32_t *inst_out) {
+    float o[3] = {o_in[0], o_in[1], o_in[2]}, d[3], inv_d[3];
     for (int k = 0; k < 3; k++) { /* :334 zero-direction fix, seen by node AND triangle tests */
         d[k] = d_in[k] == 0.0f ? F32_EPSILON : d_in[k];
         inv_d[k] = 1.0f / d[k];
     }
+    uint32_t cur_inst = INVALID, hit_inst = INVALID;
     const int tlas = s->n_instances > 0;
     u2 stack[ORC_STACK_SIZE];
     uint32_t sp = 0, max_sp = 0;
     int overflow = 0;
     uint32_t tlas_stack_size = INVALID;
     uint32_t bvh_offset = tlas ? s->tlas_start : 0;
-    const uint32_t oct_inv4 = orc_octant_inv4(d);
+    uint32_t oct_inv4 = orc_octant_inv4(d);
     u2 cur = {0, 0x80000000u};
     float t = fminf(tmax, F32_MAX);
     uint32_t prim = INVALID;
@@ -440,18 +467,44 @@ orc_hit orc_traverse(const orc_scene *s, const float o[3], const float d_in[3], 
                 if (cur.y & 0xff000000u) PUSH(cur);
                 tlas_stack_size = sp;
                 bvh_offset = s->instance_offsets[global];
+                cur_inst = global;
+                if (s->instance_w2o) {
+                    /* the ray in the instance's object space; the direction is not renormalised, so t keeps its
+                     * world-space meaning (jan-van-bergen BVH8.h:222, the TODO at query_tlas.hlsl:433) */
+                    const float *m = s->instance_w2o + 12 * (uint64_t)global;
+                    float od[3];
+                    orc_xform_point(m, o_in, o);
+                    orc_xform_dir(m, d_in, od);
+                    for (int k = 0; k < 3; k++) {
+                        d[k] = od[k] == 0.0f ? F32_EPSILON : od[k];
+                        inv_d[k] = 1.0f / d[k];
+                    }
+                    oct_inv4 = orc_octant_inv4(d);
+                }
                 cur.x = 0;
                 cur.y = 0x80000000u;
                 break;
             }
             n_tri++;
-            if (orc_intersect_tri(o, d, s->tris + 9 * (uint64_t)global, tmin, &t, sem)) prim = global;
+            if (orc_intersect_tri(o, d, s->tris + 9 * (uint64_t)global, tmin, &t, sem)) {
+                prim = global;
+                hit_inst = cur_inst;
+            }
         }
         if ((cur.y & 0xff000000u) == 0) {
             if (sp == 0) break;
             if (tlas && sp == tlas_stack_size) { /* query_tlas.hlsl:480-486 */
                 tlas_stack_size = INVALID;
                 bvh_offset = s->tlas_start;
+                cur_inst = INVALID;
+                if (s->instance_w2o) { /* "Reset Ray to untransformed version", query_tlas.hlsl:484 */
+                    for (int k = 0; k < 3; k++) {
+                        o[k] = o_in[k];
+                        d[k] = d_in[k] == 0.0f ? F32_EPSILON : d_in[k];
+                        inv_d[k] = 1.0f / d[k];
+                    }
+                    oct_inv4 = orc_octant_inv4(d);
+                }
             }
             sp--;
             if (sp < ORC_STACK_SIZE) cur = stack[sp];
@@ -467,6 +520,7 @@ orc_hit orc_traverse(const orc_scene *s, const float o[3], const float d_in[3], 
         h.t = INFINITY;
         h.prim = INVALID;
     }
+    if (inst_out) *inst_out = prim != INVALID ? hit_inst : INVALID;
     if (st) {
         st->n_rays++;
         st->n_node += n_node;
@@ -493,6 +547,12 @@ static void stats_merge(orc_stats *dst, const orc_stats *src) {
 void orc_trace_primary(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h,
                        uint32_t shard_index, uint32_t shard_count, uint32_t sem, int threads,
                        orc_hit *hits, orc_stats *st) {
+    orc_trace_primary_inst(s, view, w, h, shard_index, shard_count, sem, threads, hits, NULL, st);
+}
+
+void orc_trace_primary_inst(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h,
+                            uint32_t shard_index, uint32_t shard_count, uint32_t sem, int threads,
+                            orc_hit *hits, uint32_t *inst, orc_stats *st) {
     if (shard_count == 0) shard_count = 1;
     const uint32_t tx = (w + 7) / 8, ty = (h + 7) / 8;
     const int64_t n_tiles = (int64_t)tx * ty;
@@ -513,7 +573,9 @@ void orc_trace_primary(const orc_scene *s, const orc_view *view, uint32_t w, uin
                 if (px >= w || py >= h) continue;
                 float o[3], d[3];
                 orc_primary_ray(view, w, h, px, py, o, d);
-                hits[(uint64_t)py * w + px] = orc_traverse(s, o, d, 0.0f, F32_MAX, sem, &loc);
+                uint32_t hi = INVALID;
+                hits[(uint64_t)py * w + px] = orc_traverse_inst(s, o, d, 0.0f, F32_MAX, sem, &loc, &hi);
+                if (inst) inst[(uint64_t)py * w + px] = hi;
             }
         }
 #pragma omp critical
@@ -527,6 +589,13 @@ void orc_trace_primary(const orc_scene *s, const orc_view *view, uint32_t w, uin
 void orc_trace_ao(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h, uint32_t shard_index,
                   uint32_t shard_count, uint32_t sem, uint32_t frame, float ao_eps, int threads,
                   const orc_hit *primary, orc_hit *ao, orc_stats *st) {
+    orc_trace_ao_inst(s, view, w, h, shard_index, shard_count, sem, frame, ao_eps, threads, primary, NULL, ao, NULL, st);
+}
+
+void orc_trace_ao_inst(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h, uint32_t shard_index,
+                       uint32_t shard_count, uint32_t sem, uint32_t frame, float ao_eps, int threads,
+                       const orc_hit *primary, const uint32_t *primary_inst, orc_hit *ao, uint32_t *ao_inst,
+                       orc_stats *st) {
     if (shard_count == 0) shard_count = 1;
     const uint32_t tx = (w + 7) / 8, ty = (h + 7) / 8;
     const int64_t n_tiles = (int64_t)tx * ty;
@@ -547,12 +616,15 @@ void orc_trace_ao(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t
                 if (px >= w || py >= h) continue;
                 uint64_t i = (uint64_t)py * w + px;
                 float o[3], d[3];
-                if (orc_ao_ray(s, view, w, h, px, py, primary[i], frame, ao_eps, o, d)) {
-                    ao[i] = orc_traverse(s, o, d, 0.0f, F32_MAX, sem, &loc);
+                uint32_t hi = INVALID;
+                if (orc_ao_ray_inst(s, view, w, h, px, py, primary[i], primary_inst ? primary_inst[i] : INVALID, frame,
+                                    ao_eps, o, d)) {
+                    ao[i] = orc_traverse_inst(s, o, d, 0.0f, F32_MAX, sem, &loc, &hi);
                 } else {
                     ao[i].t = INFINITY;
                     ao[i].prim = INVALID;
                 }
+                if (ao_inst) ao_inst[i] = hi;
             }
         }
 #pragma omp critical
@@ -565,6 +637,11 @@ void orc_trace_ao(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t
 
 void orc_trace_rays(const orc_scene *s, const orc_ray *rays, uint64_t n, uint32_t sem, int threads,
                     orc_hit *hits, orc_stats *st) {
+    orc_trace_rays_inst(s, rays, n, sem, threads, hits, NULL, st);
+}
+
+void orc_trace_rays_inst(const orc_scene *s, const orc_ray *rays, uint64_t n, uint32_t sem, int threads,
+                         orc_hit *hits, uint32_t *inst, orc_stats *st) {
     threads = pick_threads(threads);
     orc_stats total;
     memset(&total, 0, sizeof(total));
@@ -574,8 +651,11 @@ void orc_trace_rays(const orc_scene *s, const orc_ray *rays, uint64_t n, uint32_
         orc_stats loc;
         memset(&loc, 0, sizeof(loc));
 #pragma omp for schedule(dynamic, 256)
-        for (int64_t i = 0; i < (int64_t)n; i++)
-            hits[i] = orc_traverse(s, rays[i].origin, rays[i].direction, rays[i].tmin, rays[i].tmax, sem, &loc);
+        for (int64_t i = 0; i < (int64_t)n; i++) {
+            uint32_t hi = INVALID;
+            hits[i] = orc_traverse_inst(s, rays[i].origin, rays[i].direction, rays[i].tmin, rays[i].tmax, sem, &loc, &hi);
+            if (inst) inst[i] = hi;
+        }
 #pragma omp critical
         stats_merge(&total, &loc);
     }

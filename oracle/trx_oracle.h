@@ -64,6 +64,11 @@ typedef struct orc_scene {
     const uint32_t *instance_offsets;
     uint32_t n_instances;
     uint32_t tlas_start;
+    /* optional: world-to-object transform of every TLAS primitive (instance), n_instances * 12 floats, three rows
+     * of {m0 m1 m2 t}: the ray is taken into the instance's object space on BLAS entry and restored on exit
+     * (the TODOs at query_tlas.hlsl:409,433,484; get_instance_transform, traversable/src/lib.rs:25-27).  NULL =
+     * identity, the reference's behaviour. */
+    const float *instance_w2o;
 } orc_scene;
 
 typedef struct orc_stats {
@@ -99,6 +104,17 @@ void orc_sincos(float theta, float *s, float *c);
 orc_hit orc_traverse(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax,
                      uint32_t sem, orc_stats *st);
 
+/* the same with the TLAS primitive (instance) the hit was found in: *inst = index into instance_offsets, or
+ * 0xFFFFFFFF for a miss / a scene without TLAS */
+orc_hit orc_traverse_inst(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax,
+                          uint32_t sem, orc_stats *st, uint32_t *inst);
+int orc_ao_ray_inst(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h, uint32_t px, uint32_t py,
+                    orc_hit primary, uint32_t primary_inst, uint32_t frame, float ao_eps, float o[3], float d[3]);
+/* point / direction through a 3x4 transform with the operation order both sides use:
+ * ((m0*x + m1*y) + m2*z) [+ t] per row */
+void orc_xform_point(const float m[12], const float p[3], float out[3]);
+void orc_xform_dir(const float m[12], const float v[3], float out[3]);
+
 /* frames; threads <= 0: all cores.  shard as trx_shard (8x8 tiles, tile % count == index);
  * pixels outside the shard are left untouched. */
 void orc_trace_primary(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h,
@@ -109,6 +125,16 @@ void orc_trace_ao(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t
                   const orc_hit *primary, orc_hit *ao, orc_stats *st);
 void orc_trace_rays(const orc_scene *s, const orc_ray *rays, uint64_t n, uint32_t sem, int threads,
                     orc_hit *hits, orc_stats *st);
+/* instance-aware forms (inst arrays may be NULL; primary_inst is needed when instance_w2o is set) */
+void orc_trace_primary_inst(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h,
+                            uint32_t shard_index, uint32_t shard_count, uint32_t sem, int threads,
+                            orc_hit *hits, uint32_t *inst, orc_stats *st);
+void orc_trace_ao_inst(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h, uint32_t shard_index,
+                       uint32_t shard_count, uint32_t sem, uint32_t frame, float ao_eps, int threads,
+                       const orc_hit *primary, const uint32_t *primary_inst, orc_hit *ao, uint32_t *ao_inst,
+                       orc_stats *st);
+void orc_trace_rays_inst(const orc_scene *s, const orc_ray *rays, uint64_t n, uint32_t sem, int threads,
+                         orc_hit *hits, uint32_t *inst, orc_stats *st);
 /* the reference's whole CPU frame (src/rt_cpu/rt_cpu.rs:35-92): primary + AO + shade per pixel */
 double orc_render_frame(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h, uint32_t sem,
                         uint32_t frame, float ao_eps, int threads, float *rgb);

@@ -149,3 +149,73 @@ def deep_chain_scene(depth):
             leaf[0] = ("leaf", bmin, bmax, 1)
             out.append(encode_node(bmin, bmax, leaf, 0, k))
     return np.array(out, dtype=np.uint32), np.array(tris, dtype=np.float32)
+
+
+# ---- instanced scenes (TLAS primitives with transforms) ----------------------------------------------------
+
+def random_affine(rng, scale_lo=0.4, scale_hi=1.6, spread=4.0):
+    """A column-major 4x4 object-to-world matrix: rotation x non-uniform scale, then a translation."""
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    A = R @ np.diag(rng.uniform(scale_lo, scale_hi, size=3))
+    M = np.eye(4)
+    M[:3, :3] = A
+    M[:3, 3] = rng.uniform(-spread, spread, size=3)
+    return M.T.reshape(16).astype(np.float32)   # column-major: m[c*4 + r]
+
+
+def w2o_rows(o2w16):
+    """World-to-object rows {m0 m1 m2 t} x 3 (12 floats) of a column-major affine 4x4, inverse taken in float64."""
+    M = np.asarray(o2w16, dtype=np.float64).reshape(4, 4).T
+    return np.linalg.inv(M)[:3, :].reshape(12).astype(np.float32)
+
+
+def instanced_scene(T, seed=3, n_objects=3, n_instances=10, tris_per_object=400):
+    """A few small triangle-soup objects and `n_instances` transformed instances of them (several per object).
+    Returns (flat, object_to_world in TLAS-primitive order, world-space triangles [n, 9] instance-major in
+    TLAS-primitive order, first world triangle of every TLAS primitive)."""
+    rng = np.random.default_rng(seed)
+    verts, counts = [], []
+    for o in range(n_objects):
+        v, _ = T.gen_scene("soup", tris_per_object + 37 * o, seed + o)
+        verts.append(v)
+        counts.append(v.shape[0])
+    verts = np.concatenate(verts)
+    inst_obj = np.array([k % n_objects for k in range(n_instances)], dtype=np.uint32)
+    o2w = np.stack([random_affine(rng) for _ in range(n_instances)])
+    o2w[0] = np.eye(4, dtype=np.float32).reshape(16)        # one identity instance among them
+    flat = T.flat_build_instanced(verts, counts, inst_obj, o2w)
+    # world-space geometry, in float64 then f32, for the BVH-independent brute-force query
+    world, first = [], [0]
+    bts = flat.blas_tri_start
+    blas_of_offset = {int(off): b for b, off in enumerate(sorted(set(int(x) for x in flat.instance_offsets)))}
+    for k in range(flat.instance_offsets.size):
+        b = blas_of_offset[int(flat.instance_offsets[k])]
+        tv = flat.tri_verts[bts[b]:bts[b + 1]].astype(np.float64).reshape(-1, 3)
+        M = flat.instance_transforms[k].astype(np.float64).reshape(4, 4).T
+        world.append((tv @ M[:3, :3].T + M[:3, 3]).reshape(-1, 9).astype(np.float32))
+        first.append(first[-1] + world[-1].shape[0])
+    return flat, flat.instance_transforms, np.concatenate(world), np.array(first), blas_of_offset
+
+
+def aimed_rays(T, tri_verts, n, seed):
+    """Rays from around the geometry towards random points of random triangles (so most of them hit something)."""
+    rng = np.random.default_rng(seed)
+    v = np.asarray(tri_verts, dtype=np.float32).reshape(-1, 3, 3)
+    lo, hi = v.reshape(-1, 3).min(0), v.reshape(-1, 3).max(0)
+    rays = np.zeros(n, dtype=T.RAY_DTYPE)
+    o = rng.uniform(lo - 0.3 * (hi - lo), hi + 0.3 * (hi - lo), size=(n, 3))
+    tri = v[rng.integers(0, v.shape[0], size=n)]
+    bc = rng.dirichlet([1, 1, 1], size=n)
+    target = (tri * bc[:, :, None]).sum(1)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays["origin"] = o.astype(np.float32)
+    rays["direction"] = d.astype(np.float32)
+    rays["tmin"] = 0.0
+    rays["tmax"] = F32_MAX
+    return rays

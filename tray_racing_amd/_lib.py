@@ -68,7 +68,8 @@ class Flat(C.Structure):
                 ("n_tris", C.c_uint64), ("instance_offsets", C.POINTER(C.c_uint32)), ("n_instances", C.c_uint32),
                 ("tlas_start", C.c_uint32), ("tri_source", C.POINTER(C.c_uint32)),
                 ("blas_tri_start", C.POINTER(C.c_uint32)), ("n_blas", C.c_uint32), ("blas_build_s", C.c_double),
-                ("tlas_build_s", C.c_double), ("tri_boxes", C.POINTER(C.c_float))]
+                ("tlas_build_s", C.c_double), ("tri_boxes", C.POINTER(C.c_float)),
+                ("instance_source", C.POINTER(C.c_uint32)), ("instance_transforms", C.POINTER(C.c_float))]
 
 
 class BuildParams(C.Structure):
@@ -93,11 +94,17 @@ SIGNATURES = {
     "trx_scene_device_bytes": (_u64, [_P]),
     "trx_scene_device": (_i, [_P]),
     "trx_scene_set_geometry_ranges": (_i, [_P, _P, _u32]),
+    "trx_scene_set_instance_transforms": (_i, [_P, _P, _u32]),
+    "trx_scene_get_instance_transform": (_i, [_P, _u32, _P]),
+    "trx_scene_get_instance_world_to_object": (_i, [_P, _u32, _P]),
     "trx_view_from_camera": (_i, [C.POINTER(_f), C.POINTER(_f), _f, _f, _f, C.POINTER(View)]),
     "trx_trace_primary_dev": (_i, [_P, C.POINTER(View), _u32, _u32, Shard, _u32, _P, _P]),
+    "trx_trace_primary_inst_dev": (_i, [_P, C.POINTER(View), _u32, _u32, Shard, _u32, _P, _P, _P]),
     "trx_trace_primary_batch_dev": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, Shard, _u32, _P, _u64, _P]),
     "trx_trace_ao_dev": (_i, [_P, C.POINTER(View), _u32, _u32, Shard, _u32, _u32, _f, _P, _P, _P]),
+    "trx_trace_ao_inst_dev": (_i, [_P, C.POINTER(View), _u32, _u32, Shard, _u32, _u32, _f, _P, _P, _P, _P, _P]),
     "trx_trace_rays_dev": (_i, [_P, _P, _u64, _u32, _P, _P]),
+    "trx_trace_rays_inst_dev": (_i, [_P, _P, _u64, _u32, _P, _P, _P]),
     "trx_trace_occluded_dev": (_i, [_P, _P, _u64, _u32, _P, _P]),
     "trx_trace_occluded": (_i, [_P, _P, _u64, _u32, _P, C.POINTER(_f)]),
     "trx_count_primary": (_i, [_P, C.POINTER(View), _u32, _u32, Shard, _u32, _P, C.POINTER(Stats)]),
@@ -106,7 +113,9 @@ SIGNATURES = {
     "trx_scene_check": (_i, [_P, _P]),
     "trx_trace_primary": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, C.POINTER(_f)]),
     "trx_trace_primary_ao": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _u32, _f, _P, _P, C.POINTER(_f)]),
+    "trx_trace_primary_ao_inst": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _u32, _f, _P, _P, _P, _P, C.POINTER(_f)]),
     "trx_trace_rays": (_i, [_P, _P, _u64, _u32, _P, C.POINTER(_f)]),
+    "trx_trace_rays_inst": (_i, [_P, _P, _u64, _u32, _P, _P, C.POINTER(_f)]),
     "trx_traverse1": (_i, [_P, C.POINTER(Ray), _u32, C.POINTER(RayHit)]),
     "trx_bench_primary": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _u32, _u32, C.POINTER(_f), C.POINTER(_f)]),
     "trx_set_kernel_variant": (_u32, [_u32]),
@@ -130,6 +139,7 @@ SIGNATURES = {
     "trx_bvh_total_aabb": (None, [_P, C.POINTER(_f)]),
     "trx_bvh_build_seconds": (C.c_double, [_P]),
     "trx_flat_build": (_i, [_P, _P, _u32, _i, _u32, _i, C.POINTER(C.POINTER(Flat))]),
+    "trx_flat_build_instanced": (_i, [_P, _P, _u32, _P, _P, _u32, _u32, _i, C.POINTER(C.POINTER(Flat))]),
     "trx_flat_build_params": (_i, [_P, _P, _u32, _i, C.POINTER(BuildParams), _i, C.POINTER(C.POINTER(Flat))]),
     "trx_build_params_default": (None, [C.POINTER(BuildParams)]),
     "trx_flat_destroy": (None, [C.POINTER(Flat)]),

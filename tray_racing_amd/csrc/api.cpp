@@ -120,10 +120,15 @@ struct trx_scene {
     std::recursive_mutex host_mu; // scratch buffers and event pair of the synchronous entry points
     // scratch for the host-buffer convenience entry points
     trx_hit *d_scratch_a = nullptr, *d_scratch_b = nullptr;
+    uint32_t *d_scratch_ia = nullptr, *d_scratch_ib = nullptr; // instance ids beside scratch_a / scratch_b
     trx_ray *d_scratch_rays = nullptr;
     uint64_t scratch_hits = 0, scratch_rays = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<uint32_t> blas_tri_start; // geometry_id lookup for trx_traverse1
+    // instance transforms (TLAS scenes): object-to-world as given (get_instance_transform), world-to-object rows as
+    // the kernels use them, and their device copy; empty / null = identity
+    std::vector<float> inst_o2w, inst_w2o;
+    float4 *d_inst_xform = nullptr;
 };
 
 struct trx_bvh {
@@ -246,10 +251,17 @@ int ensure_scratch(trx_scene *s, uint64_t hits, uint64_t rays) {
     if (hits > s->scratch_hits) {
         if (s->d_scratch_a) (void)hipFree(s->d_scratch_a);
         if (s->d_scratch_b) (void)hipFree(s->d_scratch_b);
+        if (s->d_scratch_ia) (void)hipFree(s->d_scratch_ia);
+        if (s->d_scratch_ib) (void)hipFree(s->d_scratch_ib);
         s->d_scratch_a = s->d_scratch_b = nullptr;
+        s->d_scratch_ia = s->d_scratch_ib = nullptr;
         s->scratch_hits = 0;
         HIP_TRY(hipMalloc(&s->d_scratch_a, hits * sizeof(trx_hit)));
         HIP_TRY(hipMalloc(&s->d_scratch_b, hits * sizeof(trx_hit)));
+        if (s->tlas) {
+            HIP_TRY(hipMalloc(&s->d_scratch_ia, hits * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&s->d_scratch_ib, hits * sizeof(uint32_t)));
+        }
         s->scratch_hits = hits;
     }
     if (rays > s->scratch_rays) {
@@ -333,7 +345,11 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.nodes = s->d_nodes;
     p.tris = s->d_tris;
     p.inst = s->d_inst;
+    p.inst_xform = s->d_inst_xform;
     p.tlas_start = s->tlas_start;
+    if (s->d_inst_xform && mode == kModeAo && !p.primary_inst)
+        return fail(TRX_ERR_INVALID, "this scene has instance transforms: the AO pass needs the primary pass's instance ids "
+                                     "(trx_trace_ao_inst_dev) to take the hit normal into world space");
     p.ctr = slot.ctr;
     p.spill = slot.spill;
     p.tie_first = (sem & TRX_SEM_TIE_FIRST) ? 1u : 0u;
@@ -559,8 +575,11 @@ void trx_scene_destroy(trx_scene *s) {
     if (s->d_inst) (void)hipFree(s->d_inst);
     if (s->d_scratch_a) (void)hipFree(s->d_scratch_a);
     if (s->d_scratch_b) (void)hipFree(s->d_scratch_b);
+    if (s->d_scratch_ia) (void)hipFree(s->d_scratch_ia);
+    if (s->d_scratch_ib) (void)hipFree(s->d_scratch_ib);
     if (s->d_scratch_rays) (void)hipFree(s->d_scratch_rays);
     if (s->d_wave_times) (void)hipFree(s->d_wave_times);
+    if (s->d_inst_xform) (void)hipFree(s->d_inst_xform);
     for (Slot &sl : s->slots) {
         if (sl.ctr) (void)hipFree(sl.ctr);
         if (sl.spill) (void)hipFree(sl.spill);
@@ -589,6 +608,81 @@ int trx_scene_device(const trx_scene *s) { return s ? s->device : -1; }
 int trx_scene_set_geometry_ranges(trx_scene *s, const uint32_t *blas_tri_start, uint32_t n_blas) {
     if (!s || (!blas_tri_start && n_blas)) return fail(TRX_ERR_INVALID, "null argument");
     s->blas_tri_start.assign(blas_tri_start, blas_tri_start + n_blas + (n_blas ? 1 : 0));
+    return TRX_OK;
+}
+
+// Instance transforms: the TODOs at query_tlas.hlsl:409,433,484 and Traversable::get_instance_transform
+// (traversable/src/lib.rs:25-27).  object_to_world: n column-major 4x4 matrices (glam Mat4) in TLAS-primitive order.
+int trx_scene_set_instance_transforms(trx_scene *s, const float *object_to_world, uint32_t n) {
+    if (!s) return fail(TRX_ERR_INVALID, "null scene");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu);
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize()); // no kernel may be reading the table while it changes
+    if (!object_to_world || n == 0) { // back to identity
+        if (s->d_inst_xform) (void)hipFree(s->d_inst_xform);
+        s->d_inst_xform = nullptr;
+        s->inst_o2w.clear();
+        s->inst_w2o.clear();
+        return TRX_OK;
+    }
+    if (!s->tlas) return fail(TRX_ERR_INVALID, "instance transforms need a TLAS scene");
+    if (n != s->n_inst) return fail(TRX_ERR_INVALID, "%u transforms for %u instances", n, s->n_inst);
+    std::vector<float> w2o((size_t)n * 12);
+    for (uint32_t k = 0; k < n; k++) {
+        const float *m = object_to_world + (size_t)k * 16; // m[c*4 + r]
+        if (m[3] != 0.f || m[7] != 0.f || m[11] != 0.f || m[15] != 1.f)
+            return fail(TRX_ERR_INVALID, "instance %u: transform is not affine (last row must be 0 0 0 1)", k);
+        // inverse of the affine map in double, rounded once to f32
+        const double a = m[0], b = m[4], c = m[8], d = m[1], e = m[5], f = m[9], g = m[2], h = m[6], i = m[10];
+        const double tx = m[12], ty = m[13], tz = m[14];
+        const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+        if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return fail(TRX_ERR_INVALID, "instance %u: singular transform", k);
+        const double r = 1.0 / det;
+        const double inv[9] = {(e * i - f * h) * r, (c * h - b * i) * r, (b * f - c * e) * r,
+                               (f * g - d * i) * r, (a * i - c * g) * r, (c * d - a * f) * r,
+                               (d * h - e * g) * r, (b * g - a * h) * r, (a * e - b * d) * r};
+        float *o = &w2o[(size_t)k * 12];
+        for (int row = 0; row < 3; row++) {
+            o[4 * row + 0] = (float)inv[3 * row + 0];
+            o[4 * row + 1] = (float)inv[3 * row + 1];
+            o[4 * row + 2] = (float)inv[3 * row + 2];
+            o[4 * row + 3] = (float)-(inv[3 * row + 0] * tx + inv[3 * row + 1] * ty + inv[3 * row + 2] * tz);
+        }
+    }
+    float4 *d = nullptr;
+    HIP_TRY(hipMalloc(&d, w2o.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(d, w2o.data(), w2o.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail(TRX_ERR_NO_DEVICE, "upload of the instance transforms failed: %s", hipGetErrorString(e));
+    }
+    if (s->d_inst_xform) (void)hipFree(s->d_inst_xform);
+    s->d_inst_xform = d;
+    s->inst_o2w.assign(object_to_world, object_to_world + (size_t)n * 16);
+    s->inst_w2o.swap(w2o);
+    return TRX_OK;
+}
+
+int trx_scene_get_instance_transform(const trx_scene *s, uint32_t instance_id, float out_object_to_world[16]) {
+    if (!s || !out_object_to_world) return fail(TRX_ERR_INVALID, "null argument");
+    if (instance_id >= std::max<uint32_t>(s->n_inst, 1)) return fail(TRX_ERR_INVALID, "instance %u of %u", instance_id, s->n_inst);
+    if (s->inst_o2w.empty()) { // Mat4::default(): identity, like the reference (src/cwbvh.rs:163-165,189-191)
+        for (int k = 0; k < 16; k++) out_object_to_world[k] = (k % 5 == 0) ? 1.f : 0.f;
+        return TRX_OK;
+    }
+    std::memcpy(out_object_to_world, &s->inst_o2w[(size_t)instance_id * 16], 64);
+    return TRX_OK;
+}
+
+int trx_scene_get_instance_world_to_object(const trx_scene *s, uint32_t instance_id, float out_rows[12]) {
+    if (!s || !out_rows) return fail(TRX_ERR_INVALID, "null argument");
+    if (instance_id >= std::max<uint32_t>(s->n_inst, 1)) return fail(TRX_ERR_INVALID, "instance %u of %u", instance_id, s->n_inst);
+    if (s->inst_w2o.empty()) {
+        static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        std::memcpy(out_rows, ident, 48);
+        return TRX_OK;
+    }
+    std::memcpy(out_rows, &s->inst_w2o[(size_t)instance_id * 12], 48);
     return TRX_OK;
 }
 
@@ -655,16 +749,22 @@ int trx_view_from_camera(const float eye[3], const float look_at[3], float fov_d
 
 // ---- tracing: device-resident -----------------------------------------------------------
 
-int trx_trace_primary_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard,
-                          uint32_t sem, trx_hit *d_hits, void *stream) {
+int trx_trace_primary_inst_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard,
+                               uint32_t sem, trx_hit *d_hits, uint32_t *d_inst, void *stream) {
     if (!s || !d_hits) return fail(TRX_ERR_INVALID, "null argument");
     TraceParams p;
     std::memset(&p, 0, sizeof(p));
     int rc = image_params(p, view, w, h, shard);
     if (rc) return rc;
     p.out = d_hits;
+    p.out_inst = d_inst;
     if (p.n_items == 0) return TRX_OK;
     return enqueue(s, p, kModePrimary, sem, false, (hipStream_t)stream, nullptr);
+}
+
+int trx_trace_primary_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard,
+                          uint32_t sem, trx_hit *d_hits, void *stream) {
+    return trx_trace_primary_inst_dev(s, view, w, h, shard, sem, d_hits, nullptr, stream);
 }
 
 int trx_trace_primary_batch_dev(trx_scene *s, const trx_view *views, uint32_t n_frames, uint32_t w, uint32_t h,
@@ -691,23 +791,32 @@ int trx_trace_primary_batch_dev(trx_scene *s, const trx_view *views, uint32_t n_
     return enqueue(s, p, kModePrimary, sem, false, (hipStream_t)stream, nullptr);
 }
 
-int trx_trace_ao_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,
-                     uint32_t frame, float ao_eps, const trx_hit *d_primary, trx_hit *d_ao, void *stream) {
+int trx_trace_ao_inst_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,
+                          uint32_t frame, float ao_eps, const trx_hit *d_primary, const uint32_t *d_primary_inst,
+                          trx_hit *d_ao, uint32_t *d_ao_inst, void *stream) {
     if (!s || !d_primary || !d_ao) return fail(TRX_ERR_INVALID, "null argument");
     TraceParams p;
     std::memset(&p, 0, sizeof(p));
     int rc = image_params(p, view, w, h, shard);
     if (rc) return rc;
     p.primary = d_primary;
+    p.primary_inst = d_primary_inst;
     p.out = d_ao;
+    p.out_inst = d_ao_inst;
     p.frame = frame;
     p.ao_eps = ao_eps;
     if (p.n_items == 0) return TRX_OK;
     return enqueue(s, p, kModeAo, sem, false, (hipStream_t)stream, nullptr);
 }
 
+int trx_trace_ao_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,
+                     uint32_t frame, float ao_eps, const trx_hit *d_primary, trx_hit *d_ao, void *stream) {
+    return trx_trace_ao_inst_dev(s, view, w, h, shard, sem, frame, ao_eps, d_primary, nullptr, d_ao, nullptr, stream);
+}
+
 static int trace_rays_impl(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, trx_hit *d_hits,
-                           hipStream_t stream, bool count, SlotCounters **ctr, bool any_hit = false) {
+                           hipStream_t stream, bool count, SlotCounters **ctr, bool any_hit = false,
+                           uint32_t *d_inst = nullptr) {
     // the work queue is 32-bit: split very large batches
     const uint64_t chunk = 1ull << 30;
     for (uint64_t off = 0; off < n; off += chunk) {
@@ -716,6 +825,7 @@ static int trace_rays_impl(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint
         p.rays = d_rays + off;
         p.out = any_hit ? reinterpret_cast<trx_hit *>(reinterpret_cast<uint8_t *>(d_hits) + off) : d_hits + off;
         p.any_hit = any_hit ? 1u : 0u;
+        p.out_inst = d_inst ? d_inst + off : nullptr;
         p.n_items = (uint32_t)std::min(chunk, n - off);
         int rc = enqueue(s, p, kModeRays, sem, count, stream, ctr);
         if (rc) return rc;
@@ -723,10 +833,15 @@ static int trace_rays_impl(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint
     return TRX_OK;
 }
 
-int trx_trace_rays_dev(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, trx_hit *d_hits, void *stream) {
+int trx_trace_rays_inst_dev(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, trx_hit *d_hits,
+                            uint32_t *d_inst, void *stream) {
     if (!s || (n && (!d_rays || !d_hits))) return fail(TRX_ERR_INVALID, "null argument");
     if (n == 0) return TRX_OK;
-    return trace_rays_impl(s, d_rays, n, sem, d_hits, (hipStream_t)stream, false, nullptr);
+    return trace_rays_impl(s, d_rays, n, sem, d_hits, (hipStream_t)stream, false, nullptr, false, d_inst);
+}
+
+int trx_trace_rays_dev(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, trx_hit *d_hits, void *stream) {
+    return trx_trace_rays_inst_dev(s, d_rays, n, sem, d_hits, nullptr, stream);
 }
 
 int trx_trace_occluded_dev(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, uint8_t *d_flags, void *stream) {
@@ -922,15 +1037,23 @@ int trx_trace_primary(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h
 
 int trx_trace_primary_ao(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint32_t frame,
                          float ao_eps, trx_hit *out_primary, trx_hit *out_ao, float *out_ms) {
+    return trx_trace_primary_ao_inst(s, view, w, h, sem, frame, ao_eps, out_primary, nullptr, out_ao, nullptr, out_ms);
+}
+
+int trx_trace_primary_ao_inst(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint32_t frame,
+                              float ao_eps, trx_hit *out_primary, uint32_t *out_primary_inst, trx_hit *out_ao,
+                              uint32_t *out_ao_inst, float *out_ms) {
     if (!s) return fail(TRX_ERR_INVALID, "null scene");
     std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure_scratch(s, (uint64_t)w * h, 0);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev0, nullptr));
-    rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, nullptr);
+    // instance ids travel with the hits whenever the scene has a TLAS (the AO pass needs them once transforms are set)
+    rc = trx_trace_primary_inst_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, s->d_scratch_ia, nullptr);
     if (rc) return rc;
-    rc = trx_trace_ao_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, frame, ao_eps, s->d_scratch_a, s->d_scratch_b, nullptr);
+    rc = trx_trace_ao_inst_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, frame, ao_eps, s->d_scratch_a, s->d_scratch_ia,
+                               s->d_scratch_b, s->d_scratch_ib, nullptr);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev1, nullptr));
     HIP_TRY(hipEventSynchronize(s->ev1));
@@ -938,10 +1061,22 @@ int trx_trace_primary_ao(trx_scene *s, const trx_view *view, uint32_t w, uint32_
     const uint64_t bytes = (uint64_t)w * h * sizeof(trx_hit);
     if (out_primary) HIP_TRY(hipMemcpy(out_primary, s->d_scratch_a, bytes, hipMemcpyDeviceToHost));
     if (out_ao) HIP_TRY(hipMemcpy(out_ao, s->d_scratch_b, bytes, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 2; k++) {
+        uint32_t *dst = k ? out_ao_inst : out_primary_inst;
+        const uint32_t *src = k ? s->d_scratch_ib : s->d_scratch_ia;
+        if (!dst) continue;
+        if (src) HIP_TRY(hipMemcpy(dst, src, (uint64_t)w * h * 4, hipMemcpyDeviceToHost));
+        else std::memset(dst, 0xff, (uint64_t)w * h * 4); // no TLAS: no instances
+    }
     return trx_scene_check(s, nullptr);
 }
 
 int trx_trace_rays(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t sem, trx_hit *out_hits, float *out_ms) {
+    return trx_trace_rays_inst(s, rays, n, sem, out_hits, nullptr, out_ms);
+}
+
+int trx_trace_rays_inst(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t sem, trx_hit *out_hits, uint32_t *out_inst,
+                        float *out_ms) {
     if (!s || (n && !rays)) return fail(TRX_ERR_INVALID, "null argument");
     std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     if (n == 0) return TRX_OK;
@@ -950,12 +1085,16 @@ int trx_trace_rays(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t sem, 
     if (rc) return rc;
     HIP_TRY(hipMemcpy(s->d_scratch_rays, rays, n * sizeof(trx_ray), hipMemcpyHostToDevice));
     HIP_TRY(hipEventRecord(s->ev0, nullptr));
-    rc = trx_trace_rays_dev(s, s->d_scratch_rays, n, sem, s->d_scratch_a, nullptr);
+    rc = trx_trace_rays_inst_dev(s, s->d_scratch_rays, n, sem, s->d_scratch_a, out_inst ? s->d_scratch_ia : nullptr, nullptr);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev1, nullptr));
     HIP_TRY(hipEventSynchronize(s->ev1));
     if (out_ms) HIP_TRY(hipEventElapsedTime(out_ms, s->ev0, s->ev1));
     if (out_hits) HIP_TRY(hipMemcpy(out_hits, s->d_scratch_a, n * sizeof(trx_hit), hipMemcpyDeviceToHost));
+    if (out_inst) {
+        if (s->d_scratch_ia) HIP_TRY(hipMemcpy(out_inst, s->d_scratch_ia, n * 4, hipMemcpyDeviceToHost));
+        else std::memset(out_inst, 0xff, n * 4);
+    }
     return trx_scene_check(s, nullptr);
 }
 
@@ -984,7 +1123,7 @@ struct ThreadRayLane {
     int device = -1;
     hipStream_t stream = nullptr;
     trx_ray *d_ray = nullptr;
-    trx_hit *d_hit = nullptr;
+    trx_hit *d_hit = nullptr; // {hit, instance id}: 12 bytes
 };
 struct ThreadRayLanes {
     std::vector<ThreadRayLane> lanes;
@@ -1009,7 +1148,7 @@ int thread_ray_lane(int device, ThreadRayLane **out) {
     l.device = device;
     HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
     hipError_t e = hipMalloc(&l.d_ray, sizeof(trx_ray));
-    if (e == hipSuccess) e = hipMalloc(&l.d_hit, sizeof(trx_hit));
+    if (e == hipSuccess) e = hipMalloc(&l.d_hit, sizeof(trx_hit) + sizeof(uint32_t));
     if (e != hipSuccess) {
         (void)hipStreamDestroy(l.stream);
         if (l.d_ray) (void)hipFree(l.d_ray);
@@ -1028,12 +1167,15 @@ int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *ou
     int rc = thread_ray_lane(s->device, &lane);
     if (rc) return rc;
     hipStream_t st = lane->stream;
-    trx_hit h{};
+    struct { trx_hit h; uint32_t inst; } rec{};
+    rec.inst = 0xFFFFFFFFu;
+    uint32_t *d_inst = reinterpret_cast<uint32_t *>(lane->d_hit + 1);
     if (hipMemcpyAsync(lane->d_ray, ray, sizeof(trx_ray), hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "copy failed");
-    if (!rc) rc = trace_rays_impl(s, lane->d_ray, 1, sem, lane->d_hit, st, false, nullptr);
-    if (!rc && hipMemcpyAsync(&h, lane->d_hit, sizeof(trx_hit), hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "copy failed");
+    if (!rc) rc = trace_rays_impl(s, lane->d_ray, 1, sem, lane->d_hit, st, false, nullptr, false, s->tlas ? d_inst : nullptr);
+    if (!rc && hipMemcpyAsync(&rec, lane->d_hit, s->tlas ? 12 : 8, hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "copy failed");
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "sync failed");
     if (rc) return rc;
+    const trx_hit h = rec.h;
     out->t = h.t;
     out->instance_id = 0xFFFFFFFFu;
     if (h.prim == 0xFFFFFFFFu) { // RayHit::none()
@@ -1049,6 +1191,7 @@ int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *ou
         out->primitive_id = h.prim - s->blas_tri_start[g];
         out->instance_id = g;
     }
+    if (s->tlas) out->instance_id = rec.inst; // the TLAS primitive the hit was found in
     return TRX_OK;
 }
 
@@ -1256,7 +1399,9 @@ void trx_bvh_total_aabb(const trx_bvh *b, float out6[6]) {
 double trx_bvh_build_seconds(const trx_bvh *b) { return b ? b->bvh.build_seconds : 0.0; }
 
 static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects, int use_tlas,
-                           uint32_t max_prims, int threads, const BuildSettings &settings, trx_flat **out);
+                           uint32_t max_prims, int threads, const BuildSettings &settings, trx_flat **out,
+                           const uint32_t *instance_object = nullptr, const float *instance_o2w = nullptr,
+                           uint32_t n_instances = 0);
 
 // BvhBuildParams of the reference (src/main.rs:571-585) applied for one build, then the process-wide settings
 // are put back; the stand-in builder has no PLOC stage, so the three PLOC fields only have to be sane.
@@ -1295,8 +1440,25 @@ int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32
     return flat_build_impl(verts, object_tri_counts, n_objects, use_tlas, max_prims, threads, build_settings(), out);
 }
 
+// One BLAS per object and a TLAS over INSTANCES of them: instance k places object instance_object[k] with the
+// affine object-to-world matrix instance_object_to_world + 16 k (column-major; NULL = identity for all).  The TLAS
+// boxes bound the transformed BLAS boxes; trx_flat.instance_transforms / instance_source come back in
+// TLAS-primitive order, ready for trx_scene_create + trx_scene_set_instance_transforms.
+int trx_flat_build_instanced(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects,
+                             const uint32_t *instance_object, const float *instance_object_to_world, uint32_t n_instances,
+                             uint32_t max_prims, int threads, trx_flat **out) {
+    if (!instance_object || n_instances == 0) return fail(TRX_ERR_INVALID, "no instances");
+    for (uint32_t k = 0; k < n_instances; k++) {
+        if (instance_object[k] >= n_objects) return fail(TRX_ERR_INVALID, "instance %u names object %u of %u", k, instance_object[k], n_objects);
+        if (object_tri_counts && object_tri_counts[instance_object[k]] == 0) return fail(TRX_ERR_INVALID, "instance %u names an empty object", k);
+    }
+    return flat_build_impl(verts, object_tri_counts, n_objects, 1, max_prims, threads, build_settings(), out, instance_object,
+                           instance_object_to_world, n_instances);
+}
+
 static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects, int use_tlas,
-                           uint32_t max_prims, int threads, const BuildSettings &settings, trx_flat **out) {
+                           uint32_t max_prims, int threads, const BuildSettings &settings, trx_flat **out,
+                           const uint32_t *instance_object, const float *instance_o2w, uint32_t n_instances) {
     if (!out || !object_tri_counts || n_objects == 0) return fail(TRX_ERR_INVALID, "null argument");
     if (max_prims < 1 || max_prims > 3) return fail(TRX_ERR_INVALID, "CWBVH only supports a maximum of 3 primitives per leaf.");
     uint64_t total = 0;
@@ -1307,9 +1469,13 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
     try {
         // without --tlas everything is flattened into the first object (src/main.rs:300-308)
         std::vector<uint64_t> counts;
+        std::vector<uint32_t> blas_of_object(n_objects, 0xFFFFFFFFu); // objects without triangles have no BLAS
         if (use_tlas) {
             for (uint32_t i = 0; i < n_objects; i++)
-                if (object_tri_counts[i]) counts.push_back(object_tri_counts[i]);
+                if (object_tri_counts[i]) {
+                    blas_of_object[i] = (uint32_t)counts.size();
+                    counts.push_back(object_tri_counts[i]);
+                }
             if (counts.empty()) counts.push_back(0);
         } else {
             counts.push_back(total);
@@ -1394,9 +1560,38 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             first += cnt;
         }
         blas_tri_start.push_back((uint32_t)(tri_out.size() / 9));
-        std::vector<uint32_t> inst;
+        std::vector<uint32_t> inst, inst_source;
+        std::vector<float> inst_xf;
         uint32_t tlas_start = 0;
         if (use_tlas) {
+            // what the TLAS is built over: one box per BLAS (the reference, src/cwbvh.rs:114), or one box per
+            // instance = the BLAS box carried to world space by the instance's transform, padded by a few ulps of
+            // its magnitude (the ray is taken to object space by the rounded INVERSE, which does not commute
+            // exactly with transforming the box forward)
+            std::vector<Aabb> tlas_boxes = blas_aabb;
+            if (instance_object) {
+                tlas_boxes.assign(n_instances, Aabb{});
+                for (uint32_t k = 0; k < n_instances; k++) {
+                    const Aabb &bb = blas_aabb[blas_of_object[instance_object[k]]];
+                    Aabb wb;
+                    for (int a = 0; a < 3; a++) { wb.mn[a] = 3.402823466e+38f; wb.mx[a] = -3.402823466e+38f; }
+                    for (int c = 0; c < 8; c++) {
+                        const float p[3] = {c & 1 ? bb.mx[0] : bb.mn[0], c & 2 ? bb.mx[1] : bb.mn[1], c & 4 ? bb.mx[2] : bb.mn[2]};
+                        float q[3] = {p[0], p[1], p[2]};
+                        if (instance_o2w) {
+                            const float *m = instance_o2w + (size_t)k * 16;
+                            for (int r = 0; r < 3; r++) q[r] = m[r] * p[0] + m[4 + r] * p[1] + m[8 + r] * p[2] + m[12 + r];
+                        }
+                        for (int a = 0; a < 3; a++) { wb.mn[a] = std::min(wb.mn[a], q[a]); wb.mx[a] = std::max(wb.mx[a], q[a]); }
+                    }
+                    for (int a = 0; a < 3; a++) {
+                        const float pad = 1e-5f * (std::max(std::fabs(wb.mn[a]), std::fabs(wb.mx[a])) + (wb.mx[a] - wb.mn[a])) + 1e-30f;
+                        wb.mn[a] -= pad;
+                        wb.mx[a] += pad;
+                    }
+                    tlas_boxes[k] = wb;
+                }
+            }
             // TLAS over the BLAS boxes (src/cwbvh.rs:114,132); instance table in TLAS
             // primitive order (mod.rs:72-78); TLAS nodes appended last (mod.rs:88-99)
             CwBvh tlas;
@@ -1408,9 +1603,13 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             // ... and an instance is dearer than a node visit: cost 3 instead of 0.3 keeps one instance per leaf
             // slot, each with its own quantised box (same scene: 62.7 -> 60.6 node visits per ray)
             bpt.prim_cost = std::max(bpt.prim_cost, 3.0f);
-            build_cwbvh_from_aabbs(blas_aabb.data(), blas_aabb.size(), bpt, tlas);
+            build_cwbvh_from_aabbs(tlas_boxes.data(), tlas_boxes.size(), bpt, tlas);
             tlas_s = tlas.build_seconds;
-            for (uint32_t pi : tlas.primitive_indices) inst.push_back(blas_offset[pi]);
+            for (uint32_t pi : tlas.primitive_indices) {
+                inst.push_back(blas_offset[instance_object ? blas_of_object[instance_object[pi]] : pi]);
+                inst_source.push_back(pi);
+                if (instance_o2w) inst_xf.insert(inst_xf.end(), instance_o2w + (size_t)pi * 16, instance_o2w + (size_t)pi * 16 + 16);
+            }
             tlas_start = (uint32_t)nodes.size();
             nodes.insert(nodes.end(), tlas.nodes.begin(), tlas.nodes.end());
         }
@@ -1434,6 +1633,12 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
         f->blas_tri_start = (uint32_t *)dup(blas_tri_start.data(), blas_tri_start.size() * 4);
         f->blas_build_s = blas_s;
         f->tlas_build_s = tlas_s;
+        f->instance_source = (uint32_t *)dup(inst_source.data(), inst_source.size() * 4);
+        f->instance_transforms = inst_xf.empty() ? nullptr : (float *)dup(inst_xf.data(), inst_xf.size() * 4);
+        if (!f->instance_source || (!inst_xf.empty() && !f->instance_transforms)) {
+            trx_flat_destroy(f);
+            return fail(TRX_ERR_OOM, "host allocation failed");
+        }
         if (!f->bvh_bytes || !f->tri_verts || !f->instance_offsets || !f->tri_source || !f->blas_tri_start || !f->tri_boxes) {
             trx_flat_destroy(f);
             return fail(TRX_ERR_OOM, "host allocation failed");
@@ -1453,6 +1658,8 @@ void trx_flat_destroy(trx_flat *f) {
     std::free(f->tri_source);
     std::free(f->blas_tri_start);
     std::free(f->tri_boxes);
+    std::free(f->instance_source);
+    std::free(f->instance_transforms);
     std::free(f);
 }
 

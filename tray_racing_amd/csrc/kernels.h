@@ -64,6 +64,12 @@ struct TraceParams {
     const trx_ray *rays;
     const trx_hit *primary;
     trx_hit *out;
+    // instance transforms (TLAS scenes; all null = the reference's identity behaviour): world-to-object rows
+    // {m0 m1 m2 t} x 3 per TLAS primitive; the instance each hit was found in, per record like `out`; the
+    // primary pass's instance ids (AO mode: to take the hit triangle's normal into world space)
+    const float4 *inst_xform;
+    uint32_t *out_inst;
+    const uint32_t *primary_inst;
     SlotCounters *ctr;
     uint2 *spill;
     uint32_t n_items;

@@ -27,7 +27,7 @@
 #define TRX_NODE_UNROLL 2
 #endif
 #ifndef TRX_TRI_PAIRS
-#define TRX_TRI_PAIRS 1 // per-lane triangle rounds test two triangles at once with packed f32 math
+#define TRX_TRI_PAIRS 0 // 1: per-lane triangle rounds test two triangles at once with packed f32 math (measured: no gain, +12 VGPRs)
 #endif
 
 #pragma clang fp contract(off)
@@ -171,6 +171,7 @@ __device__ __forceinline__ bool intersect_tri(const Ray &r, const float4 a, cons
     return false;
 }
 
+#if TRX_TRI_PAIRS
 // Two triangles against one ray with packed f32 math (v_pk_mul_f32 / v_pk_add_f32 are two IEEE operations
 // each): component k of every value is exactly what intersect_tri computes for triangle k.  Returns tt
 // (untested against t) and whether the barycentric / determinant test accepted it.
@@ -198,6 +199,7 @@ __device__ __forceinline__ void intersect_tri2(const Ray &r, const float4 a0, co
     ok0 = inv_det.x != 0.0f && (h0 & 0x80000000u) == 0;
     ok1 = inv_det.y != 0.0f && (h1 & 0x80000000u) == 0;
 }
+#endif
 
 __device__ __forceinline__ void finish_ray_dir(Ray &r, float dx, float dy, float dz) {
     r.dx = dx == 0.0f ? TRX_F32_EPSILON : dx;
@@ -347,6 +349,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     float t = 0.0f;
     uint32_t prim = TRX_INVALID, out_index = 0, sp = 0, steps = 0;
     uint32_t tlas_sp = TRX_INVALID, bvh_off = 0;
+    // instance transforms (TLAS): the instance being walked / the one the current hit was found in, and the
+    // world-space ray (origin, direction as given) to come back to when the BLAS is left
+    uint32_t cur_inst = TRX_INVALID, hit_inst = TRX_INVALID;
+    float wox = 0.0f, woy = 0.0f, woz = 0.0f, wdx = 0.0f, wdy = 0.0f, wdz = 0.0f;
     uint2 cur = make_uint2(0u, 0u);
     bool overflow = false;
     // COUNT only
@@ -529,6 +535,18 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                                 // normal of the hit triangle, flipped toward the viewer
                                 const float4 *tp = P.tris + (size_t)ph.prim * 3;
                                 float nx = tp[0].w, ny = tp[1].w, nz = tp[2].w; // cross(e1, e2)
+                                if (TLAS && P.inst_xform) {
+                                    // object-space normal -> world: transpose of world-to-object
+                                    const uint32_t pi = P.primary_inst[out_index];
+                                    if (pi != TRX_INVALID) {
+                                        const float4 *m = P.inst_xform + (size_t)pi * 3;
+                                        const float4 r0 = m[0], r1 = m[1], r2 = m[2];
+                                        const float ax = (r0.x * nx + r1.x * ny) + r2.x * nz;
+                                        const float ay = (r0.y * nx + r1.y * ny) + r2.y * nz;
+                                        const float az = (r0.z * nx + r1.z * ny) + r2.z * nz;
+                                        nx = ax; ny = ay; nz = az;
+                                    }
+                                }
                                 const float ninv = 1.0f / sqrtf(dot3(nx, ny, nz, nx, ny, nz));
                                 nx *= ninv; ny *= ninv; nz *= ninv;
                                 const float nd = (nx * -dx + ny * -dy) + nz * -dz;
@@ -560,6 +578,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                                 miss.t = __builtin_inff();
                                 miss.prim = TRX_INVALID;
                                 P.out[out_index] = miss;
+                                if (TLAS && P.out_inst) P.out_inst[out_index] = TRX_INVALID;
                             }
                         }
                         if (MODE != kModeRays) {
@@ -580,6 +599,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     if (TLAS) {
                         tlas_sp = TRX_INVALID;
                         bvh_off = P.tlas_start;
+                        cur_inst = hit_inst = TRX_INVALID;
+                        wox = r.ox; woy = r.oy; woz = r.oz;
+                        wdx = dx; wdy = dy; wdz = dz;
                     }
                     has_ray = true;
                 }
@@ -652,6 +674,22 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     if (COUNT) c_maxsp = max(c_maxsp, sp);
                     tlas_sp = sp;
                     bvh_off = P.inst[gidx];
+                    cur_inst = gidx;
+                    if (P.inst_xform) {
+                        // the ray in the instance's object space; the direction is not renormalised, so t keeps
+                        // its world-space meaning (the TODO at query_tlas.hlsl:433)
+                        const float4 *m = P.inst_xform + (size_t)gidx * 3;
+                        const float4 r0 = m[0], r1 = m[1], r2 = m[2];
+                        r.ox = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
+                        r.oy = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
+                        r.oz = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
+                        const float odx = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
+                        const float ody = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
+                        const float odz = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
+                        finish_ray_dir(r, odx, ody, odz);
+                        lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+                        lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+                    }
                     cur = make_uint2(0u, 0x80000000u);
                     tri.y = 0u;
                 }
@@ -713,10 +751,12 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         if (ok0 && tt.x >= r.tmin && (tie_first ? (tt.x < t) : (tt.x <= t))) {
                             t = tt.x;
                             prim = g0;
+                            if (TLAS) hit_inst = cur_inst;
                         }
                         if (two && ok1 && tt.y >= r.tmin && (tie_first ? (tt.y < t) : (tt.y <= t))) {
                             t = tt.y;
                             prim = g1;
+                            if (TLAS) hit_inst = cur_inst;
                         }
                     }
 #else
@@ -734,7 +774,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             if (lane_rank(__ballot(1)) == 0) c_wtri++;
                             if (P.touch_tris) P.touch_tris[gidx] = 1;
                         }
-                        if (intersect_tri(r, a, b, c4, t, tie_first)) prim = gidx;
+                        if (intersect_tri(r, a, b, c4, t, tie_first)) {
+                            prim = gidx;
+                            if (TLAS) hit_inst = cur_inst;
+                        }
                     }
 #endif
                 } else {
@@ -777,6 +820,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             if (tie_first ? (tt < t) : (tt <= t)) {
                                 t = tt;
                                 prim = rr.y;
+                                if (TLAS) hit_inst = cur_inst;
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -798,6 +842,13 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         if (TLAS && sp == tlas_sp) { // back to the TLAS (query_tlas.hlsl:480-486)
                             tlas_sp = TRX_INVALID;
                             bvh_off = P.tlas_start;
+                            cur_inst = TRX_INVALID;
+                            if (P.inst_xform) { // "Reset Ray to untransformed version" (query_tlas.hlsl:484)
+                                r.ox = wox; r.oy = woy; r.oz = woz;
+                                finish_ray_dir(r, wdx, wdy, wdz);
+                                lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+                                lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+                            }
                         }
                         sp--;
                         if (sp < (uint32_t)kLdsStack) cur = lds_stack[sp * kWave + lane];
@@ -825,6 +876,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     h.t = prim != TRX_INVALID ? t : __builtin_inff();
                     h.prim = prim;
                     P.out[out_index] = h;
+                    if (TLAS && P.out_inst) P.out_inst[out_index] = prim != TRX_INVALID ? hit_inst : TRX_INVALID;
                     if (COUNT) {
                         c_rays++;
                         c_hits += prim != TRX_INVALID;

@@ -71,7 +71,7 @@ class FlatScene:
     """The buffers rt_gpu_software::start receives: bvh_bytes, tri_bytes, instance_bytes, tlas_start."""
 
     def __init__(self, nodes, tri_verts, instance_offsets, tlas_start, tri_source, blas_tri_start,
-                 blas_build_s=0.0, tlas_build_s=0.0, tri_boxes=None):
+                 blas_build_s=0.0, tlas_build_s=0.0, tri_boxes=None, instance_source=None, instance_transforms=None):
         self.nodes = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 20)
         self.tri_verts = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
         self.instance_offsets = np.ascontiguousarray(instance_offsets, dtype=np.uint32)
@@ -82,6 +82,11 @@ class FlatScene:
         self.tlas_build_s = tlas_build_s
         # box every triangle entry was built with (pre-split references cover only part of their triangle)
         self.tri_boxes = None if tri_boxes is None else np.ascontiguousarray(tri_boxes, dtype=np.float32).reshape(-1, 6)
+        # TLAS primitive k = the caller's object / instance instance_source[k]; object-to-world 4x4 (column-major)
+        # per TLAS primitive, or None = identity (the reference, src/cwbvh.rs:163-165)
+        self.instance_source = None if instance_source is None else np.ascontiguousarray(instance_source, dtype=np.uint32)
+        self.instance_transforms = None if instance_transforms is None else np.ascontiguousarray(
+            instance_transforms, dtype=np.float32).reshape(-1, 16)
 
     @property
     def n_nodes(self):
@@ -131,9 +136,29 @@ def _take_flat(lib, fp):
         src = np.ctypeslib.as_array(f.tri_source, shape=(max(f.n_tris, 1),))[: f.n_tris].copy()
         bts = np.ctypeslib.as_array(f.blas_tri_start, shape=(f.n_blas + 1,)).copy()
         boxes = np.ctypeslib.as_array(f.tri_boxes, shape=(max(f.n_tris, 1), 6))[: f.n_tris].copy()
-        return FlatScene(nodes, tris, inst, f.tlas_start, src, bts, f.blas_build_s, f.tlas_build_s, boxes)
+        isrc = np.ctypeslib.as_array(f.instance_source, shape=(max(f.n_instances, 1),))[: f.n_instances].copy()
+        ixf = None
+        if f.instance_transforms:
+            ixf = np.ctypeslib.as_array(f.instance_transforms, shape=(max(f.n_instances, 1), 16))[: f.n_instances].copy()
+        return FlatScene(nodes, tris, inst, f.tlas_start, src, bts, f.blas_build_s, f.tlas_build_s, boxes, isrc, ixf)
     finally:
         lib.trx_flat_destroy(fp)
+
+
+def flat_build_instanced(verts, object_counts, instance_object, object_to_world=None, max_prims_per_leaf=3, threads=0):
+    """One BLAS per object, a TLAS over instances of them (trx_flat_build_instanced).  object_to_world: [n, 16]
+    column-major affine matrices (glam Mat4), or None for identity."""
+    lib = L.load()
+    verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
+    counts = np.ascontiguousarray(object_counts, dtype=np.uint64)
+    io = np.ascontiguousarray(instance_object, dtype=np.uint32)
+    xf = None if object_to_world is None else np.ascontiguousarray(object_to_world, dtype=np.float32).reshape(-1, 16)
+    if xf is not None and xf.shape[0] != io.size:
+        raise L.TrxError(L.TRX_ERR_INVALID, "one transform per instance")
+    fp = C.POINTER(L.Flat)()
+    L.check(lib.trx_flat_build_instanced(_ptr(verts), _ptr(counts), counts.size, _ptr(io), _ptr(xf) if xf is not None else None,
+                                         io.size, max_prims_per_leaf, threads, C.byref(fp)))
+    return _take_flat(lib, fp)
 
 
 def build_params(**fields):
@@ -191,6 +216,30 @@ class Scene:
         if flat.blas_tri_start.size > 1:
             L.check(lib.trx_scene_set_geometry_ranges(self._h, _ptr(flat.blas_tri_start),
                                                       flat.blas_tri_start.size - 1))
+        if getattr(flat, "instance_transforms", None) is not None:
+            self.set_instance_transforms(flat.instance_transforms)
+
+    def set_instance_transforms(self, object_to_world):
+        """Object-to-world 4x4 (column-major) per TLAS primitive; None restores identity."""
+        if object_to_world is None:
+            L.check(self._lib.trx_scene_set_instance_transforms(self._h, None, 0))
+            return
+        xf = np.ascontiguousarray(object_to_world, dtype=np.float32).reshape(-1, 16)
+        L.check(self._lib.trx_scene_set_instance_transforms(self._h, _ptr(xf), xf.shape[0]))
+
+    def instance_transform(self, instance_id):
+        """Traversable::get_instance_transform (traversable/src/lib.rs:25-27): object-to-world, column-major."""
+        m = np.zeros(16, dtype=np.float32)
+        L.check(self._lib.trx_scene_get_instance_transform(self._h, instance_id, _ptr(m)))
+        return m
+
+    def instance_world_to_object(self):
+        """[n_instances, 12] world-to-object rows exactly as the kernels use them."""
+        n = self.flat.instance_offsets.size
+        out = np.zeros((n, 12), dtype=np.float32)
+        for k in range(n):
+            L.check(self._lib.trx_scene_get_instance_world_to_object(self._h, k, _ptr(out[k])))
+        return out
 
     def close(self):
         if self._h:
@@ -225,6 +274,24 @@ class Scene:
         L.check(self._lib.trx_trace_primary_ao(self._h, C.byref(view), width, height, sem, frame, ao_eps, _ptr(prim),
                                                _ptr(ao), C.byref(ms)))
         return prim, ao, ms.value
+
+    def trace_primary_ao_inst(self, view, width, height, sem=L.SEM_HLSL, frame=0, ao_eps=0.01):
+        """(primary, primary instance ids, ao, ao instance ids, ms): RayHit.instance_id beside every hit."""
+        n = width * height
+        prim, ao = np.empty(n, dtype=HIT_DTYPE), np.empty(n, dtype=HIT_DTYPE)
+        pi, ai = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
+        ms = C.c_float()
+        L.check(self._lib.trx_trace_primary_ao_inst(self._h, C.byref(view), width, height, sem, frame, ao_eps, _ptr(prim),
+                                                    _ptr(pi), _ptr(ao), _ptr(ai), C.byref(ms)))
+        return prim, pi, ao, ai, ms.value
+
+    def trace_rays_inst(self, rays, sem=L.SEM_HLSL):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.empty(rays.shape[0], dtype=HIT_DTYPE)
+        inst = np.empty(rays.shape[0], dtype=np.uint32)
+        ms = C.c_float()
+        L.check(self._lib.trx_trace_rays_inst(self._h, _ptr(rays), rays.shape[0], sem, _ptr(hits), _ptr(inst), C.byref(ms)))
+        return hits, inst, ms.value
 
     def trace_rays(self, rays, sem=L.SEM_HLSL):
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
