@@ -174,19 +174,24 @@ def w2o_rows(o2w16):
     return np.linalg.inv(M)[:3, :].reshape(12).astype(np.float32)
 
 
-def instanced_scene(T, seed=3, n_objects=3, n_instances=10, tris_per_object=400):
+def instanced_scene(T, seed=3, n_objects=3, n_instances=10, tris_per_object=400, kind="soup", spread=4.0):
     """A few small triangle-soup objects and `n_instances` transformed instances of them (several per object).
     Returns (flat, object_to_world in TLAS-primitive order, world-space triangles [n, 9] instance-major in
     TLAS-primitive order, first world triangle of every TLAS primitive)."""
     rng = np.random.default_rng(seed)
-    verts, counts = [], []
-    for o in range(n_objects):
-        v, _ = T.gen_scene("soup", tris_per_object + 37 * o, seed + o)
-        verts.append(v)
-        counts.append(v.shape[0])
-    verts = np.concatenate(verts)
+    if kind == "soup":
+        verts, counts = [], []
+        for o in range(n_objects):
+            v, _ = T.gen_scene("soup", tris_per_object + 37 * o, seed + o)
+            verts.append(v)
+            counts.append(v.shape[0])
+        verts = np.concatenate(verts)
+    else:   # the objects of a procedural scene (walls, boxes ...: large triangles, dense images)
+        verts, counts = T.gen_scene(kind, tris_per_object, seed)
+        counts = [int(c) for c in counts if c]
+        n_objects = len(counts)
     inst_obj = np.array([k % n_objects for k in range(n_instances)], dtype=np.uint32)
-    o2w = np.stack([random_affine(rng) for _ in range(n_instances)])
+    o2w = np.stack([random_affine(rng, spread=spread) for _ in range(n_instances)])
     o2w[0] = np.eye(4, dtype=np.float32).reshape(16)        # one identity instance among them
     flat = T.flat_build_instanced(verts, counts, inst_obj, o2w)
     # world-space geometry, in float64 then f32, for the BVH-independent brute-force query

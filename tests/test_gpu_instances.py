@@ -38,11 +38,11 @@ def test_transformed_instances_explicit_rays_all_semantics(trx, orc):
 
 
 def test_transformed_instances_primary_and_ao_frames(trx, orc):
-    flat, sc, osc, world = _scene_and_oracle(trx, orc, n_instances=14, tris_per_object=900)
+    flat, sc, osc, world = _scene_and_oracle(trx, orc, n_instances=14, tris_per_object=0, kind="cornell", spread=1.0)
     w, h = 200, 120
     lo, hi = world.reshape(-1, 3).min(0), world.reshape(-1, 3).max(0)
-    eye = (hi + 0.8 * (hi - lo)).tolist()
-    view = trx.view_from_camera(eye, (0.5 * (lo + hi)).tolist(), 55.0, w, h)
+    eye = (hi + 0.1 * (hi - lo)).tolist()
+    view = trx.view_from_camera(eye, (0.5 * (lo + hi)).tolist(), 80.0, w, h)
     ov = orc.view_from_bytes(bytes(view))
     for sem in (0, 3):
         gp, gpi, gao, gaoi, ms = sc.trace_primary_ao_inst(view, w, h, sem=sem, frame=3, ao_eps=0.01)
