@@ -22,7 +22,7 @@ def bench_ao(sc, view, w, h, frames, sem=3):
     return best_f, hits
 
 
-for name, w, h, tlas in [("kitchen", 1920, 1080, False), ("bistro", 1920, 1080, False), ("hairball", 1920, 1080, False),
+for name, w, h, tlas in [("kitchen", 1920, 1080, False), ("bistro", 1920, 1080, False), ("bistro_dense", 1920, 1080, False), ("hairball", 1920, 1080, False),
                          ("san_miguel", 3840, 2160, True), ("demoscene", 512, 1080, False)]:
     verts, counts = T.gen_scene(name, 0, 1)
     t0 = time.time()

@@ -10,6 +10,7 @@ import tray_racing_amd as T  # noqa: E402
 from tray_racing_amd import _lib as L  # noqa: E402
 
 lib = L.load()
+lib.trx_set_kernel_variant(int(os.environ.get("TRX_VARIANT", "0"), 0))
 name = sys.argv[1] if len(sys.argv) > 1 else "bistro"
 w, h = 1920, 1080
 verts, counts = T.gen_scene(name, 0, 1)

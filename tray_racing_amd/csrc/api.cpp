@@ -360,6 +360,12 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.refill_idle = refill ? std::min(refill, 64u) : (mode == kModePrimary ? 64u : 20u);
     if (p.n_frames > 1) p.refill_idle = 64u; // the kernel takes the frame of a wave from its (whole) tile
     p.variant = variant;
+    {
+        const char *tune = getenv("TRX_TUNE"); // development switches
+        p.tune = tune ? (uint32_t)strtoul(tune, nullptr, 0) : 0u;
+    }
+    p.n_tris = (uint32_t)s->n_tris;
+    p.n_nodes = (uint32_t)s->n_nodes;
     {   // tuning: variant bits 25..28 = compaction threshold (0 = default, 15 = never)
         const uint32_t c = (variant >> 25) & 0xfu;
         p.tri_compact_min = c == 0u ? 2u : c == 15u ? 0xffffffffu : c;

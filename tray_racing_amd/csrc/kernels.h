@@ -95,6 +95,8 @@ struct TraceParams {
     uint32_t tri_compact_min; // consider spreading the wave's triangle tests over all lanes when a lane owns this many
     uint32_t tri_coop_ratio;  // ... and do it when the largest per-lane count exceeds this x the cooperative rounds
     uint32_t variant;
+    uint32_t tune;                   // development switches (TRX_TUNE environment word), 0 in the product
+    uint32_t n_tris, n_nodes;        // buffer extents (prefetch addresses are clamped to them)
     uint32_t waves_per_block;        // 1, 2 or 4
     unsigned long long *wave_times;  // diagnostics: [8*wave] start, [8*wave+1] end (wall_clock64), [+2..7] phase cycles in TRX_STAMPS builds; or null
     // frames per launch (image modes): frame f = local_tile / tiles_per_frame uses views[f] and writes its

@@ -348,13 +348,14 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     r.oct_inv4 = 0;
     float t = 0.0f;
     uint32_t prim = TRX_INVALID, out_index = 0, sp = 0, steps = 0;
+    uint32_t trip = 0; // traversal-loop trips of this wave (uniform)
     uint32_t tlas_sp = TRX_INVALID, bvh_off = 0;
     // instance transforms (TLAS): the instance being walked / the one the current hit was found in, and the
     // world-space ray (origin, direction as given) to come back to when the BLAS is left
     uint32_t cur_inst = TRX_INVALID, hit_inst = TRX_INVALID;
     float wox = 0.0f, woy = 0.0f, woz = 0.0f, wdx = 0.0f, wdy = 0.0f, wdz = 0.0f;
     uint2 cur = make_uint2(0u, 0u);
-    bool overflow = false;
+    uint32_t overflow = 0; // sticky, set on the rare paths only (stack past its HBM part, step cap)
     // COUNT only
     uint32_t c_node = 0, c_tri = 0, c_rays = 0, c_hits = 0, c_maxsp = 0, c_over = 0;
     uint32_t c_wnode = 0, c_wtri = 0; // wave-level executions (leader lane only): SIMD-efficiency denominators
@@ -593,8 +594,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
                     prim = TRX_INVALID;
                     sp = 0;
-                    steps = 0;
-                    overflow = false;
+                    steps = trip; // the wave trip this ray starts at
+                    overflow = 0u;
                     cur = make_uint2(0u, 0x80000000u);
                     if (TLAS) {
                         tlas_sp = TRX_INVALID;
@@ -617,91 +618,40 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         // The loop is wave-uniform (every lane iterates, work is predicated on `act`), so that the
         // triangle phase can use all 64 lanes whichever lanes own the triangles.
         const uint32_t keep = kWave - P.refill_idle; // leave when this few lanes remain
-        for (;;) {
-            const bool act = has_ray;
-            uint2 tri = make_uint2(0u, 0u);
-            if (act) {
-                if (cur.y & 0xff000000u) {
-                    const uint32_t hits_imask = cur.y;
-                    const uint32_t child_bit = 31u - (uint32_t)__clz((int)hits_imask);
-                    const uint32_t child_base = cur.x;
-                    cur.y &= ~(1u << child_bit);
-                    if (cur.y & 0xff000000u) {
-                        if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = cur;
-                        else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave] = cur;
-                        else overflow = true;
-                        sp++;
-                        if (COUNT) c_maxsp = max(c_maxsp, sp);
-                    }
-                    const uint32_t slot = (child_bit - 24u) ^ (r.oct_inv4 & 0xffu);
-                    const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
-                    uint32_t node_index = child_base + rel;
-                    if (TLAS) node_index += bvh_off;
-                    const uint4 *np = P.nodes + (size_t)node_index * 5;
-                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                    TRX_STAMP(k_fetch);
-                    if (COUNT) {
-                        c_node++;
-                        if (lane_rank(__ballot(1)) == 0) c_wnode++;
-                        if (P.touch_nodes) P.touch_nodes[node_index] = 1;
-                    }
-                    const uint32_t hitmask = node_intersect<NODE>(r, t, n0, n1, n2, n3, n4);
-                    cur.x = n1.x;
-                    tri.x = n1.y;
-                    cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
-                    tri.y = hitmask & 0x00ffffffu;
-                } else {
-                    tri = cur;
-                    cur = make_uint2(0u, 0u);
+        // Stack push / pop.  Fast path: every lane's top is inside the LDS part, so the write needs no
+        // predication at all (an entry above a lane's top is free to clobber) and the whole push is one
+        // ds_write_b64 plus a conditional increment; lanes past the LDS part (rare: depth > kLdsStack) take the
+        // general path behind a wave-uniform branch.
+        auto stack_push = [&](uint2 e, bool cond) {
+            if (__builtin_expect(__ballot(sp >= (uint32_t)kLdsStack) != 0ull, 0)) {
+                if (cond) {
+                    if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = e;
+                    else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave] = e;
+                    else overflow = 1u;
                 }
-                if (TLAS && tlas_sp == TRX_INVALID && tri.y != 0u) {
-                    // a TLAS primitive is an instance (query_tlas.hlsl:410-446): enter its BLAS
-                    const uint32_t local = 31u - (uint32_t)__clz((int)tri.y);
-                    tri.y &= ~(1u << local);
-                    const uint32_t gidx = tri.x + local;
-                    if (tri.y != 0u) {
-                        if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = tri;
-                        else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave] = tri;
-                        else overflow = true;
-                        sp++;
-                    }
-                    if (cur.y & 0xff000000u) {
-                        if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = cur;
-                        else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave] = cur;
-                        else overflow = true;
-                        sp++;
-                    }
-                    if (COUNT) c_maxsp = max(c_maxsp, sp);
-                    tlas_sp = sp;
-                    bvh_off = P.inst[gidx];
-                    cur_inst = gidx;
-                    if (P.inst_xform) {
-                        // the ray in the instance's object space; the direction is not renormalised, so t keeps
-                        // its world-space meaning (the TODO at query_tlas.hlsl:433)
-                        const float4 *m = P.inst_xform + (size_t)gidx * 3;
-                        const float4 r0 = m[0], r1 = m[1], r2 = m[2];
-                        r.ox = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
-                        r.oy = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
-                        r.oz = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
-                        const float odx = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
-                        const float ody = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
-                        const float odz = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
-                        finish_ray_dir(r, odx, ody, odz);
-                        lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
-                        lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
-                    }
-                    cur = make_uint2(0u, 0x80000000u);
-                    tri.y = 0u;
-                }
+            } else {
+                lds_stack[sp * kWave + lane] = e;
             }
+            sp += cond ? 1u : 0u;
+            if (COUNT) c_maxsp = max(c_maxsp, sp);
+        };
+        auto stack_pop = [&]() -> uint2 { // callers guarantee sp != 0
+            sp--;
+            if (__builtin_expect(__ballot(sp >= (uint32_t)kLdsStack) != 0ull, 0)) {
+                if (sp < (uint32_t)kLdsStack) return lds_stack[sp * kWave + lane];
+                if (sp < (uint32_t)(kLdsStack + kSpillStack)) return spill[(sp - kLdsStack) * kWave];
+                return make_uint2(0u, 0u);
+            }
+            return lds_stack[sp * kWave + lane];
+        };
 
-            TRX_STAMP(k_test);
-            // ---- triangle phase ---------------------------------------------------------
+        // ---- triangle phase ---------------------------------------------------------
             // Each lane owns cnt triangle tests (the hit leaves of its node, highest bit first).
             // Few per lane: every owner tests its own, one round per triangle.  Otherwise the
             // wave's (ray, triangle) pairs are laid out densely over all 64 lanes: pair g goes to
             // lane g % 64, tests read the owner's ray from LDS, and owners then commit their
             // results in order, so a ray's triangle sequence (and its tie rule) is unchanged.
+        auto triangle_phase = [&](uint2 tri) {
             const uint32_t cnt = (uint32_t)__popc(tri.y);
             if (__ballot(cnt != 0u) != 0ull) {
                 if (COUNT) {
@@ -761,7 +711,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     }
 #else
                     while (tri.y != 0u) {
-                        const uint32_t local = 31u - (uint32_t)__clz((int)tri.y);
+                        const uint32_t local = 31u - (uint32_t)__builtin_clz(tri.y); // tri.y != 0
                         tri.y &= ~(1u << local);
                         const uint32_t gidx = tri.x + local;
                         const float4 *tp = P.tris + (size_t)gidx * 3;
@@ -829,6 +779,75 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 }
             }
 
+        };
+
+
+        for (;;) {
+            const bool act = has_ray;
+            uint2 tri = make_uint2(0u, 0u);
+            trip++;
+            if (act) {
+                // BLAS-only: a lane at the top of the loop always holds a node group (triangle groups are drained
+                // in the trip that found them; only the TLAS walk parks them on the stack)
+                if (!TLAS || (cur.y & 0xff000000u)) {
+                    const uint32_t hits_imask = cur.y;
+                    const uint32_t child_bit = 31u - (uint32_t)__builtin_clz(hits_imask); // hits_imask != 0
+                    const uint32_t child_base = cur.x;
+                    cur.y &= ~(1u << child_bit);
+                    const uint32_t slot = (child_bit - 24u) ^ (r.oct_inv4 & 0xffu);
+                    const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
+                    uint32_t node_index = child_base + rel;
+                    if (TLAS) node_index += bvh_off;
+                    const uint4 *np = P.nodes + (size_t)node_index * 5;
+                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                    stack_push(cur, (cur.y & 0xff000000u) != 0u); // after the loads are on their way
+                    TRX_STAMP(k_fetch);
+                    if (COUNT) {
+                        c_node++;
+                        if (lane_rank(__ballot(1)) == 0) c_wnode++;
+                        if (P.touch_nodes) P.touch_nodes[node_index] = 1;
+                    }
+                    const uint32_t hitmask = node_intersect<NODE>(r, t, n0, n1, n2, n3, n4);
+                    cur.x = n1.x;
+                    tri.x = n1.y;
+                    cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                    tri.y = hitmask & 0x00ffffffu;
+                } else {
+                    tri = cur;
+                    cur = make_uint2(0u, 0u);
+                }
+                if (TLAS && tlas_sp == TRX_INVALID && tri.y != 0u) {
+                    // a TLAS primitive is an instance (query_tlas.hlsl:410-446): enter its BLAS
+                    const uint32_t local = 31u - (uint32_t)__clz((int)tri.y);
+                    tri.y &= ~(1u << local);
+                    const uint32_t gidx = tri.x + local;
+                    stack_push(tri, tri.y != 0u);
+                    stack_push(cur, (cur.y & 0xff000000u) != 0u);
+                    tlas_sp = sp;
+                    bvh_off = P.inst[gidx];
+                    cur_inst = gidx;
+                    if (P.inst_xform) {
+                        // the ray in the instance's object space; the direction is not renormalised, so t keeps
+                        // its world-space meaning (the TODO at query_tlas.hlsl:433)
+                        const float4 *m = P.inst_xform + (size_t)gidx * 3;
+                        const float4 r0 = m[0], r1 = m[1], r2 = m[2];
+                        r.ox = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
+                        r.oy = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
+                        r.oz = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
+                        const float odx = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
+                        const float ody = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
+                        const float odz = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
+                        finish_ray_dir(r, odx, ody, odz);
+                        lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+                        lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+                    }
+                    cur = make_uint2(0u, 0x80000000u);
+                    tri.y = 0u;
+                }
+            }
+
+            TRX_STAMP(k_test);
+            triangle_phase(tri);
             TRX_STAMP(k_tri);
 #ifdef TRX_STAMPS
             k_iters++;
@@ -850,14 +869,13 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                                 lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
                             }
                         }
-                        sp--;
-                        if (sp < (uint32_t)kLdsStack) cur = lds_stack[sp * kWave + lane];
-                        else if (sp < (uint32_t)(kLdsStack + kSpillStack)) cur = spill[(sp - kLdsStack) * kWave];
-                        else cur = make_uint2(0u, 0u);
+                        cur = stack_pop();
                     }
                 }
-                if (++steps > kMaxSteps) {
-                    overflow = true;
+                // step cap (every wave reaches an exit whatever the tree): a ray's steps are bounded by the wave's
+                // trips since it started; looked at once per 1024 trips, so the common trip pays nothing for it
+                if (__builtin_expect((trip & 1023u) == 0u, 0) && trip - steps > kMaxSteps) {
+                    overflow = 1u;
                     done = true;
                 }
                 // any-hit query (intersects_bl_bvh, query.hlsl:440-445): the first accepted triangle settles it.
@@ -869,7 +887,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         c_rays++;
                         c_hits += prim != TRX_INVALID;
                     }
-                    c_over += overflow ? 1u : 0u;
+                    c_over += overflow;
                     has_ray = false;
                 } else if (done) {
                     trx_hit h;
@@ -881,7 +899,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         c_rays++;
                         c_hits += prim != TRX_INVALID;
                     }
-                    c_over += overflow ? 1u : 0u;
+                    c_over += overflow;
                     has_ray = false;
                 }
             }
