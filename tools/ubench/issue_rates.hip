@@ -25,6 +25,7 @@ template <int VAR>
 __global__ void __launch_bounds__(1024) k_issue(const uint4 *nodes, uint32_t n_nodes, uint32_t *out, unsigned long long *cyc,
                                                 int iters, float negzero) {
     __shared__ uint2 lds[1024 * 2];
+    if (VAR >= 8) { lds[threadIdx.x] = make_uint2(threadIdx.x * 2654435761u, threadIdx.x); lds[threadIdx.x + 1024] = make_uint2(threadIdx.x * 40503u, 77u); __syncthreads(); }
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint4 *np = nodes + (size_t)(tid % n_nodes) * 8;
     uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
@@ -52,6 +53,19 @@ __global__ void __launch_bounds__(1024) k_issue(const uint4 *nodes, uint32_t n_n
                 asm volatile(BR1(0) BR1(1) BR1(2) BR1(3) BR1(4) BR1(5) BR1(6) BR1(7) : "+v"(dummy) :: "s20", "scc");
                 asm volatile(BR1(0) BR1(1) BR1(2) BR1(3) BR1(4) BR1(5) BR1(6) BR1(7) : "+v"(dummy) :: "s20", "scc");
                 asm volatile(BR1(0) BR1(1) BR1(2) BR1(3) BR1(4) BR1(5) BR1(6) BR1(7) : "+v"(dummy) :: "s20", "scc");
+            }
+            if (VAR == 6 || VAR == 7) {
+                // the next node's 80 bytes (L1 / L2 hits): VAR 6 every lane the same node, VAR 7 a node per lane
+                const uint32_t idx = VAR == 6 ? ((acc >> 3) + blockIdx.x) % n_nodes : ((acc >> 3) + tid * 7u) % n_nodes;
+                const uint4 *q = nodes + (size_t)idx * 8;
+                n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; n4 = q[4];
+            }
+            if (VAR == 8 || VAR == 9) {
+                const uint32_t idx = VAR == 8 ? ((acc >> 3) & 63u) : ((acc >> 3) + threadIdx.x) & 63u;
+                const uint4 *q = reinterpret_cast<const uint4 *>(lds) + idx * 5;
+                n2 = q[2]; n3 = q[3]; n4 = q[4];
+                const uint4 a = q[0], b = q[1];
+                n0.w = a.w; n1.z = b.z; n1.w = b.w;
             }
             if (VAR == 3) {
 #pragma unroll
@@ -119,5 +133,9 @@ int main() {
     run<3>("+ 8 LDS write/read pairs", d_nodes, n_nodes, d_out, d_cyc, cus);
     run<4>("body unrolled 8x (~12 KB loop)", d_nodes, n_nodes, d_out, d_cyc, cus);
     run<5>("+ 96 SALU + 24 taken branches", d_nodes, n_nodes, d_out, d_cyc, cus);
+    run<6>("+ node fetch, 5 x dwordx4, wave-uniform", d_nodes, n_nodes, d_out, d_cyc, cus);
+    run<7>("+ node fetch, 5 x dwordx4, a node per lane", d_nodes, n_nodes, d_out, d_cyc, cus);
+    run<8>("+ node from LDS, 5 x b128, wave-uniform", d_nodes, n_nodes, d_out, d_cyc, cus);
+    run<9>("+ node from LDS, 5 x b128, a node per lane", d_nodes, n_nodes, d_out, d_cyc, cus);
     return 0;
 }

@@ -662,7 +662,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     }
                     if (lane == 0) {
                         atomicAdd(&P.ctr->hist_max[min(mx, 15u)], 1u);
-                        atomicAdd(&P.ctr->hist_total[min((sum + 7u) >> 3, 15u)], 1u);
+                        if (!(P.tune & 0x100u)) atomicAdd(&P.ctr->hist_total[min((sum + 7u) >> 3, 15u)], 1u);
                     }
                 }
                 // Cooperative rounds cost about three per-lane rounds of VALU work (scans, owner look-up, the LDS
@@ -798,6 +798,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
                     uint32_t node_index = child_base + rel;
                     if (TLAS) node_index += bvh_off;
+                    // (tried: when every lane wants the same node - 47 % of the wave-level steps on the bistro-class frame,
+                    // 90 % on the kitchen-class one - one copy through the scalar cache instead of 64 through the vector
+                    // path: no change in frame time)
                     const uint4 *np = P.nodes + (size_t)node_index * 5;
                     const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
                     stack_push(cur, (cur.y & 0xff000000u) != 0u); // after the loads are on their way
@@ -806,6 +809,19 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         c_node++;
                         if (lane_rank(__ballot(1)) == 0) c_wnode++;
                         if (P.touch_nodes) P.touch_nodes[node_index] = 1;
+                        if (P.tune & 0x100u) {
+                            // diagnostics: distinct nodes among the lanes of this wave-level node step
+                            unsigned long long todo = __ballot(1);
+                            const uint32_t first = (uint32_t)__ffsll((long long)todo) - 1u;
+                            uint32_t distinct = 0;
+                            while (todo) {
+                                const uint32_t l = (uint32_t)__ffsll((long long)todo) - 1u;
+                                const uint32_t v = (uint32_t)__shfl((int)node_index, (int)l);
+                                todo &= ~__ballot(node_index == v);
+                                distinct++;
+                            }
+                            if (lane == first) atomicAdd(&P.ctr->hist_total[min(distinct, 15u)], 1u);
+                        }
                     }
                     const uint32_t hitmask = node_intersect<NODE>(r, t, n0, n1, n2, n3, n4);
                     cur.x = n1.x;
