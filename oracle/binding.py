@@ -58,6 +58,7 @@ def load():
     VP, SP, STP = C.POINTER(View), C.POINTER(SceneC), C.POINTER(Stats)
     sigs = {
         "orc_tris_from_verts": (None, [P, u64, P]),
+        "orc_set_ao_libm": (None, [i]),
         "orc_tris_from_f16": (None, [P, u64, P]),
         "orc_view_from_camera": (None, [P, P, f, f, f, VP]),
         "orc_octant_inv4": (u32, [P]),
@@ -91,6 +92,11 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def set_ao_libm(on):
+    """Measurement aid: AO directions from libm sinf / cosf instead of the explicit polynomial (oracle only)."""
+    load().orc_set_ao_libm(1 if on else 0)
 
 
 def _ptr(a):

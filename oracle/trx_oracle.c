@@ -225,7 +225,18 @@ float orc_hash_noise(uint32_t x, uint32_t y, uint32_t frame) {
  * Both this oracle and the kernels use the same explicit evaluation instead:
  * Cody-Waite reduction by pi/2 and the cephes single-precision minimax
  * polynomials on [-pi/4, pi/4] (max error ~1 ulp). */
+static int g_ao_libm = 0;
+/* Exposure measurement only (tools/semantics_exposure.py): AO directions from this platform's libm sinf / cosf, the
+ * way the reference calls its platform's (sampling.hlsl:33-34), instead of the explicit evaluation below.  The
+ * product has no such switch; the count of AO rays whose hit changes is what "parity unpinned" costs here. */
+void orc_set_ao_libm(int on) { g_ao_libm = on; }
+
 void orc_sincos(float theta, float *s, float *c) {
+    if (g_ao_libm) {
+        *s = sinf(theta);
+        *c = cosf(theta);
+        return;
+    }
     float kf = floorf(theta * 0.636619772f + 0.5f); /* round(theta * 2/pi) */
     int k = (int)kf;
     float r = theta - kf * 1.5703125f;              /* pi/2 split: hi */

@@ -99,6 +99,7 @@ int orc_ao_ray(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h,
 uint32_t orc_uhash(uint32_t a, uint32_t b);
 float orc_hash_noise(uint32_t x, uint32_t y, uint32_t frame);
 void orc_sincos(float theta, float *s, float *c);
+void orc_set_ao_libm(int on); /* measurement aid: libm sinf / cosf in the AO direction */
 
 /* single ray through the CWBVH (BLAS-only when n_instances == 0) */
 orc_hit orc_traverse(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax,
