@@ -782,6 +782,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         };
 
 
+
         for (;;) {
             const bool act = has_ray;
             uint2 tri = make_uint2(0u, 0u);
