@@ -96,6 +96,9 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (child processes)")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (cold order, HLSL, pipelined, HBM copy)")
     ap.add_argument("--sim-shards", type=int, default=1, help=argparse.SUPPRESS)
+    ap.add_argument("--gather", default="torch", choices=["torch", "abi"],
+                    help="N > 1: the shard gather through torch.distributed (default) or through the C ABI "
+                         "(trx_comm_* / trx_gather_shards / trx_assemble_frames: RCCL driven by libtrx.so itself)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the shard gather through host memory (lets N ranks share one GPU in tests)")
     ap.add_argument("--dump-frame", default="", help="rank 0 writes the last timed frame (int64 {t, prim} records, "
@@ -209,7 +212,11 @@ def main():
     # collectives).  Batch b runs on stream b % streams: F kernels back to back, the all-gather, the
     # de-interleave; `streams` batches are in flight, so a gather overlaps the tracing of other batches.
     F = 1 if world == 1 else (args.gather_batch if args.gather_batch > 0 else 8)
-    fgs = [D.FrameGather(w, h, rank, world, "cuda", batch=F) for _ in range(n_streams)] if world > 1 else []
+    if world > 1 and args.gather == "abi" and args.dist_backend == "nccl":
+        # one communicator per stream's buffer (RCCL orders the collectives of a communicator on its stream)
+        fgs = [D.AbiFrameGather.from_process_group(w, h, torch.device("cuda", local_rank), batch=F) for _ in range(n_streams)]
+    else:
+        fgs = [D.FrameGather(w, h, rank, world, "cuda", batch=F) for _ in range(n_streams)] if world > 1 else []
     frames = [torch.empty(F * n_rays_total, dtype=torch.int64, device="cuda") for _ in range(n_streams)]
     state = {"k": 0, "batch": 0, "last": None}
 
@@ -262,7 +269,8 @@ def main():
                 e_g0.record(s)
                 if args.dist_backend == "nccl":
                     work = fg.gather(m=m, async_op=True)         # the one collective: 8 B/ray, m frames at once
-                    work.wait()                                   # stream s (not the host) waits for it
+                    if work is not None:
+                        work.wait()                               # stream s (not the host) waits for it
                 else:  # test mode: the same gather staged through host memory
                     s.synchronize()
                     nrec = m * fg.records
@@ -484,8 +492,9 @@ def main():
                 "trace": round(kernel_ms, 4),
                 "gather": round(sum(a.elapsed_time(b) for a, b, _, _ in phases) / nf, 4),
                 "assemble": round(sum(b.elapsed_time(c) for _, b, c, _ in phases) / nf, 4),
-                "collective_world_size": dist.get_world_size(),
+                "collective_world_size": fgs[0].world_size() if hasattr(fgs[0], "world_size") else dist.get_world_size(),
                 "backend": dist.get_backend(),
+                "gather_via": args.gather,
             }
 
     if rank == 0 and args.dump_frame:

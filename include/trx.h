@@ -386,6 +386,30 @@ int trx_debug_tile_profile(trx_scene *scene, const trx_view *view, uint32_t widt
  * value.  Variants compute identical results. */
 uint32_t trx_set_kernel_variant(uint32_t variant);
 
+/* ---- multi-GPU: the hit-shard gather -----------------------------------------
+ * tray_racing is single-GPU; these entry points are the north_star's "RCCL only for the final hit-buffer gather"
+ * in a form a Rust / C host can drive: one process per GPU, rank r traces
+ * trx_shard{r, N, TRX_LAYOUT_SHARD} of every frame of a batch straight into its block of a gather buffer laid out
+ * [N][m][R] (R = trx_shard_tiles(w, h, {0, N}) * 64 records, the same on every rank), ONE in-place all-gather per
+ * batch completes the m frames on every rank, and trx_assemble_frames de-interleaves them into row-major frames.
+ * RCCL (librccl.so) is loaded on first use; a single-GPU host never touches it. */
+typedef struct trx_comm trx_comm;
+/* 128 opaque bytes (ncclUniqueId): produced on rank 0, handed to the other ranks by the host's own means. */
+int trx_comm_unique_id(void *out_id128);
+/* Collective over all ranks (ncclCommInitRank).  device: the HIP device of this rank. */
+int trx_comm_create(const void *id128, int rank, int world, int device, trx_comm **out);
+void trx_comm_destroy(trx_comm *comm);
+int trx_comm_world_size(const trx_comm *comm); /* as the communicator reports it */
+/* In-place all-gather (ncclAllGather over xGMI) of `records_per_rank` hit records per rank, enqueued on `stream`:
+ * d_flat holds world blocks of records_per_rank records, this rank's block (already written by its trace launches)
+ * at rank * records_per_rank.  For a batch of m frames records_per_rank = m * R. */
+int trx_gather_shards(trx_comm *comm, trx_hit *d_flat, uint64_t records_per_rank, void *stream);
+/* De-interleave a gathered [world][n_frames][records_per_frame] buffer into n_frames row-major width x height
+ * frames (d_frames: n_frames * width * height records), enqueued on `stream`.  Needs no communicator: with
+ * world == 1 it turns one shard-layout frame into an image-layout one. */
+int trx_assemble_frames(const trx_hit *d_flat, uint64_t records_per_frame, uint32_t width, uint32_t height,
+                        uint32_t world, uint32_t n_frames, trx_hit *d_frames, void *stream);
+
 /* ---- host side: CWBVH construction (CPU) -------------------------------------
  * Stands in for obvhs build_cwbvh_from_tris / build_cwbvh (called at
  * src/cwbvh.rs:97,132), which the Rust host keeps doing in a real
@@ -468,10 +492,12 @@ int trx_flat_build_instanced(const float *verts, const uint64_t *object_tri_coun
                              uint32_t n_instances, uint32_t max_prims_per_leaf, int threads, trx_flat **out);
 
 /* The reference's BvhBuildParams (src/main.rs:571-585), field for field, for callers that carry one around.
- * The stand-in builder honours pre_split, reinsertion_batch_ratio, max_prims_per_leaf and
- * collapse_traversal_cost; ploc_search_distance, search_depth_threshold and
- * post_collapse_reinsertion_batch_ratio_multiplier belong to OBVHS' PLOC stage and are accepted as they are;
- * sort_precision must be 64 or 128 ("Unsupported sort precision", src/main.rs:576-580). */
+ * trx_flat_build_params runs the ploc_cwbvh pipeline with them: Morton sort at sort_precision bits (64 | 128,
+ * "Unsupported sort precision" otherwise, src/main.rs:576-580), PLOC merging with ploc_search_distance (1..32)
+ * places either side and distance 1 for the first search_depth_threshold rounds, reinsertion at
+ * reinsertion_batch_ratio, optional pre_split, collapse to <= max_prims_per_leaf triangles per leaf at
+ * collapse_traversal_cost.  post_collapse_reinsertion_batch_ratio_multiplier is "For BVH2 only" in the reference
+ * (src/main.rs:119-123) and has no effect on a CWBVH build. */
 typedef struct trx_build_params {
     uint32_t pre_split;                 /* --split */
     uint32_t ploc_search_distance;      /* --search-distance */

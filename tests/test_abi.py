@@ -185,3 +185,20 @@ def test_integration_md_matches_the_header():
     # every call the shim makes through ffi:: is bound
     called = set(re.findall(r"ffi::(trx_[a-z0-9_]+)\s*\(", rust))
     assert called <= {n for n, _ in fns}, sorted(called - {n for n, _ in fns})
+
+
+def test_multi_gpu_entry_points_validate_their_arguments(trx):
+    """trx_comm_* / trx_gather_shards / trx_assemble_frames refuse bad arguments with an error string before they
+    touch RCCL or the device (so this runs without a GPU)."""
+    import ctypes as C
+    lib = trx.load()
+    ident = (C.c_ubyte * 128)()
+    comm = C.c_void_p()
+    assert lib.trx_comm_create(None, 0, 1, 0, C.byref(comm)) == -1 and b"null" in lib.trx_last_error()
+    assert lib.trx_comm_create(ident, 3, 2, 0, C.byref(comm)) == -1 and b"rank 3 of 2" in lib.trx_last_error()
+    assert lib.trx_comm_create(ident, 0, 0, 0, C.byref(comm)) == -1
+    assert lib.trx_comm_unique_id(None) == -1
+    assert lib.trx_gather_shards(None, None, 64, None) == -1
+    assert lib.trx_assemble_frames(None, 64, 8, 8, 1, 1, None, None) == -1
+    assert lib.trx_comm_world_size(None) == 0
+    lib.trx_comm_destroy(None)

@@ -224,3 +224,52 @@ def test_build_params_struct_mirrors_the_reference(trx, orc):
     with pytest.raises(trx.TrxError, match="maximum of 3 primitives"):            # src/main.rs:176-178
         trx.flat_build_params(verts, counts, trx.build_params(max_prims_per_leaf=8))
     assert (trx.flat_build(verts, counts).nodes == before.nodes).all()
+
+
+@pytest.mark.parametrize("name,n,tlas", [("kitchen", 9000, False), ("bistro", 40000, True), ("hairball", 20000, False),
+                                          ("soup", 3000, False), ("demoscene", 20000, False)])
+def test_ploc_build_honours_the_reference_parameters(trx, orc, name, n, tlas):
+    """The ploc_cwbvh pipeline behind trx_flat_build_params: PLOC (Meister & Bittner 2018) over a Morton order of
+    sort_precision bits, merging within ploc_search_distance places (distance 1 for the first
+    search_depth_threshold rounds), then reinsertion and the 8-wide collapse.  Every setting yields a valid tree
+    whose hits equal the brute-force query; the PLOC parameters really change the tree (src/main.rs:571-585)."""
+    verts, counts = trx.gen_scene(name, n, 1)
+    eye, look, fov = trx.scene_camera(name)
+    view = orc.view_from_bytes(trx.view_from_camera(eye, look, fov, 40, 24))
+    want = None
+    trees = {}
+    for dist, thresh, bits, ratio in [(14, 2, 64, 0.15), (1, 0, 64, 0.0), (2, 0, 64, 0.0), (32, 5, 64, 0.05), (14, 2, 128, 0.0),
+                                      (14, 0, 64, 0.0), (6, 1, 128, 1.5)]:
+        bp = trx.build_params(ploc_search_distance=dist, search_depth_threshold=thresh, sort_precision=bits,
+                              reinsertion_batch_ratio=ratio)
+        flat = trx.flat_build_params(verts, counts, bp, use_tlas=tlas)
+        assert flat.n_tris == n and sorted(flat.tri_source.tolist()) == list(range(n))
+        osc = orc.Scene.from_flat(flat)
+        assert osc.validate() == (0, ""), (dist, thresh, bits, ratio)
+        got, _ = osc.trace_primary(view, 40, 24)
+        if want is None:
+            want = osc.brute_primary(view, 40, 24)
+        assert (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all(), (dist, thresh, bits, ratio)
+        trees[(dist, thresh, bits, ratio)] = flat.nodes.tobytes()
+    # the search distance, the depth threshold and the sort precision each matter
+    assert trees[(1, 0, 64, 0.0)] != trees[(2, 0, 64, 0.0)] != trees[(14, 0, 64, 0.0)]
+    assert trees[(14, 0, 64, 0.0)] != trees[(14, 2, 128, 0.0)]
+    # and the build is the same whatever the thread count
+    bp = trx.build_params(reinsertion_batch_ratio=0.05)
+    a = trx.flat_build_params(verts, counts, bp, use_tlas=tlas, threads=1)
+    b = trx.flat_build_params(verts, counts, bp, use_tlas=tlas, threads=5)
+    assert (a.nodes == b.nodes).all() and (a.tri_source == b.tri_source).all()
+
+
+def test_ploc_parameter_errors_and_tiny_inputs(trx, orc):
+    verts, counts = trx.gen_scene("soup", 64, 3)
+    for bad in (0, 33):
+        with pytest.raises(trx.TrxError, match="ploc_search_distance"):
+            trx.flat_build_params(verts, counts, trx.build_params(ploc_search_distance=bad))
+    for n in (1, 2, 3, 5):
+        flat = trx.flat_build_params(verts[:n], np.array([n], dtype=np.uint64), trx.build_params(reinsertion_batch_ratio=0.0))
+        assert flat.n_tris == n and orc.Scene.from_flat(flat).validate() == (0, "")
+    # identical centroids (one Morton cell): PLOC still terminates and the tree is valid
+    same = np.repeat(verts[:1], 50, axis=0)
+    flat = trx.flat_build_params(same, np.array([50], dtype=np.uint64), trx.build_params())
+    assert orc.Scene.from_flat(flat).validate() == (0, "")

@@ -476,25 +476,19 @@ def test_full_size_san_miguel_tlas_4k_all_eight_shards(trx, orc):
     ov = orc.view_from_bytes(view)
     want, ost = osc.trace_primary(ov, w, h, sem=3)
     world = 8
-    frame = np.zeros(w * h, dtype=trx.HIT_DTYPE)
-    tx = (w + 7) // 8
-    ys, xs = np.divmod(np.arange(64), 8)
-    covered = np.zeros(w * h, dtype=bool)
-    for rank in range(world):
-        fg = D.FrameGather(w, h, rank, world, "cuda")
-        local = fg.new_local()
-        sc.trace_primary_dev(view, w, h, local.data_ptr(), sem=3, shard=(rank, world, 1))
-        sc.check()
-        got = D.int64_to_hits(local)
-        lt = np.arange(fg.records // 64)
-        tile = lt * world + rank
-        px = (tile[:, None] % tx) * 8 + xs[None, :]
-        py = (tile[:, None] // tx) * 8 + ys[None, :]
-        ok = (px < w) & (py < h) & (tile[:, None] < tx * ((h + 7) // 8))
-        rec = lt[:, None] * 64 + np.arange(64)[None, :]
-        frame[(py * w + px)[ok]] = got[rec[ok]]
-        covered[(py * w + px)[ok]] = True
-    assert covered.all()
+    import ctypes as C
+    import torch
+    from tray_racing_amd import _lib as L
+    R = D.max_shard_tiles(w, h, world) * 64
+    miss = D.FrameGather(w, h, 0, world, "cuda").new_local()[0]
+    buf = torch.full((world * R,), int(miss), dtype=torch.int64, device="cuda")
+    for rank in range(world):   # what each of the 8 ranks would trace, into its block of the gather buffer
+        sc.trace_primary_dev(view, w, h, buf[rank * R:(rank + 1) * R].data_ptr(), sem=3, shard=(rank, world, 1))
+    sc.check()
+    out = torch.empty(w * h, dtype=torch.int64, device="cuda")
+    L.check(L.load().trx_assemble_frames(C.c_void_p(buf.data_ptr()), R, w, h, world, 1, C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    frame = D.int64_to_hits(out)
     assert_hits_equal(frame, want, "san_miguel tlas 4k, 8 shards assembled")
     gp, gao, _ = sc.trace_primary_ao(view, w, h, sem=3, frame=0, ao_eps=0.01)
     assert_hits_equal(gp, want, "san_miguel tlas 4k, one GPU")

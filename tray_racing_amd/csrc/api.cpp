@@ -42,6 +42,8 @@ struct BuildSettings {
     int sah_bins = 32;
     uint32_t sweep_max = 48;
     float pre_split = 0.0f;
+    uint32_t ploc_distance = 0; // 0: binned-SAH BVH2; > 0: PLOC with this search distance
+    uint32_t ploc_depth_threshold = 2, ploc_sort_bits = 64;
 };
 BuildSettings g_build;
 std::mutex g_build_mu;
@@ -60,6 +62,9 @@ BuildParams to_build_params(const BuildSettings &b, uint32_t max_prims, int thre
     bp.sah_bins = b.sah_bins;
     bp.sweep_max = b.sweep_max;
     bp.pre_split_ratio = b.pre_split;
+    bp.ploc_search_distance = b.ploc_distance;
+    bp.ploc_search_depth_threshold = b.ploc_depth_threshold;
+    bp.ploc_sort_bits = b.ploc_sort_bits;
     return bp;
 }
 
@@ -101,6 +106,19 @@ struct Slot {
 };
 
 } // namespace
+
+namespace trx {
+// error reporting for the other translation units of the library (comm.cpp)
+int fail_msg(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+} // namespace trx
 
 struct trx_scene {
     int device = 0;
@@ -1409,8 +1427,10 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
                            const uint32_t *instance_object = nullptr, const float *instance_o2w = nullptr,
                            uint32_t n_instances = 0);
 
-// BvhBuildParams of the reference (src/main.rs:571-585) applied for one build, then the process-wide settings
-// are put back; the stand-in builder has no PLOC stage, so the three PLOC fields only have to be sane.
+// BvhBuildParams of the reference (src/main.rs:571-585) for one build: the BVH2 comes from PLOC with the caller's
+// search distance, depth threshold and Morton width, is optimised by the reinsertion pass at the caller's batch ratio
+// and collapsed at the caller's traversal cost.  post_collapse_reinsertion_batch_ratio_multiplier is "For BVH2 only"
+// in the reference's own words (src/main.rs:119-123): a CWBVH build has no such pass.
 int trx_flat_build_params(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects, int use_tlas,
                           const trx_build_params *bp, int threads, trx_flat **out) {
     if (!bp) return fail(TRX_ERR_INVALID, "build params are null");
@@ -1424,6 +1444,11 @@ int trx_flat_build_params(const float *verts, const uint64_t *object_tri_counts,
     b.reinsert_iters = bp->reinsertion_batch_ratio > 1.f ? (int)std::ceil(bp->reinsertion_batch_ratio)
                        : bp->reinsertion_batch_ratio > 0.f ? std::max(1, b.reinsert_iters) : 0;
     b.pre_split = bp->pre_split ? 0.3f : 0.0f;
+    if (bp->ploc_search_distance < 1 || bp->ploc_search_distance > 32)
+        return fail(TRX_ERR_INVALID, "ploc_search_distance %u outside 1..32", bp->ploc_search_distance);
+    b.ploc_distance = bp->ploc_search_distance;
+    b.ploc_depth_threshold = bp->search_depth_threshold;
+    b.ploc_sort_bits = bp->sort_precision;
     return flat_build_impl(verts, object_tri_counts, n_objects, use_tlas, bp->max_prims_per_leaf, threads, b, out);
 }
 

@@ -265,6 +265,202 @@ struct Bvh2Builder {
     }
 };
 
+// Back to DFS pre-order (left child == self + 1, a subtree over k primitives owns 2k-1 consecutive nodes, root at 0),
+// which the collapse relies on.  `root` is where the tree starts in the given array.
+void relayout_dfs(BigVec<Node2> &nodes, uint32_t root, int threads) {
+    const size_t n = nodes.size();
+    BigVec<Node2> out(n);
+    typedef std::pair<uint32_t, uint32_t> Job; // (old index, new index) of a subtree root
+    auto place = [&](Job root, uint32_t stop_below, std::vector<Job> *deferred) {
+        std::vector<Job> todo{root};
+        while (!todo.empty()) {
+            auto [o, w] = todo.back();
+            todo.pop_back();
+            const Node2 &nd = nodes[o];
+            if (deferred && nd.count <= stop_below) { // small enough: a worker places this subtree
+                deferred->push_back(Job(o, w));
+                continue;
+            }
+            Node2 &dst = out[w];
+            dst.box = nd.box;
+            dst.prim = nd.prim;
+            dst.count = nd.count;
+            if (nd.count > 1) {
+                dst.left = w + 1;
+                dst.right = w + 2 * nodes[nd.left].count;
+                todo.emplace_back(nd.right, dst.right);
+                todo.emplace_back(nd.left, dst.left);
+            } else {
+                dst.left = dst.right = 0;
+            }
+        }
+    };
+    std::vector<Job> jobs;
+    const uint32_t grain = std::max<uint32_t>(1024u, nodes[root].count / (uint32_t)(std::max(1, threads) * 16));
+    if (threads <= 1) {
+        place(Job(root, 0u), 0u, nullptr);
+    } else {
+        place(Job(root, 0u), grain, &jobs);
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t k = next.fetch_add(1); k < jobs.size(); k = next.fetch_add(1)) place(jobs[k], 0u, nullptr);
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) pool.emplace_back(worker);
+        for (auto &th : pool) th.join();
+    }
+    nodes.swap(out);
+}
+
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) -----------------------------
+// The BVH2 stage of obvhs' ploc builder (build_cwbvh_from_tris, src/cwbvh.rs:97; parameters src/main.rs:571-585):
+// primitives are sorted along a Morton curve through their box centres; every round each cluster looks `radius`
+// places either side for the neighbour whose union with it has the smallest surface area, clusters that chose each
+// other merge under a new node, and the survivors keep their order.  Rounds repeat until one cluster is left.
+// Deterministic for any thread count: the searches only read, the merges happen in index order.
+struct PlocBuilder {
+    typedef unsigned __int128 u128;
+    static inline uint64_t spread21(uint64_t x) { // 21 bits -> every third bit
+        x &= 0x1fffffull;
+        x = (x | x << 32) & 0x1f00000000ffffull;
+        x = (x | x << 16) & 0x1f0000ff0000ffull;
+        x = (x | x << 8) & 0x100f00f00f00f00full;
+        x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+        x = (x | x << 2) & 0x1249249249249249ull;
+        return x;
+    }
+    static inline u128 spread42(uint64_t x) { // 42 bits -> every third bit of 126
+        return (u128)spread21(x & 0x1fffffull) | ((u128)spread21(x >> 21) << 63);
+    }
+
+    template <class Key>
+    static void radix_sort(std::vector<Key> &keys, std::vector<uint32_t> &idx, int key_bits) {
+        const size_t n = keys.size();
+        std::vector<Key> k2(n);
+        std::vector<uint32_t> i2(n);
+        for (int shift = 0; shift < key_bits; shift += 16) {
+            std::vector<uint32_t> count(65537, 0u);
+            for (size_t i = 0; i < n; i++) count[(size_t)((keys[i] >> shift) & 0xffffu) + 1]++;
+            bool trivial = false;
+            for (size_t b = 0; b < 65536; b++) {
+                if (count[b + 1] == n) trivial = true; // every key shares this digit
+                count[b + 1] += count[b];
+            }
+            if (trivial) continue;
+            for (size_t i = 0; i < n; i++) {
+                const uint32_t d = count[(size_t)((keys[i] >> shift) & 0xffffu)]++;
+                k2[d] = keys[i];
+                i2[d] = idx[i];
+            }
+            keys.swap(k2);
+            idx.swap(i2);
+        }
+    }
+
+    // nodes: out, 2n-1 entries in DFS pre-order with the root at 0
+    static void run(const Aabb *boxes, const float *cen, uint32_t n, uint32_t radius, uint32_t depth_threshold,
+                    uint32_t sort_bits, int threads, BigVec<Node2> &nodes) {
+        nodes.clear();
+        if (n == 0) return;
+        nodes.resize(2 * (size_t)n - 1);
+        // Morton order of the box centres
+        float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+        for (uint32_t i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) {
+                lo[k] = std::min(lo[k], cen[3 * (size_t)i + k]);
+                hi[k] = std::max(hi[k], cen[3 * (size_t)i + k]);
+            }
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; i++) order[i] = i;
+        const int bits = sort_bits == 128 ? 42 : 21;
+        double scale[3];
+        for (int k = 0; k < 3; k++) {
+            const double ext = (double)hi[k] - (double)lo[k];
+            scale[k] = ext > 0.0 ? ((double)((1ull << bits) - 1ull)) / ext : 0.0;
+        }
+        auto quant = [&](uint32_t i, int k) -> uint64_t {
+            const double q = ((double)cen[3 * (size_t)i + k] - (double)lo[k]) * scale[k];
+            return q <= 0.0 ? 0ull : (uint64_t)q;
+        };
+        if (sort_bits == 128) {
+            std::vector<u128> keys(n);
+            for (uint32_t i = 0; i < n; i++) keys[i] = spread42(quant(i, 0)) | (spread42(quant(i, 1)) << 1) | (spread42(quant(i, 2)) << 2);
+            radix_sort(keys, order, 128);
+        } else {
+            std::vector<uint64_t> keys(n);
+            for (uint32_t i = 0; i < n; i++) keys[i] = spread21(quant(i, 0)) | (spread21(quant(i, 1)) << 1) | (spread21(quant(i, 2)) << 2);
+            radix_sort(keys, order, 64);
+        }
+        // leaves, in curve order, fill the first n entries; inner nodes follow in creation order
+        std::vector<uint32_t> cur(n), nxt;
+        for (uint32_t i = 0; i < n; i++) {
+            Node2 &leaf = nodes[i];
+            leaf.box = boxes[order[i]];
+            leaf.left = leaf.right = 0;
+            leaf.prim = order[i];
+            leaf.count = 1;
+            cur[i] = i;
+        }
+        uint32_t next_node = n;
+        std::vector<uint32_t> nn;
+        threads = std::max(1, threads);
+        for (uint32_t round = 0; cur.size() > 1; round++) {
+            const uint32_t m = (uint32_t)cur.size();
+            const uint32_t r = round < depth_threshold ? 1u : std::max(1u, radius);
+            nn.resize(m);
+            auto search = [&](uint32_t begin, uint32_t end) {
+                for (uint32_t i = begin; i < end; i++) {
+                    const Aabb &bi = nodes[cur[i]].box;
+                    const uint32_t j0 = i > r ? i - r : 0u, j1 = std::min(m - 1u, i + r);
+                    float best = kInf;
+                    uint32_t best_j = i == 0 ? 1u : i - 1u;
+                    for (uint32_t j = j0; j <= j1; j++) {
+                        if (j == i) continue;
+                        Aabb u = bi;
+                        grow(u, nodes[cur[j]].box);
+                        const float a = half_area(u);
+                        if (a < best) { // first of equals: the lowest index
+                            best = a;
+                            best_j = j;
+                        }
+                    }
+                    nn[i] = best_j;
+                }
+            };
+            const int use = (int)std::min<uint32_t>((uint32_t)threads, std::max(1u, m / 4096u));
+            if (use <= 1) {
+                search(0u, m);
+            } else {
+                std::vector<std::thread> pool;
+                for (int t = 0; t < use; t++)
+                    pool.emplace_back(search, (uint32_t)((uint64_t)m * t / use), (uint32_t)((uint64_t)m * (t + 1) / use));
+                for (auto &th : pool) th.join();
+            }
+            nxt.clear();
+            nxt.reserve(m);
+            for (uint32_t i = 0; i < m; i++) {
+                const uint32_t j = nn[i];
+                if (nn[j] == i) {
+                    if (i < j) { // the pair merges where its first member stood
+                        Node2 &p = nodes[next_node];
+                        p.left = cur[i];
+                        p.right = cur[j];
+                        p.box = nodes[cur[i]].box;
+                        grow(p.box, nodes[cur[j]].box);
+                        p.prim = 0;
+                        p.count = nodes[cur[i]].count + nodes[cur[j]].count;
+                        nxt.push_back(next_node++);
+                    }
+                } else {
+                    nxt.push_back(cur[i]);
+                }
+            }
+            cur.swap(nxt);
+        }
+        relayout_dfs(nodes, cur[0], threads);
+    }
+};
+
 // ---- BVH2 reinsertion optimisation ------------------------------------------
 // Meister & Bittner 2018, "Parallel Reinsertion for Bounding Volume Hierarchy
 // Optimization" (the pass obvhs runs after PLOC, knob `reinsertion_batch_ratio`
@@ -411,52 +607,7 @@ struct Reinserter {
         return moved;
     }
 
-    // Back to DFS pre-order (left child == self + 1, a subtree over k primitives
-    // owns 2k-1 consecutive nodes), which the collapse below relies on.
-    void relayout(int threads) {
-        const size_t n = nodes.size();
-        BigVec<Node2> out(n);
-        typedef std::pair<uint32_t, uint32_t> Job; // (old index, new index) of a subtree root
-        auto place = [&](Job root, uint32_t stop_below, std::vector<Job> *deferred) {
-            std::vector<Job> todo{root};
-            while (!todo.empty()) {
-                auto [o, w] = todo.back();
-                todo.pop_back();
-                const Node2 &nd = nodes[o];
-                if (deferred && nd.count <= stop_below) { // small enough: a worker places this subtree
-                    deferred->push_back(Job(o, w));
-                    continue;
-                }
-                Node2 &dst = out[w];
-                dst.box = nd.box;
-                dst.prim = nd.prim;
-                dst.count = nd.count;
-                if (nd.count > 1) {
-                    dst.left = w + 1;
-                    dst.right = w + 2 * nodes[nd.left].count;
-                    todo.emplace_back(nd.right, dst.right);
-                    todo.emplace_back(nd.left, dst.left);
-                } else {
-                    dst.left = dst.right = 0;
-                }
-            }
-        };
-        std::vector<Job> jobs;
-        const uint32_t grain = std::max<uint32_t>(1024u, nodes[0].count / (uint32_t)(std::max(1, threads) * 16));
-        if (threads <= 1) {
-            place(Job(0u, 0u), 0u, nullptr);
-        } else {
-            place(Job(0u, 0u), grain, &jobs);
-            std::atomic<size_t> next{0};
-            auto worker = [&]() {
-                for (size_t k = next.fetch_add(1); k < jobs.size(); k = next.fetch_add(1)) place(jobs[k], 0u, nullptr);
-            };
-            std::vector<std::thread> pool;
-            for (int t = 0; t < threads; t++) pool.emplace_back(worker);
-            for (auto &th : pool) th.join();
-        }
-        nodes.swap(out);
-    }
+    void relayout(int threads) { relayout_dfs(nodes, 0u, threads); }
 };
 
 // ---- BVH2 -> BVH8 collapse (Ylitie et al. 2017, section 4.2) ------------------
@@ -713,7 +864,7 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
     }
     Bvh2Builder b2;
     b2.boxes = boxes;
-    b2.cen.assign(centroids, centroids + 3 * n);
+    if (params.ploc_search_distance == 0) b2.cen.assign(centroids, centroids + 3 * n);
     b2.kBins = std::max(2, std::min(params.sah_bins, (int)Bvh2Builder::kMaxBins));
     b2.kSweepMax = std::min<uint32_t>(params.sweep_max, Bvh2Builder::kMaxSweep);
     const bool verbose = getenv("TRX_BUILD_VERBOSE") != nullptr && n > 100000;
@@ -722,8 +873,12 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
             fprintf(stderr, "[trx build] %-12s %.3f s\n", what,
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     };
-    b2.run((uint32_t)n, threads);
-    lap("bvh2");
+    if (params.ploc_search_distance > 0)
+        PlocBuilder::run(boxes, centroids, (uint32_t)n, params.ploc_search_distance, params.ploc_search_depth_threshold,
+                         params.ploc_sort_bits, threads, b2.nodes);
+    else
+        b2.run((uint32_t)n, threads);
+    lap(params.ploc_search_distance > 0 ? "bvh2 (ploc)" : "bvh2");
     out.total_aabb = b2.nodes[0].box;
     if (params.reinsertion_batch_ratio > 0.f && params.reinsertion_iterations > 0) {
         Reinserter opt(b2.nodes);

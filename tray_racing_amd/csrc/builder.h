@@ -34,6 +34,14 @@ struct BuildParams {
     // pre-splitting (obvhs pre_split / --split): up to this fraction of extra triangle references, spent on
     // the triangles whose boxes are emptiest; 0 = off (the reference's default)
     float pre_split_ratio = 0.0f;
+    // BVH2 stage.  0: top-down binned SAH (this builder's own).  > 0: PLOC (Meister & Bittner 2018, the BVH2 stage of
+    // obvhs' ploc builder): bottom-up merging of mutual nearest neighbours found within this many places either
+    // side in Morton order — obvhs `ploc_search_distance`, the reference's --search-distance (src/main.rs:85-92).
+    uint32_t ploc_search_distance = 0;
+    // PLOC: the first this-many merge rounds search one place either side only (obvhs `search_depth_threshold`,
+    // "Below this depth a search distance of 1 will be used for ploc", src/main.rs:93-98)
+    uint32_t ploc_search_depth_threshold = 2;
+    uint32_t ploc_sort_bits = 64; // Morton code width: 64 (21 bits per axis) or 128 (42 bits per axis), --sort-precision
     int sah_bins = 32;       // BVH2: SAH bins per axis (2..32)
     uint32_t sweep_max = 48; // BVH2: ranges of at most this many primitives get the exact SAH sweep (<= 64)
     int threads = 0; // <= 0: hardware_concurrency

@@ -32,7 +32,9 @@ struct Options { // src/main.rs:65-171 (flags this backend cannot honour are rej
     float collapse_traversal_cost = 1.0f;
     unsigned passes = 3;
     std::string preset;
-    float reinsertion_batch_ratio = -1.0f; // -r; < 0: library default
+    float reinsertion_batch_ratio = 0.15f; // -r (src/main.rs:113-118)
+    unsigned search_distance = 14, search_depth_threshold = 2, sort_precision = 64; // src/main.rs:85-98,110-112
+    float post_collapse_multiplier = 0.0f;
     bool dry_run = false; // load + build only (no device needed)
     bool split = false;   // --split: pre-splitting of large triangles
     int device = 0;
@@ -135,9 +137,14 @@ Options parse_args(int argc, char **argv) {
             std::exit(0);
         } else if (a == "-r") {
             o.reinsertion_batch_ratio = (float)std::atof(need(i));
-        } else if (a == "--search-distance" || a == "--search-depth-threshold" || a == "--sort-precision" ||
-                   a == "--post-collapse-reinsertion-batch-ratio-multiplier") {
-            need(i); // PLOC parameters of the OBVHS builder: accepted, not used by the stand-in builder
+        } else if (a == "--search-distance") {
+            o.search_distance = (unsigned)std::atoi(need(i));
+        } else if (a == "--search-depth-threshold") {
+            o.search_depth_threshold = (unsigned)std::atoi(need(i));
+        } else if (a == "--sort-precision") {
+            o.sort_precision = (unsigned)std::atoi(need(i));
+        } else if (a == "--post-collapse-reinsertion-batch-ratio-multiplier") {
+            o.post_collapse_multiplier = (float)std::atof(need(i)); // "For BVH2 only" (src/main.rs:119-123)
         } else if (a == "--split") {
             o.split = true;
         } else if (a == "--auto-tune" || a == "--disable-auto-tune-model-cache") {
@@ -250,19 +257,27 @@ Stats render_input(const Options &o, const std::string &input) {
     }
     const bool tlas = o.tlas && !o.flatten_blas; // src/main.rs:300-308
     if (o.verbose) std::printf("%u objects \"%s\"\ntriangles %llu\n", n_objects, st.name.c_str(), (unsigned long long)n_tris);
-    check(trx_set_build_costs(o.collapse_traversal_cost, 0.3f), "build costs");
-    // a named preset overrides the individual builder flags, "" leaves them in charge (src/main.rs:563-585)
-    check(trx_set_build_preset(o.preset.c_str()), "preset");
-    if (o.preset.empty()) {
-        check(trx_set_build_split(o.split ? 0.3f : 0.0f), "split"); // obvhs pre_split is a switch; 30 % extra references here
-        if (o.reinsertion_batch_ratio >= 0.f) {
-            // obvhs: 0..1 is the candidate ratio of one pass, above 1 the whole set is evaluated several times
-            float r = o.reinsertion_batch_ratio;
-            check(trx_set_build_reinsertion(r > 1.f ? 1.f : r, r > 1.f ? (int)std::ceil(r) : 1), "reinsertion");
-        }
-    }
     trx_flat *flat = nullptr;
-    check(trx_flat_build(verts, counts, n_objects, tlas ? 1 : 0, o.max_prims_per_leaf, 0, &flat), "build");
+    if (o.preset.empty()) {
+        // no preset: BvhBuildParams from the individual flags (src/main.rs:571-585), the ploc_cwbvh pipeline
+        trx_build_params bp;
+        trx_build_params_default(&bp);
+        bp.pre_split = o.split ? 1u : 0u;
+        bp.ploc_search_distance = o.search_distance;
+        bp.search_depth_threshold = o.search_depth_threshold;
+        bp.reinsertion_batch_ratio = o.reinsertion_batch_ratio;
+        bp.sort_precision = o.sort_precision;
+        bp.max_prims_per_leaf = o.max_prims_per_leaf;
+        bp.post_collapse_reinsertion_batch_ratio_multiplier = o.post_collapse_multiplier;
+        bp.collapse_traversal_cost = o.collapse_traversal_cost;
+        check(trx_flat_build_params(verts, counts, n_objects, tlas ? 1 : 0, &bp, 0, &flat), "build");
+    } else {
+        // a named preset overrides the individual builder flags (src/main.rs:563-570); obvhs' preset values are not in
+        // the reference tree, so the names select this library's own settings of matching cost
+        check(trx_set_build_costs(o.collapse_traversal_cost, 0.3f), "build costs");
+        check(trx_set_build_preset(o.preset.c_str()), "preset");
+        check(trx_flat_build(verts, counts, n_objects, tlas ? 1 : 0, o.max_prims_per_leaf, 0, &flat), "build");
+    }
     st.blas_build_time_s = flat->blas_build_s;
     st.tlas_build_time_ms = flat->tlas_build_s * 1000.0;
     if (o.verbose) std::printf("nodes %llu tlas_start %u instances %u\n", (unsigned long long)flat->n_nodes, flat->tlas_start, flat->n_instances);

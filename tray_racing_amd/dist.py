@@ -132,3 +132,76 @@ def int64_to_hits(t):
     import numpy as np
     from .host import HIT_DTYPE
     return t.detach().cpu().numpy().view(HIT_DTYPE)
+
+
+class AbiFrameGather(FrameGather):
+    """The same batch gather through the C ABI instead of torch.distributed: trx_comm_* (RCCL loaded by libtrx.so
+    itself), trx_gather_shards (the in-place ncclAllGather, on the caller's stream) and trx_assemble_frames (one
+    de-interleave kernel, no index tensor).  This is what a Rust / C host binds.
+
+    The 128-byte communicator id comes from rank 0 (`unique_id()`) and reaches the other ranks by the host's own
+    means; `from_process_group` uses a torch.distributed broadcast for that and nothing else."""
+
+    def __init__(self, width, height, rank, world, device, id_bytes, batch=1):
+        super().__init__(width, height, rank, world, device, batch=batch)
+        import ctypes as C
+        from . import _lib as L
+        self._L, self._C = L, C
+        self._comm = C.c_void_p()
+        dev = self.device.index if self.device.index is not None else 0
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(id_bytes))
+        L.check(L.load().trx_comm_create(buf, rank, world, dev, C.byref(self._comm)))
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib as L
+        buf = (C.c_ubyte * 128)()
+        L.check(L.load().trx_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_process_group(cls, width, height, device, batch=1):
+        rank, world = dist.get_rank(), dist.get_world_size()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            ident = torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8).clone()
+        on_gpu = dist.get_backend() == "nccl"
+        t = ident.to(device) if on_gpu else ident
+        dist.broadcast(t, src=0)
+        return cls(width, height, rank, world, device, bytes(t.cpu().numpy().tobytes()), batch=batch)
+
+    def world_size(self):
+        return self._L.load().trx_comm_world_size(self._comm)
+
+    def gather(self, local=None, async_op=False, m=1):
+        if local is not None:
+            assert m == 1
+            self.slot(0, 1).copy_(local)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._L.check(self._L.load().trx_gather_shards(self._comm, self._C.c_void_p(self.flat.data_ptr()), m * self.records,
+                                                      self._C.c_void_p(stream)))
+        return None  # enqueued on the current stream: nothing to wait for on the host
+
+    def assemble(self, out=None, m=1):
+        if out is None:
+            out = torch.empty(m * self.width * self.height, dtype=torch.int64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._L.check(self._L.load().trx_assemble_frames(self._C.c_void_p(self.flat.data_ptr()), self.records, self.width,
+                                                        self.height, self.world, m, self._C.c_void_p(out.data_ptr()),
+                                                        self._C.c_void_p(stream)))
+        return out
+
+    def prepare(self, *batch_sizes):
+        pass  # no index tensors to build
+
+    def close(self):
+        if self._comm:
+            self._L.load().trx_comm_destroy(self._comm)
+            self._comm = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
