@@ -117,4 +117,29 @@ for name in sys.argv[1:] or ["bistro"]:
         order = torch.sort(key, stable=True).indices
         t, out = time_rays(sc, base[order].contiguous())
         print("   24 direction bins inside %s tiles: %.3f ms (x%.2f)" % (group if group < 1 << 30 else "all", t, t_tile / t), flush=True)
+    # origin sort: Morton code of the ray origin (10 bits per axis), alone and inside direction octants
+    o = base[:, 0:3]
+    lo, hi = o.min(0).values, o.max(0).values
+    q = ((o - lo) / (hi - lo).clamp(min=1e-20) * 1023.0).long().clamp(0, 1023)
+
+    def spread(x):
+        x = (x | (x << 16)) & 0x030000FF
+        x = (x | (x << 8)) & 0x0300F00F
+        x = (x | (x << 4)) & 0x030C30C3
+        x = (x | (x << 2)) & 0x09249249
+        return x
+    morton = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    for label, key in (("Morton order of the origins", morton), ("octant, then Morton order of the origins", (octant << 30) | morton)):
+        order = torch.sort(key, stable=True).indices
+        t, out = time_rays(sc, base[order].contiguous())
+        same = bool((out == ref[order]).all())
+        print("   %s: %.3f ms (x%.2f) same=%s; the sort itself (torch.sort of %d keys): " % (label, t, t_tile / t, same, n), end="", flush=True)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(5):
+            o2 = torch.sort(key, stable=True).indices
+            _ = base[o2]
+        ev1.record()
+        torch.cuda.synchronize()
+        print("%.3f ms with the gather" % (ev0.elapsed_time(ev1) / 5), flush=True)
     sc.close()
