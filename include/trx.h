@@ -513,6 +513,12 @@ typedef struct trx_build_params {
     float collapse_traversal_cost;      /* --collapse-traversal-cost */
 } trx_build_params;
 void trx_build_params_default(trx_build_params *params); /* the reference's command-line defaults */
+/* Where the BVH2 stage of trx_flat_build_params (Morton sort + PLOC merge rounds) runs for subsequent builds
+ * (process-wide): device >= 0 = on that HIP device, as kernels (objects of at least 32,768 primitives; the many small
+ * BLASes of a TLAS scene stay on the host cores), -1 = on the host cores (default).  The device stage returns the very
+ * tree the host stage returns (same operations in the same order); reinsertion, collapse and encoding follow on the
+ * host either way.  A device failure fails the build (TRX_ERR_NO_DEVICE / TRX_ERR_OOM): nothing falls back silently. */
+int trx_set_build_device(int device);
 int trx_flat_build_params(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects,
                           int use_tlas, const trx_build_params *params, int threads, trx_flat **out);
 

@@ -202,3 +202,13 @@ def test_multi_gpu_entry_points_validate_their_arguments(trx):
     assert lib.trx_assemble_frames(None, 64, 8, 8, 1, 1, None, None) == -1
     assert lib.trx_comm_world_size(None) == 0
     lib.trx_comm_destroy(None)
+
+
+def test_build_device_setter(trx, has_gpu):
+    """trx_set_build_device: -1 (host) always works; a device that does not exist is refused, never silently ignored."""
+    lib = trx.load()
+    assert lib.trx_set_build_device(-1) == 0
+    assert lib.trx_set_build_device(97) == -2 and b"no HIP device 97" in lib.trx_last_error()
+    if not has_gpu:
+        assert lib.trx_set_build_device(0) == -2
+    assert lib.trx_set_build_device(-1) == 0

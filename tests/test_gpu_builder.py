@@ -1,0 +1,61 @@
+"""The BVH2 stage of the ploc_cwbvh build on the GPU (csrc/ploc_gpu.cpp: Morton codes, radix sort, PLOC merge rounds as
+kernels) must return the very tree the host stage returns: same operations in the same order, so the flat buffers that
+come out of reinsertion / collapse / encoding are byte-identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+
+
+@pytest.mark.parametrize("name,n", [("bistro", 200000), ("hairball", 120000), ("kitchen", 56939), ("soup", 40000)])
+def test_device_ploc_tree_equals_host_ploc_tree(trx, orc, name, n):
+    lib = trx.load()
+    verts, _counts = trx.gen_scene(name, n, 1)
+    counts = np.array([n], dtype=np.uint64)   # one object: large enough for the device stage
+    try:
+        for dist, thresh, bits, ratio in [(14, 2, 64, 0.0), (14, 2, 128, 0.0), (2, 0, 64, 0.0), (32, 5, 64, 0.02)]:
+            bp = trx.build_params(ploc_search_distance=dist, search_depth_threshold=thresh, sort_precision=bits,
+                                  reinsertion_batch_ratio=ratio)
+            assert lib.trx_set_build_device(-1) == 0
+            host = trx.flat_build_params(verts, counts, bp)
+            assert lib.trx_set_build_device(0) == 0
+            dev = trx.flat_build_params(verts, counts, bp)
+            assert (host.nodes == dev.nodes).all(), (name, dist, thresh, bits, ratio)
+            assert (host.tri_source == dev.tri_source).all()
+        assert orc.Scene.from_flat(dev).validate() == (0, "")
+    finally:
+        lib.trx_set_build_device(-1)
+
+
+def test_device_ploc_full_size_bistro_traces_like_the_host_build(trx, orc):
+    """3.87 M triangles through the device stage: valid tree, and a traced frame equal to the oracle's on it."""
+    import time
+    lib = trx.load()
+    verts, _c = trx.gen_scene("bistro", 0, 1)
+    counts = np.array([verts.shape[0]], dtype=np.uint64)
+    bp = trx.build_params(reinsertion_batch_ratio=0.0)
+    try:
+        assert lib.trx_set_build_device(0) == 0
+        t0 = time.time()
+        flat = trx.flat_build_params(verts, counts, bp)
+        t_dev = time.time() - t0
+        lib.trx_set_build_device(-1)
+        t0 = time.time()
+        host = trx.flat_build_params(verts, counts, bp)
+        t_host = time.time() - t0
+    finally:
+        lib.trx_set_build_device(-1)
+    print("bistro-class 3.87 M triangles, PLOC alone: %.2f s with the BVH2 stage on the GPU, %.2f s on the host cores" % (t_dev, t_host))
+    assert (flat.nodes == host.nodes).all()
+    osc = orc.Scene.from_flat(flat)
+    assert osc.validate() == (0, "")
+    eye, look, fov = trx.scene_camera("bistro")
+    w, h = 480, 270
+    view = trx.view_from_camera(eye, look, fov, w, h)
+    sc = trx.Scene(flat)
+    got, _ = sc.trace_primary(view, w, h, sem=3)
+    sc.close()
+    want, _ = osc.trace_primary(orc.view_from_bytes(view), w, h, sem=3)
+    assert (got["prim"] == want["prim"]).all() and (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()

@@ -137,6 +137,7 @@ SIGNATURES = {
     "trx_set_build_reinsertion": (_i, [_f, _i]),
     "trx_set_build_preset": (_i, [C.c_char_p]),
     "trx_set_build_split": (_i, [_f]),
+    "trx_set_build_device": (_i, [_i]),
     "trx_bvh_destroy": (None, [_P]),
     "trx_bvh_node_count": (_u64, [_P]),
     "trx_bvh_prim_count": (_u64, [_P]),

@@ -44,6 +44,7 @@ struct BuildSettings {
     float pre_split = 0.0f;
     uint32_t ploc_distance = 0; // 0: binned-SAH BVH2; > 0: PLOC with this search distance
     uint32_t ploc_depth_threshold = 2, ploc_sort_bits = 64;
+    int ploc_device = -1;       // >= 0: the PLOC stage of large builds runs on this HIP device (trx_set_build_device)
 };
 BuildSettings g_build;
 std::mutex g_build_mu;
@@ -65,6 +66,7 @@ BuildParams to_build_params(const BuildSettings &b, uint32_t max_prims, int thre
     bp.ploc_search_distance = b.ploc_distance;
     bp.ploc_search_depth_threshold = b.ploc_depth_threshold;
     bp.ploc_sort_bits = b.ploc_sort_bits;
+    bp.ploc_device = b.ploc_device;
     return bp;
 }
 
@@ -1336,6 +1338,9 @@ int trx_bvh_build_tris(const float *verts, uint64_t n, uint32_t max_prims, int t
     const BuildParams bp = to_build_params(build_settings(), max_prims, threads);
     try {
         build_cwbvh_from_tris(verts, n, bp, b->bvh);
+    } catch (const std::runtime_error &e) { // the GPU build stage reports its own failures
+        delete b;
+        return fail(TRX_ERR_NO_DEVICE, "%s", e.what());
     } catch (const std::exception &) {
         delete b;
         return fail(TRX_ERR_OOM, "out of memory building the BVH");
@@ -1354,6 +1359,9 @@ int trx_bvh_build_aabbs(const float *aabbs, uint64_t n, uint32_t max_prims, int 
     bp.reinsertion_batch_ratio = 0.f; // boxes of instances: see trx_flat_build
     try {
         build_cwbvh_from_aabbs((const Aabb *)aabbs, n, bp, b->bvh);
+    } catch (const std::runtime_error &e) { // the GPU build stage reports its own failures
+        delete b;
+        return fail(TRX_ERR_NO_DEVICE, "%s", e.what());
     } catch (const std::exception &) {
         delete b;
         return fail(TRX_ERR_OOM, "out of memory building the BVH");
@@ -1367,6 +1375,16 @@ int trx_set_build_costs(float traversal_cost, float prim_cost) {
     std::lock_guard<std::mutex> lock(g_build_mu);
     g_build.traversal_cost = traversal_cost;
     g_build.prim_cost = prim_cost;
+    return TRX_OK;
+}
+
+int trx_set_build_device(int device) {
+    if (device >= 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || device >= n) return fail(TRX_ERR_NO_DEVICE, "no HIP device %d for the build stage", device);
+    }
+    std::lock_guard<std::mutex> lock(g_build_mu);
+    g_build.ploc_device = device < 0 ? -1 : device;
     return TRX_OK;
 }
 
@@ -1539,6 +1557,7 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             if (!small.empty()) {
                 BuildParams one = bp;
                 one.threads = 1;
+                one.ploc_device = -1; // the many small BLASes of a TLAS scene stay on the host cores
                 std::atomic<size_t> next{0};
                 std::atomic<bool> failed{false};
                 auto worker = [&]() {
@@ -1675,6 +1694,8 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             return fail(TRX_ERR_OOM, "host allocation failed");
         }
         *out = f;
+    } catch (const std::runtime_error &e) { // the GPU build stage reports its own failures
+        return fail(TRX_ERR_NO_DEVICE, "%s", e.what());
     } catch (const std::exception &) {
         return fail(TRX_ERR_OOM, "out of memory building the scene");
     }

@@ -1,5 +1,6 @@
 // builder.cpp — CPU construction of the 80-byte CWBVH (see builder.h).
 #include "builder.h"
+#include "ploc_gpu.h"
 
 #include <algorithm>
 #include <atomic>
@@ -9,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <stdexcept>
 #include <thread>
 
 namespace trx {
@@ -873,7 +875,21 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
             fprintf(stderr, "[trx build] %-12s %.3f s\n", what,
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     };
-    if (params.ploc_search_distance > 0)
+    if (params.ploc_search_distance > 0 && params.ploc_device >= 0 && n >= kDevicePlocMinPrims) {
+        // Morton sort + PLOC rounds as kernels; the tree is the one PlocBuilder::run returns
+        static_assert(sizeof(Node2) == 40, "Node2 is shared with ploc_gpu.cpp");
+        b2.nodes.resize(2 * (size_t)n - 1);
+        uint32_t root = 0;
+        std::string err;
+        double dev_s = 0.0;
+        if (!ploc_bvh2_device(params.ploc_device, boxes, centroids, (uint32_t)n, params.ploc_search_distance,
+                              params.ploc_search_depth_threshold, params.ploc_sort_bits, b2.nodes.data(), &root, &dev_s, err))
+            throw std::runtime_error("GPU build stage: " + err);
+        for (size_t i = n; i < b2.nodes.size(); i++) // children precede their parent in creation order
+            b2.nodes[i].count = b2.nodes[b2.nodes[i].left].count + b2.nodes[b2.nodes[i].right].count;
+        if (verbose) fprintf(stderr, "[trx build] ploc on device %d: %.4f s of kernels\n", params.ploc_device, dev_s);
+        relayout_dfs(b2.nodes, root, threads);
+    } else if (params.ploc_search_distance > 0)
         PlocBuilder::run(boxes, centroids, (uint32_t)n, params.ploc_search_distance, params.ploc_search_depth_threshold,
                          params.ploc_sort_bits, threads, b2.nodes);
     else

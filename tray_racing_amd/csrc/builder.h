@@ -41,11 +41,14 @@ struct BuildParams {
     // PLOC: the first this-many merge rounds search one place either side only (obvhs `search_depth_threshold`,
     // "Below this depth a search distance of 1 will be used for ploc", src/main.rs:93-98)
     uint32_t ploc_search_depth_threshold = 2;
+    int ploc_device = -1;         // >= 0: PLOC (sort + merge rounds) of builds with >= kDevicePlocMinPrims primitives runs on this HIP device
     uint32_t ploc_sort_bits = 64; // Morton code width: 64 (21 bits per axis) or 128 (42 bits per axis), --sort-precision
     int sah_bins = 32;       // BVH2: SAH bins per axis (2..32)
     uint32_t sweep_max = 48; // BVH2: ranges of at most this many primitives get the exact SAH sweep (<= 64)
     int threads = 0; // <= 0: hardware_concurrency
 };
+
+constexpr uint64_t kDevicePlocMinPrims = 32768;
 
 // Build over arbitrary primitive boxes (TLAS path, src/cwbvh.rs:114,132).
 void build_cwbvh_from_aabbs(const Aabb *boxes, uint64_t n, const BuildParams &params, CwBvh &out);

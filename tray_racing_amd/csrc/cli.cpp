@@ -36,6 +36,7 @@ struct Options { // src/main.rs:65-171 (flags this backend cannot honour are rej
     unsigned search_distance = 14, search_depth_threshold = 2, sort_precision = 64; // src/main.rs:85-98,110-112
     float post_collapse_multiplier = 0.0f;
     bool dry_run = false; // load + build only (no device needed)
+    bool gpu_build = false; // --gpu-build: Morton sort + PLOC rounds of the build on the device (trx_set_build_device)
     bool split = false;   // --split: pre-splitting of large triangles
     int device = 0;
     unsigned semantics = TRX_SEM_HLSL; // the GPU path of the reference is the HLSL text
@@ -101,6 +102,7 @@ void usage() {
               "  [--build ploc_cwbvh] [--max-prims-per-leaf 1..3] [--collapse-traversal-cost c] [--preset p]\n"
               "  [--width w] [--height h] [--animate] [--tlas] [--flatten-blas] [--passes n] [--verbose] [--device d]\n"
               "  [--png] [--cpu-semantics] [--dry-run (load + build only, needs no GPU)] [-r reinsertion_batch_ratio]\n"
+              "  [--search-distance d] [--search-depth-threshold n] [--sort-precision 64|128] [--split] [--gpu-build]\n"
               "stand-in names: cornell demoscene kitchen bistro hairball san_miguel (seeded procedural scenes)");
 }
 
@@ -132,6 +134,7 @@ Options parse_args(int argc, char **argv) {
         else if (a == "--flatten-blas") o.flatten_blas = true;
         else if (a == "--cpu-semantics") o.semantics = TRX_SEM_CPU;
         else if (a == "--dry-run") o.dry_run = true;
+        else if (a == "--gpu-build") o.gpu_build = true;
         else if (a == "-h" || a == "--help") {
             usage();
             std::exit(0);
@@ -258,6 +261,7 @@ Stats render_input(const Options &o, const std::string &input) {
     const bool tlas = o.tlas && !o.flatten_blas; // src/main.rs:300-308
     if (o.verbose) std::printf("%u objects \"%s\"\ntriangles %llu\n", n_objects, st.name.c_str(), (unsigned long long)n_tris);
     trx_flat *flat = nullptr;
+    check(trx_set_build_device(o.gpu_build ? o.device : -1), "build device");
     if (o.preset.empty()) {
         // no preset: BvhBuildParams from the individual flags (src/main.rs:571-585), the ploc_cwbvh pipeline
         trx_build_params bp;
