@@ -49,6 +49,10 @@ HIT_BYTES = 8
 SIMDS = 1024           # 256 CUs x 4 SIMD-32
 CLOCK_GHZ = 2.4        # max engine clock
 VALU_CYCLES = 2.0      # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (same guide, "Wave scheduling")
+# measured on this part (tools/ubench/valu_rates2.hip, profiles/r02_ubench_valu_rates2.log): at 4 waves per SIMD the
+# instruction classes the node test is made of (v_cvt_f32_ubyte, v_pk_mul/add_f32, v_max3/min3, v_cndmask, shifts,
+# SDWA, and scalar ALU alike) issue at one per 2.63 cycles per SIMD; only v_fma/mul/add_f32, v_and, v_add_u32 reach 1.62
+ISSUE_CYCLES_MEASURED = 2.63
 VARIANT_COLD = 1 << 20  # trx_set_kernel_variant: tile-order feedback off
 
 
@@ -109,7 +113,7 @@ def parse():
 # ---- live counters: rocprofv3 --pmc over a child process that replays the same scene -------------------------
 
 PMC_GROUPS = [
-    "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES",
+    "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS",
     "FETCH_SIZE",
     "WRITE_SIZE",
 ]
@@ -367,6 +371,22 @@ def main():
         torch.cuda.synchronize()
         legs["hbm_copy_gbs"] = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
         del src, dst
+        # (g) second headline row: the denser bistro-class stand-in built to the reference's PROFILE_RT legend
+        #     (about 30 node visits / 15 triangle tests per primary ray, rt_gpu_software.hlsl:95,102), same protocol
+        if args.scene == "bistro" and args.tris == 0:
+            dv, dc = T.gen_scene("bistro_dense", 0, 1)
+            dflat = T.flat_build(dv, dc, use_tlas=False, threads=threads, preset=args.preset)
+            dscene = T.Scene(dflat, device=local_rank)
+            dst = dscene.count_primary(view, w, h, sem=args.sem)
+            dp = [dscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
+            legs["dense_scene"] = {
+                "scene": "bistro_dense", "tris": int(dflat.n_tris), "nodes_per_ray": round(dst.n_node / dst.n_rays, 2),
+                "tris_per_ray": round(dst.n_tri / dst.n_rays, 2),
+                "min_ms": round(sum(p[0] for p in dp) / 3, 4), "mean_ms": round(sum(p[1] for p in dp) / 3, 4),
+                "mrays_at_mean": round(n_rays_total / (sum(p[1] for p in dp) / 3) / 1e3, 1),
+            }
+            dscene.close()
+            del dv, dc, dflat
         # (f) compulsory footprint: distinct nodes / triangles one frame touches
         fn, ft = scene.footprint(view, w, h, sem=args.sem)
         legs["footprint"] = {"nodes": fn, "tris": ft, "bytes": NODE_BYTES * fn + TRI_BYTES * ft + HIT_BYTES * n_rays_total}
@@ -426,6 +446,19 @@ def main():
             "kernel_ms": round(kernel_ms, 4),
             "valu_wave_insts_per_launch": int(valu) if valu else None,
         }
+        if pmc and pmc.get("SQ_INSTS"):
+            # every instruction class shares the SIMD's issue stage: all wave-instructions per second
+            # against the issue rate measured for this instruction mix at this occupancy
+            peak_meas = SIMDS * CLOCK_GHZ / ISSUE_CYCLES_MEASURED
+            roof["issue_stage"] = {
+                "all_wave_insts_per_launch": int(pmc["SQ_INSTS"]),
+                "achieved_ginstr_s": round(pmc["SQ_INSTS"] / (kernel_ms * 1e-3) / 1e9, 1),
+                "peak_measured_ginstr_s": round(peak_meas, 1),
+                "frac": round(pmc["SQ_INSTS"] / (kernel_ms * 1e-3) / 1e9 / peak_meas, 4),
+                "valu_frac_of_measured": round(ach_ginstr / peak_meas, 4) if ach_ginstr else None,
+                "note": "peak = one instruction per 2.63 cycles per SIMD at 4 waves per SIMD, measured "
+                        "(profiles/r02_ubench_valu_rates2.log); the 2-cycle figure in `peak` is the nominal SIMD-32 rate",
+            }
         if pmc and "SQ_WAVE_CYCLES" in pmc:
             wc = pmc["SQ_WAVE_CYCLES"]
             roof["wave_cycle_split"] = {k: round(pmc[c] / wc, 3) for k, c in (

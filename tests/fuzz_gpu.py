@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
-SCENES = ("cornell", "kitchen", "bistro", "hairball", "san_miguel", "soup", "demoscene")
+SCENES = ("cornell", "kitchen", "bistro", "bistro_dense", "hairball", "san_miguel", "soup", "demoscene")
 
 
 def bits(a):

@@ -1,4 +1,5 @@
-"""Distinct nodes per wave-level node step (development aid; TRX_TUNE bit 8 re-purposes the pair-total histogram)."""
+"""[needs a development build: make -C tray_racing_amd/csrc KFLAGS=-DTRX_DEV_TUNE OUT=... and TRX_LIB pointing at it]
+Distinct nodes per wave-level node step (development aid; TRX_TUNE bit 8 re-purposes the pair-total histogram)."""
 import ctypes as C
 import os
 import sys

@@ -1,4 +1,5 @@
-"""Times a list of TRX_TUNE development words (and optionally kernel-variant words, as tune:variant) on scenes
+"""[needs a development build: make -C tray_racing_amd/csrc KFLAGS=-DTRX_DEV_TUNE OUT=... and TRX_LIB pointing at it]
+Times a list of TRX_TUNE development words (and optionally kernel-variant words, as tune:variant) on scenes
 (development aid).  usage: python tools/gpu_tune.py bistro,hairball 0 1 2 0x4:0x100000"""
 import os
 import sys

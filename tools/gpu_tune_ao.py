@@ -1,4 +1,5 @@
-"""Times the AO pass and an explicit-ray pass for a list of TRX_TUNE development words / kernel-variant words
+"""[needs a development build: make -C tray_racing_amd/csrc KFLAGS=-DTRX_DEV_TUNE OUT=... and TRX_LIB pointing at it]
+Times the AO pass and an explicit-ray pass for a list of TRX_TUNE development words / kernel-variant words
 (tune:variant) on scenes (development aid).  usage: python tools/gpu_tune_ao.py bistro,hairball 0 1 0:0x14"""
 import os
 import sys

@@ -45,6 +45,7 @@ struct BuildSettings {
     uint32_t ploc_distance = 0; // 0: binned-SAH BVH2; > 0: PLOC with this search distance
     uint32_t ploc_depth_threshold = 2, ploc_sort_bits = 64;
     int ploc_device = -1;       // >= 0: the PLOC stage of large builds runs on this HIP device (trx_set_build_device)
+    bool reinsert_batched = false;
 };
 BuildSettings g_build;
 std::mutex g_build_mu;
@@ -67,6 +68,7 @@ BuildParams to_build_params(const BuildSettings &b, uint32_t max_prims, int thre
     bp.ploc_search_depth_threshold = b.ploc_depth_threshold;
     bp.ploc_sort_bits = b.ploc_sort_bits;
     bp.ploc_device = b.ploc_device;
+    bp.reinsertion_batched = b.reinsert_batched;
     return bp;
 }
 
@@ -380,10 +382,13 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.refill_idle = refill ? std::min(refill, 64u) : (mode == kModePrimary ? 64u : 20u);
     if (p.n_frames > 1) p.refill_idle = 64u; // the kernel takes the frame of a wave from its (whole) tile
     p.variant = variant;
-    {
-        const char *tune = getenv("TRX_TUNE"); // development switches
+#ifdef TRX_DEV_TUNE
+    {   // development builds only (make KFLAGS=-DTRX_DEV_TUNE): experiment switches of kernels.hip, some of which
+        // produce wrong results on purpose (ablation timing); the product has no such environment variable
+        const char *tune = getenv("TRX_TUNE");
         p.tune = tune ? (uint32_t)strtoul(tune, nullptr, 0) : 0u;
     }
+#endif
     p.n_tris = (uint32_t)s->n_tris;
     p.n_nodes = (uint32_t)s->n_nodes;
     {   // tuning: variant bits 25..28 = compaction threshold (0 = default, 15 = never)
@@ -1467,6 +1472,7 @@ int trx_flat_build_params(const float *verts, const uint64_t *object_tri_counts,
     b.ploc_distance = bp->ploc_search_distance;
     b.ploc_depth_threshold = bp->search_depth_threshold;
     b.ploc_sort_bits = bp->sort_precision;
+    b.reinsert_batched = true; // the parallel reinsertion pass, as in the reference's builder
     return flat_build_impl(verts, object_tri_counts, n_objects, use_tlas, bp->max_prims_per_leaf, threads, b, out);
 }
 

@@ -575,6 +575,102 @@ struct Reinserter {
         refit_up(tp);
     }
 
+    // Batched variant (Meister & Bittner's parallel formulation): the candidates of a batch search the tree as the
+    // previous batch left it, all at once; their moves are then applied in candidate order, skipping a move whose nodes
+    // an earlier move of the same batch touched or that would no longer be a legal re-link.  The searches are
+    // read-only and the application order is fixed, so the result does not depend on the thread count.
+    uint32_t run_batched(float batch_ratio, int iterations, int threads) {
+        const size_t n = nodes.size();
+        uint32_t moved = 0;
+        if (n < 8 || batch_ratio <= 0.f) return 0;
+        constexpr size_t kBatch = 2048;
+        threads = std::max(1, threads);
+        BigVec<std::pair<float, uint32_t>> cand;
+        std::vector<uint32_t> found(kBatch);
+        std::vector<uint32_t> touched_at(n, 0u); // batch stamp of the last move that re-linked this node
+        uint32_t stamp = 0;
+        // persistent workers: the main thread publishes a batch, everyone (it included) takes candidates by ticket
+        struct Shared {
+            std::atomic<uint32_t> generation{0}, next{0}, done{0};
+            std::atomic<bool> quit{false};
+            size_t begin = 0, count = 0;
+        } sh;
+        auto search_some = [&](Scratch &scratch) {
+            for (uint32_t k = sh.next.fetch_add(1); k < sh.count; k = sh.next.fetch_add(1)) {
+                const uint32_t from = cand[sh.begin + k].second;
+                uint32_t to = kNone;
+                if (parent[from] != 0 && parent[from] != kNone) (void)find(scratch, from, to);
+                found[k] = to;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; t++)
+            pool.emplace_back([&]() {
+                Scratch scratch;
+                uint32_t seen = 0;
+                for (;;) {
+                    uint32_t g;
+                    while ((g = sh.generation.load(std::memory_order_acquire)) == seen) {
+                        if (sh.quit.load(std::memory_order_acquire)) return;
+                        std::this_thread::yield();
+                    }
+                    seen = g;
+                    search_some(scratch);
+                    sh.done.fetch_add(1, std::memory_order_acq_rel);
+                }
+            });
+        Scratch scratch;
+        for (int it = 0; it < iterations; it++) {
+            cand.clear();
+            for (uint32_t i = 1; i < n; i++)
+                if (parent[i] != 0) cand.emplace_back(half_area(nodes[i].box), i);
+            const size_t take = std::min(cand.size(), (size_t)std::max(1.0, (double)n * batch_ratio));
+            auto larger = [](const std::pair<float, uint32_t> &a, const std::pair<float, uint32_t> &b) {
+                return a.first > b.first || (a.first == b.first && a.second < b.second);
+            };
+            if (take < cand.size()) std::nth_element(cand.begin(), cand.begin() + take, cand.end(), larger);
+            std::sort(cand.begin(), cand.begin() + take, larger);
+            uint32_t moved_now = 0;
+            for (size_t begin = 0; begin < take; begin += kBatch) {
+                sh.begin = begin;
+                sh.count = std::min(kBatch, take - begin);
+                sh.next.store(0, std::memory_order_relaxed);
+                sh.done.store(0, std::memory_order_relaxed);
+                sh.generation.fetch_add(1, std::memory_order_release);
+                search_some(scratch);
+                while (sh.done.load(std::memory_order_acquire) != (uint32_t)pool.size()) std::this_thread::yield();
+                stamp++;
+                for (size_t k = 0; k < sh.count; k++) {
+                    const uint32_t from = cand[begin + k].second, to = found[k];
+                    if (to == kNone) continue;
+                    const uint32_t p = parent[from];
+                    if (p == 0 || p == kNone || to == p || to == from || parent[to] == kNone) continue;
+                    const uint32_t s = sibling(from), g = parent[p], tp = parent[to];
+                    if (to == s) continue; // already its sibling: nothing to gain
+                    if (touched_at[from] == stamp || touched_at[p] == stamp || touched_at[s] == stamp || touched_at[g] == stamp ||
+                        touched_at[to] == stamp || touched_at[tp] == stamp)
+                        continue; // an earlier move of this batch re-linked one of them: the search is stale
+                    bool inside = false; // `to` must not lie below `from` (an earlier move may have put it there)
+                    for (uint32_t a = to; a != kNone; a = parent[a])
+                        if (a == from) {
+                            inside = true;
+                            break;
+                        }
+                    if (inside) continue;
+                    move(from, to);
+                    touched_at[from] = touched_at[p] = touched_at[s] = touched_at[g] = touched_at[to] = touched_at[tp] = stamp;
+                    moved_now++;
+                }
+            }
+            moved += moved_now;
+            if (moved_now == 0) break;
+        }
+        sh.quit.store(true, std::memory_order_release);
+        for (auto &th : pool) th.join();
+        if (moved) relayout(threads);
+        return moved;
+    }
+
     uint32_t run(float batch_ratio, int iterations, int threads) {
         const size_t n = nodes.size();
         uint32_t moved = 0;
@@ -898,8 +994,11 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
     out.total_aabb = b2.nodes[0].box;
     if (params.reinsertion_batch_ratio > 0.f && params.reinsertion_iterations > 0) {
         Reinserter opt(b2.nodes);
-        opt.run(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads);
-        lap("reinsertion");
+        if (params.reinsertion_batched)
+            opt.run_batched(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads);
+        else
+            opt.run(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads);
+        lap(params.reinsertion_batched ? "reinsertion (batched)" : "reinsertion");
     }
 
     Collapser col(b2.nodes, params, out);

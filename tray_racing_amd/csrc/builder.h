@@ -31,6 +31,10 @@ struct BuildParams {
     // per iteration (obvhs `reinsertion_batch_ratio`, src/main.rs:113-118); 0 = off
     float reinsertion_batch_ratio = 0.02f;
     int reinsertion_iterations = 4;
+    // false: candidates one at a time, each on the tree the previous move left (this library's own pipeline);
+    // true: batches of 2 048 candidates search the same tree on every core and their moves are applied in order,
+    // stale ones skipped (the parallel formulation of the paper, as obvhs runs it) — the ploc_cwbvh pipeline
+    bool reinsertion_batched = false;
     // pre-splitting (obvhs pre_split / --split): up to this fraction of extra triangle references, spent on
     // the triangles whose boxes are emptiest; 0 = off (the reference's default)
     float pre_split_ratio = 0.0f;

@@ -146,6 +146,7 @@ __device__ __forceinline__ uint32_t node_intersect(const Ray &r, float max_dista
 
 // TriDev = {v0, e1 = v0 - v1, e2 = v2 - v0} as three float4; ng = cross(e1, e2) (query.hlsl:93) rides in the
 // w lanes, evaluated at upload exactly as written there.
+template <bool EARLY = false>
 __device__ __forceinline__ bool intersect_tri(const Ray &r, const float4 a, const float4 b, const float4 c4,
                                               float &t, bool tie_first) {
     const float e1x = b.x, e1y = b.y, e1z = b.z;
@@ -155,9 +156,20 @@ __device__ __forceinline__ bool intersect_tri(const Ray &r, const float4 a, cons
     const float rx = r.dy * cz - r.dz * cy;
     const float ry = r.dz * cx - r.dx * cz;
     const float rz = r.dx * cy - r.dy * cx;
-    const float inv_det = 1.0f / dot3(ngx, ngy, ngz, r.dx, r.dy, r.dz);
-    const float u = dot3(rx, ry, rz, e2x, e2y, e2z) * inv_det;
-    const float v = dot3(rx, ry, rz, e1x, e1y, e1z) * inv_det;
+    const float det = dot3(ngx, ngy, ngz, r.dx, r.dy, r.dz);
+    const float un = dot3(rx, ry, rz, e2x, e2y, e2z), vn = dot3(rx, ry, rz, e1x, e1y, e1z);
+    if (EARLY) {
+        // u = un * (1 / det) and v = vn * (1 / det) carry the sign bits sign(un) ^ sign(det), sign(vn) ^ sign(det)
+        // whatever the magnitudes (a product's sign is the XOR of its operands', 1 / x keeps the sign of x, also
+        // for zeros and infinities); where a NaN appears the test below rejects anyway.  A set sign bit rejects the
+        // triangle (query.hlsl:111-116), so when NO lane of the wave can still accept, the IEEE divide, w, tt and the
+        // range test are skipped for the whole wave.  Lanes that go on compute exactly what they always did.
+        const uint32_t neg = ((__float_as_uint(un) ^ __float_as_uint(det)) | (__float_as_uint(vn) ^ __float_as_uint(det))) & 0x80000000u;
+        if (__ballot(neg == 0u) == 0ull) return false;
+    }
+    const float inv_det = 1.0f / det;
+    const float u = un * inv_det;
+    const float v = vn * inv_det;
     const float w = 1.0f - u - v;
     const uint32_t hit = __float_as_uint(u) | __float_as_uint(v) | __float_as_uint(w);
     if (inv_det != 0.0f && (hit & 0x80000000u) == 0) {
@@ -662,7 +674,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     }
                     if (lane == 0) {
                         atomicAdd(&P.ctr->hist_max[min(mx, 15u)], 1u);
-                        if (!(P.tune & 0x100u)) atomicAdd(&P.ctr->hist_total[min((sum + 7u) >> 3, 15u)], 1u);
+#ifdef TRX_DEV_TUNE
+                        if (!(P.tune & 0x100u))
+#endif
+                            atomicAdd(&P.ctr->hist_total[min((sum + 7u) >> 3, 15u)], 1u);
                     }
                 }
                 // Cooperative rounds cost about three per-lane rounds of VALU work (scans, owner look-up, the LDS
@@ -724,7 +739,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             if (lane_rank(__ballot(1)) == 0) c_wtri++;
                             if (P.touch_tris) P.touch_tris[gidx] = 1;
                         }
-                        if (intersect_tri(r, a, b, c4, t, tie_first)) {
+                        if (intersect_tri<true>(r, a, b, c4, t, tie_first)) {
                             prim = gidx;
                             if (TLAS) hit_inst = cur_inst;
                         }
@@ -810,6 +825,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         c_node++;
                         if (lane_rank(__ballot(1)) == 0) c_wnode++;
                         if (P.touch_nodes) P.touch_nodes[node_index] = 1;
+#ifdef TRX_DEV_TUNE
                         if (P.tune & 0x100u) {
                             // diagnostics: distinct nodes among the lanes of this wave-level node step
                             unsigned long long todo = __ballot(1);
@@ -823,12 +839,16 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             }
                             if (lane == first) atomicAdd(&P.ctr->hist_total[min(distinct, 15u)], 1u);
                         }
+#endif
                     }
                     const uint32_t hitmask = node_intersect<NODE>(r, t, n0, n1, n2, n3, n4);
                     cur.x = n1.x;
                     tri.x = n1.y;
                     cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
                     tri.y = hitmask & 0x00ffffffu;
+#ifdef TRX_DEV_TUNE
+                    if (P.tune & 2u) tri.y = 0u; // ablation (timing only, results wrong): no triangle phase at all
+#endif
                 } else {
                     tri = cur;
                     cur = make_uint2(0u, 0u);
