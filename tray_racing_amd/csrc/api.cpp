@@ -1465,7 +1465,7 @@ int trx_flat_build_params(const float *verts, const uint64_t *object_tri_counts,
     // obvhs: 0..1 is the candidate ratio of one pass, above 1 the whole set is evaluated several times
     b.reinsert_ratio = std::min(bp->reinsertion_batch_ratio, 1.0f);
     b.reinsert_iters = bp->reinsertion_batch_ratio > 1.f ? (int)std::ceil(bp->reinsertion_batch_ratio)
-                       : bp->reinsertion_batch_ratio > 0.f ? std::max(1, b.reinsert_iters) : 0;
+                       : bp->reinsertion_batch_ratio > 0.f ? std::max(1, b.reinsert_iters) : 0; // passes: this library's (4)
     b.pre_split = bp->pre_split ? 0.3f : 0.0f;
     if (bp->ploc_search_distance < 1 || bp->ploc_search_distance > 32)
         return fail(TRX_ERR_INVALID, "ploc_search_distance %u outside 1..32", bp->ploc_search_distance);
@@ -1550,7 +1550,7 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             uint64_t f0 = 0;
             for (size_t i = 0; i < counts.size(); i++) { firsts[i] = f0; f0 += counts[i]; }
             const auto t0 = std::chrono::steady_clock::now();
-            int nthreads = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+            int nthreads = threads > 0 ? threads : usable_threads();
             if (nthreads < 1) nthreads = 1;
             const uint64_t kSmall = 65536;
             std::vector<size_t> small;

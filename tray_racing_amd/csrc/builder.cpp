@@ -13,7 +13,31 @@
 #include <stdexcept>
 #include <thread>
 
+#include <sched.h>
+
 namespace trx {
+
+int usable_threads() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        const int a = CPU_COUNT(&set);
+        if (a > 0) n = std::min(n, a);
+    }
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota> <period>" or "max <period>"
+        char quota[32] = {0};
+        long period = 0;
+        if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0) {
+            const long q = std::atol(quota);
+            if (q > 0) n = std::max(1, std::min(n, (int)((q + period / 2) / period)));
+        }
+        std::fclose(f);
+    }
+    return n;
+}
+
 namespace {
 
 constexpr float kInf = std::numeric_limits<float>::infinity();
@@ -583,8 +607,8 @@ struct Reinserter {
         const size_t n = nodes.size();
         uint32_t moved = 0;
         if (n < 8 || batch_ratio <= 0.f) return 0;
-        constexpr size_t kBatch = 2048;
-        threads = std::max(1, threads);
+        static const size_t kBatch = getenv("TRX_REINSERT_BATCH") ? (size_t)atoi(getenv("TRX_REINSERT_BATCH")) : 128;
+        threads = std::max(1, std::min(threads, std::min(usable_threads(), 32))); // the workers spin between batches: never more than the cores
         BigVec<std::pair<float, uint32_t>> cand;
         std::vector<uint32_t> found(kBatch);
         std::vector<uint32_t> touched_at(n, 0u); // batch stamp of the last move that re-linked this node
@@ -942,7 +966,7 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
     BuildParams params = params_in;
     if (params.max_prims_per_leaf < 1) params.max_prims_per_leaf = 1;
     if (params.max_prims_per_leaf > 3) params.max_prims_per_leaf = 3;
-    int threads = params.threads > 0 ? params.threads : (int)std::thread::hardware_concurrency();
+    int threads = params.threads > 0 ? params.threads : usable_threads();
     if (threads < 1) threads = 1;
 
     out.nodes.clear();

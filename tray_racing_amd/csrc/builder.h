@@ -32,7 +32,7 @@ struct BuildParams {
     float reinsertion_batch_ratio = 0.02f;
     int reinsertion_iterations = 4;
     // false: candidates one at a time, each on the tree the previous move left (this library's own pipeline);
-    // true: batches of 2 048 candidates search the same tree on every core and their moves are applied in order,
+    // true: batches of 128 candidates search the same tree on every core and their moves are applied in order,
     // stale ones skipped (the parallel formulation of the paper, as obvhs runs it) — the ploc_cwbvh pipeline
     bool reinsertion_batched = false;
     // pre-splitting (obvhs pre_split / --split): up to this fraction of extra triangle references, spent on
@@ -53,6 +53,10 @@ struct BuildParams {
 };
 
 constexpr uint64_t kDevicePlocMinPrims = 32768;
+
+// Host cores this process may really use: hardware threads, capped by the CPU affinity mask and the cgroup CPU quota
+// (a container that sees 256 hardware threads but owns 16 must not start 256 workers).
+int usable_threads();
 
 // Build over arbitrary primitive boxes (TLAS path, src/cwbvh.rs:114,132).
 void build_cwbvh_from_aabbs(const Aabb *boxes, uint64_t n, const BuildParams &params, CwBvh &out);
