@@ -32,10 +32,51 @@ def differs(got, want):
 BIG = False   # --big: few large cases (up to 1 M triangles, up to 1920x1080) instead of many small ones
 
 
+def instanced_case(T, O, rng, case):
+    """Random instanced scene (several transformed instances per object, shear and non-uniform scale included): explicit
+    rays, or a primary + AO frame, with the instance ids beside the hits."""
+    from helpers import aimed_rays, instanced_scene, random_rays
+    seed = int(rng.integers(1, 1 << 30))
+    kind = str(rng.choice(["soup", "soup", "cornell", "kitchen"]))
+    n_inst = int(rng.integers(1, 40))
+    tris = int(rng.choice([40, 400, 3000])) if kind == "soup" else (0 if kind == "cornell" else int(rng.choice([3000, 20000])))
+    sem = int(rng.integers(8))
+    flat, _o2w, world, _first, _b = instanced_scene(T, seed=seed % 100000, n_objects=int(rng.integers(1, 6)), n_instances=n_inst,
+                                                   tris_per_object=tris, kind=kind, spread=float(rng.uniform(0.5, 6.0)))
+    sc = T.Scene(flat)
+    osc = O.Scene(flat.nodes, flat.tri_verts, flat.instance_offsets, flat.tlas_start, instance_w2o=sc.instance_world_to_object())
+    desc = "case %d: instanced %s x%d seed=%d sem=%d" % (case, kind, n_inst, seed, sem)
+    bad = []
+    try:
+        if rng.integers(2):
+            wflat = type("W", (), {"tri_verts": world})
+            rays = np.concatenate([random_rays(T, wflat, int(rng.integers(1, 4000)), seed), aimed_rays(T, world, int(rng.integers(1, 12000)), seed + 1)])
+            got, gi, _ = sc.trace_rays_inst(rays, sem=sem)
+            want, wi, _ = osc.trace_rays_inst(rays, sem=sem)
+            bad += [("inst rays", differs(got, want)), ("inst ids", (int((gi != wi).sum()),) if (gi != wi).any() else None)]
+        else:
+            w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+            lo, hi = world.reshape(-1, 3).min(0), world.reshape(-1, 3).max(0)
+            eye = (lo + rng.uniform(-0.3, 1.3, 3) * (hi - lo + 1e-3)).tolist()
+            view = T.view_from_camera(eye, (0.5 * (lo + hi)).tolist(), float(rng.uniform(30, 110)), w, h)
+            ov = O.view_from_bytes(bytes(view))
+            frame = int(rng.integers(0, 5000))
+            gp, gpi, gao, gaoi, _ = sc.trace_primary_ao_inst(view, w, h, sem=sem, frame=frame, ao_eps=0.01)
+            wp, wpi, _ = osc.trace_primary_inst(ov, w, h, sem=sem)
+            wao, waoi, _ = osc.trace_ao_inst(ov, w, h, wp, wpi, sem=sem, frame=frame, ao_eps=0.01)
+            bad += [("inst primary", differs(gp, wp)), ("inst ao", differs(gao, wao)),
+                    ("inst ids", (int((gpi != wpi).sum()) + int((gaoi != waoi).sum()),) if ((gpi != wpi).any() or (gaoi != waoi).any()) else None)]
+    finally:
+        sc.close()
+    return desc, [(k, v) for k, v in bad if v]
+
+
 def one_case(T, O, rng, case):
     import torch
     from helpers import random_rays
     from tray_racing_amd import dist as D
+    if not BIG and rng.integers(8) == 0:
+        return instanced_case(T, O, rng, case)
     name = SCENES[int(rng.integers(len(SCENES)))]
     n = int(rng.choice([200000, 500000, 1000000] if BIG else [1, 2, 3, 17, 300, 2500, 20000, 90000]))
     if name in ("cornell",):
@@ -48,7 +89,13 @@ def one_case(T, O, rng, case):
     verts, counts = T.gen_scene(name, n, seed)
     leaf = int(rng.integers(1, 4))
     split = float(rng.choice([0.0, 0.0, 0.3, 1.0]))
-    flat = T.flat_build(verts, counts, use_tlas=tlas, max_prims_per_leaf=leaf, split=split)
+    if rng.integers(4) == 0:   # the ploc_cwbvh pipeline with random BvhBuildParams
+        bp = T.build_params(ploc_search_distance=int(rng.integers(1, 33)), search_depth_threshold=int(rng.integers(0, 6)),
+                            sort_precision=int(rng.choice([64, 128])), reinsertion_batch_ratio=float(rng.choice([0.0, 0.05, 0.15, 1.5])),
+                            max_prims_per_leaf=leaf, pre_split=int(split > 0))
+        flat = T.flat_build_params(verts, counts, bp, use_tlas=tlas)
+    else:
+        flat = T.flat_build(verts, counts, use_tlas=tlas, max_prims_per_leaf=leaf, split=split)
     T.flat_build(verts[:1], split=0.0)
     eye, look, fov = T.scene_camera(name)
     pts = flat.tri_verts.reshape(-1, 3)

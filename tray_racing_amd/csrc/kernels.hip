@@ -890,30 +890,30 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             k_iters++;
 #endif
             if (act) {
-                bool done = false;
-                if ((cur.y & 0xff000000u) == 0u) {
-                    if (sp == 0u) {
-                        done = true;
-                    } else {
-                        if (TLAS && sp == tlas_sp) { // back to the TLAS (query_tlas.hlsl:480-486)
-                            tlas_sp = TRX_INVALID;
-                            bvh_off = P.tlas_start;
-                            cur_inst = TRX_INVALID;
-                            if (P.inst_xform) { // "Reset Ray to untransformed version" (query_tlas.hlsl:484)
-                                r.ox = wox; r.oy = woy; r.oz = woz;
-                                finish_ray_dir(r, wdx, wdy, wdz);
-                                lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
-                                lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
-                            }
+                // a lane whose node group is spent pops the next one, or is finished when its stack is empty
+                const bool spent = (cur.y & 0xff000000u) == 0u;
+                bool done = spent && sp == 0u;
+                if (spent && sp != 0u) {
+                    if (TLAS && sp == tlas_sp) { // back to the TLAS (query_tlas.hlsl:480-486)
+                        tlas_sp = TRX_INVALID;
+                        bvh_off = P.tlas_start;
+                        cur_inst = TRX_INVALID;
+                        if (P.inst_xform) { // "Reset Ray to untransformed version" (query_tlas.hlsl:484)
+                            r.ox = wox; r.oy = woy; r.oz = woz;
+                            finish_ray_dir(r, wdx, wdy, wdz);
+                            lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+                            lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
                         }
-                        cur = stack_pop();
                     }
+                    cur = stack_pop();
                 }
                 // step cap (every wave reaches an exit whatever the tree): a ray's steps are bounded by the wave's
                 // trips since it started; looked at once per 1024 trips, so the common trip pays nothing for it
-                if (__builtin_expect((trip & 1023u) == 0u, 0) && trip - steps > kMaxSteps) {
-                    overflow = 1u;
-                    done = true;
+                if (__builtin_expect((trip & 1023u) == 0u, 0)) {
+                    if (trip - steps > kMaxSteps) {
+                        overflow = 1u;
+                        done = true;
+                    }
                 }
                 // any-hit query (intersects_bl_bvh, query.hlsl:440-445): the first accepted triangle settles it.
                 // Until a hit is accepted the walk is the closest-hit walk, so hit / no hit is the same answer.
