@@ -371,6 +371,23 @@ def main():
         torch.cuda.synchronize()
         legs["hbm_copy_gbs"] = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
         del src, dst
+        # (h) a camera that moves: every frame a new view (the eye and its target advance 5 cm along the street per frame),
+        #     the tile order learnt from the PREVIOUS view; what a renderer with temporal coherence gets, between the
+        #     static-camera figure and the cold one
+        mv = []
+        mbuf = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
+        for f in range(48):
+            off = 0.05 * f
+            v = T.view_from_camera((eye[0] + off, eye[1], eye[2]), (look[0] + off, look[1], look[2]), fov, w, h)
+            a, b = ev(), ev()
+            a.record()
+            scene.trace_primary_dev(v, w, h, mbuf.data_ptr(), sem=args.sem)
+            b.record()
+            mv.append((a, b))
+        torch.cuda.synchronize()
+        mt = [a.elapsed_time(b) for a, b in mv][8:]
+        legs["moving_camera_ms"] = {"step_m": 0.05, "frames": len(mt), "min": round(min(mt), 4), "mean": round(sum(mt) / len(mt), 4)}
+        del mbuf
         # (g) second headline row: the denser bistro-class stand-in built to the reference's PROFILE_RT legend
         #     (about 30 node visits / 15 triangle tests per primary ray, rt_gpu_software.hlsl:95,102), same protocol
         if args.scene == "bistro" and args.tris == 0:
