@@ -78,3 +78,53 @@ def test_rccl_communicator_through_the_abi(trx):
         assert (got[f]["prim"] == want["prim"]).all() and (got[f]["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
     fg.close()
     sc.close()
+
+
+def test_torch_nccl_in_place_all_gather_as_bench_calls_it(trx, tmp_path):
+    """bench.py's N > 1 loop ends in dist.all_gather_into_tensor(flat[:N*n], flat[r*n:(r+1)*n], async_op=True) on RCCL.
+    A one-GPU box can only form a one-rank group, so this checks the exact call (in place, asynchronous, waited on by
+    the stream) through torch's RCCL rather than its scaling: a child process initialises the NCCL backend, runs one
+    batch of the loop and compares the assembled frames with image-layout traces."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+import tray_racing_amd as T
+from tray_racing_amd import dist as D
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+w, h, m = 160, 96, 3
+verts, counts = T.gen_scene("kitchen", 20000, 1)
+flat = T.flat_build(verts, counts)
+eye, look, fov = T.scene_camera("kitchen")
+view = T.view_from_camera(eye, look, fov, w, h)
+sc = T.Scene(flat)
+fg = D.FrameGather(w, h, 0, 1, "cuda", batch=m)
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    sc.trace_primary_batch_dev([view] * m, w, h, fg.slot(0, m).data_ptr(), fg.records, sem=3, shard=(0, 1, 1), stream=s.cuda_stream)
+    n = m * fg.records
+    work = dist.all_gather_into_tensor(fg.flat[:n], fg.flat[:n], async_op=True)   # world 1: FrameGather.gather returns early, so call it here
+    work.wait()
+    frames = fg.assemble(m=m)
+s.synchronize()
+want, _ = sc.trace_primary(view, w, h, sem=3)
+got = D.int64_to_hits(frames).reshape(m, w * h)
+ok = all((got[f]["prim"] == want["prim"]).all() and (got[f]["t"].view(np.uint32) == want["t"].view(np.uint32)).all() for f in range(m))
+print("NCCL_OK" if ok and dist.get_backend() == "nccl" else "NCCL_BAD")
+sc.close()
+dist.destroy_process_group()
+''' % root
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode == 0 and "NCCL_OK" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])

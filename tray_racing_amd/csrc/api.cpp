@@ -378,8 +378,9 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     uint32_t refill = variant & 0x7fu;
     // coherent primary rays: refill a wave only when its whole tile is done (mixing tiles costs more
     // coherence than idle lanes cost); incoherent rays (AO, explicit batches): replace finished rays
-    // once 20 lanes idle (bistro-class AO pass 1.72 -> 1.16 ms, kitchen-class 0.75 -> 0.46 ms)
-    p.refill_idle = refill ? std::min(refill, 64u) : (mode == kModePrimary ? 64u : 20u);
+    // once 12 lanes idle (whole-tile refills: bistro-class AO pass 1.59 ms; 20 idle lanes 1.14; 12 idle lanes 1.11,
+    // and 1-3 % under the 20-lane figure on the dense and hairball-class scenes too, gpurun_out/r2e_refill.log)
+    p.refill_idle = refill ? std::min(refill, 64u) : (mode == kModePrimary ? 64u : 12u);
     if (p.n_frames > 1) p.refill_idle = 64u; // the kernel takes the frame of a wave from its (whole) tile
     p.variant = variant;
 #ifdef TRX_DEV_TUNE
