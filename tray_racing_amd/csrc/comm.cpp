@@ -111,11 +111,14 @@ int trx_comm_create(const void *id128, int rank, int world, int device, trx_comm
     if (world < 1 || rank < 0 || rank >= world) return trx::fail_msg(TRX_ERR_INVALID, "rank %d of %d", rank, world);
     Rccl &r = rccl();
     if (!r.error.empty()) return trx::fail_msg(TRX_ERR_NO_DEVICE, "%s", r.error.c_str());
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);
     if (hipSetDevice(device) != hipSuccess) return trx::fail_msg(TRX_ERR_NO_DEVICE, "no HIP device %d", device);
     NcclId id;
     std::memcpy(&id, id128, sizeof(id));
     NcclComm comm = nullptr;
-    const int rc = r.comm_init_rank(&comm, world, id, rank);
+    const int rc = r.comm_init_rank(&comm, world, id, rank); // binds the communicator to the current device
+    if (prev_device >= 0 && prev_device != device) (void)hipSetDevice(prev_device);
     if (rc != 0) return trx::fail_msg(TRX_ERR_NO_DEVICE, "ncclCommInitRank: %s", r.get_error_string ? r.get_error_string(rc) : "error");
     trx_comm *c = new trx_comm;
     c->comm = comm;

@@ -183,6 +183,14 @@ bool ploc_bvh2_device(int device, const Aabb *boxes, const float *centroids, uin
         err = "no HIP device " + std::to_string(device) + " for the GPU build stage";
         return false;
     }
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);
+    struct DeviceGuard { // the caller's current device is put back whatever happens below
+        int prev;
+        ~DeviceGuard() {
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
+    } device_guard{prev_device};
     PG_TRY(hipSetDevice(device));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     PG_TRY(hipEventCreate(&ev0));
