@@ -402,15 +402,6 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.waves_per_block = wpb;
     p.wave_times = s->d_wave_times;
     p.single_queue = (variant >> 21) & 1u;
-    if (mode != kModeRays && p.refill_idle == 64u && ((variant >> 7) & 1u)) {
-        // experiment (variant bit 7): before a tile order has been learnt, walk the tiles in a fixed scattered order
-        // (a multiplier coprime with the tile count, near the golden section) instead of row-major
-        const uint32_t n_t = (p.n_items + 63u) >> 6;
-        uint32_t a = (uint32_t)(0.6180339887 * n_t) | 1u;
-        auto gcd = [](uint32_t x, uint32_t y) { while (y) { uint32_t t = x % y; x = y; y = t; } return x; };
-        while (a > 1u && gcd(a, n_t) != 1u) a += 2u;
-        p.cold_mul = n_t > 2u ? a : 0u;
-    }
     // tile order feedback (image modes, whole-tile refills only)
     const bool lpt = mode != kModeRays && p.refill_idle == 64u && !((variant >> 20) & 1u);
     const uint32_t n_tiles = (p.n_items + 63u) >> 6;

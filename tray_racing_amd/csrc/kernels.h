@@ -78,7 +78,6 @@ struct TraceParams {
     uint32_t shard_index, shard_count;
     uint32_t compact; // TRX_LAYOUT_SHARD: hit buffers indexed by local_tile*64 + pixel-in-tile
     uint32_t single_queue;  // tuning: one global queue instead of one per XCD
-    uint32_t cold_mul;      // image modes, no learnt order yet: chunk p is tile (p * cold_mul) % n_chunks (0: p itself)
     // tile order feedback: 16 x kLptShards list counts + lists (lpt_cap entries each) read / written this frame
     uint32_t *lpt_read_counts;
     const uint32_t *lpt_read_lists;

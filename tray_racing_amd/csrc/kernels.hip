@@ -479,7 +479,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     chunk_next = chunk << 6;
                     chunk_left = min(64u, P.n_items - chunk_next);
                     cur_tile = chunk;
-                    if (MODE != kModeRays && P.cold_mul != 0u) cur_tile = (uint32_t)(((unsigned long long)chunk * P.cold_mul) % n_chunks);
                     if (ordered) {
                         // chunk -> bucket (heaviest first) -> tile
                         uint32_t j = (uint32_t)__popcll(__ballot(chunk >= end_a));
