@@ -388,6 +388,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint32_t my_q = P.single_queue ? 0u : (read_xcc_id() & 7u);
     uint32_t q_probes = 0;
     uint32_t pending = 0; // prefetched ticket of queue my_q (lane 0)
+    bool have_pending = true; // uniform: a ticket of queue my_q is in flight / held in `pending`
     if (lane == 0) pending = atomicAdd(&P.ctr->heads[my_q].taken, 1u);
     uint32_t chunk_next = 0, chunk_left = 0; // items of the current chunk not yet handed to a lane
     uint32_t n_pend = 0;                     // tile-list entries parked in lds_pend (uniform)
@@ -415,6 +416,14 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         ordered = intact && (uint32_t)__builtin_amdgcn_readlane((int)end_b, 63) == n_chunks; // complete lists
     }
 
+    // chunks below this index of the heaviest-first order take their successor's ticket late (measured: never / always /
+    // heaviest 3 % / 12 % / 50 %, profiles/r02_late_binding.log; the heavier half is best on every scene)
+#ifdef TRX_DEV_TUNE
+    const uint32_t late_sel = (P.tune >> 4) & 7u ? (P.tune >> 4) & 7u : 4u; // 1 always, 2 / 3 / 4: heaviest 3 / 12 / 50 %, 5 never
+#else
+    const uint32_t late_sel = 4u;
+#endif
+    const uint32_t late_cut = late_sel == 1u ? 0xffffffffu : late_sel >= 5u ? 0u : P.prio_cut[late_sel - 2u];
     bool exhausted = false; // wave-uniform
     for (;;) {
         TRX_STAMP(k_pop);
@@ -461,6 +470,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             while (given < n_idle) {
                 if (chunk_left == 0u) {
                     // take the prefetched ticket; walk to the next queue when this one is dry
+                    if (!have_pending && lane == 0) pending = atomicAdd(&P.ctr->heads[my_q].taken, 1u);
                     uint32_t ticket = __builtin_amdgcn_readfirstlane(pending);
                     uint32_t q_count = P.single_queue ? n_chunks : ((n_chunks + 7u - my_q) >> 3);
                     while (ticket >= q_count) {
@@ -474,7 +484,13 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         exhausted = true;
                         break;
                     }
-                    if (lane == 0) pending = atomicAdd(&P.ctr->heads[my_q].taken, 1u); // prefetch the next one
+                    // a ticket taken a tile ahead hides the atomic's round trip (1-2 us) but binds the wave's NEXT tile
+                    // while it still works on this one: a wave stuck on a 0.3 ms tile then sits on a second one that an idle
+                    // wave could have started.  Late binding wins wherever tiles are long or of unknown cost - the heavier
+                    // half of the heaviest-first order, and every pass that has no learnt order (first frame, AO, explicit
+                    // rays); only the light half of an ordered frame keeps the prefetch
+                    have_pending = ordered && ticket * (P.single_queue ? 1u : 8u) >= late_cut;
+                    if (have_pending && lane == 0) pending = atomicAdd(&P.ctr->heads[my_q].taken, 1u);
                     const uint32_t chunk = P.single_queue ? ticket : ticket * 8u + my_q;
                     chunk_next = chunk << 6;
                     chunk_left = min(64u, P.n_items - chunk_next);
