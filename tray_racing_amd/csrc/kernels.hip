@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 #else
     const uint32_t late_sel = 4u;
 #endif
-    const uint32_t late_cut = late_sel == 1u ? 0xffffffffu : late_sel >= 5u ? 0u : P.prio_cut[late_sel - 2u];
+    const uint32_t late_cut = late_sel == 1u ? 0xffffffffu : late_sel >= 5u ? 0u : late_sel == 4u ? (n_chunks >> 1) : P.prio_cut[late_sel - 2u];
     bool exhausted = false; // wave-uniform
     for (;;) {
         TRX_STAMP(k_pop);
