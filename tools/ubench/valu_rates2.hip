@@ -49,6 +49,10 @@
 #define I_MADU64(k) "v_mad_u64_u32 v[20:21], s[22:23], %8, %9, v[24:25]\n"
 #define I_FFBH(k) "v_ffbh_u32 %" #k ", %" #k "\n"
 #define I_BCNT(k) "v_bcnt_u32_b32 %" #k ", %8, %" #k "\n"
+#define I_MULLO(k) "v_mul_lo_u32 %" #k ", %8, %" #k "\n"
+#define I_MULU24(k) "v_mul_u32_u24 %" #k ", %8, %" #k "\n"
+#define I_LSHLOR(k) "v_lshl_or_b32 %" #k ", %8, 2, %" #k "\n"
+#define I_SUBU(k) "v_sub_u32 %" #k ", %8, %" #k "\n"
 #define I_RCP(k) "v_rcp_f32 %" #k ", %" #k "\n"
 #define I_MOVDPP(k) "v_mov_b32_dpp %" #k ", %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
 #define I_SAND(k) "s_and_b64 s[20:21], s[20:21], s[22:23]\n"
@@ -61,7 +65,7 @@ DEF(fma, I_FMA) DEF(mul, I_MUL) DEF(max, I_MAX) DEF(max3, I_MAX3) DEF(cvt_ub, I_
 DEF(pk_fma, I_PKFMA) DEF(and_b32, I_AND) DEF(lshl, I_LSHL) DEF(bfe, I_BFE) DEF(add_u32, I_ADDU) DEF(cnd_vcc, I_CNDVCC)
 DEF(cnd_sgpr, I_CNDSG) DEF(cmp, I_CMP) DEF(cmp_cnd, I_CMPCND) DEF(or3, I_OR3) DEF(lshl_sdwa, I_LSHLSDWA) DEF(mad_u64, I_MADU64)
 DEF(ffbh, I_FFBH) DEF(bcnt, I_BCNT) DEF(rcp, I_RCP) DEF(mov_dpp, I_MOVDPP) DEF(s_and, I_SAND) DEF(s_add, I_SADD) DEF(s_nop, I_SNOP)
-DEF(fma_salu, I_FMA_SALU) DEF(mix4, I_MIX)
+DEF(fma_salu, I_FMA_SALU) DEF(mix4, I_MIX) DEF(mul_lo, I_MULLO) DEF(mul_u24, I_MULU24) DEF(lshl_or, I_LSHLOR) DEF(sub_u32, I_SUBU)
 
 struct Entry {
     const char *name;
@@ -72,7 +76,7 @@ struct Entry {
 static const Entry entries[] = {
     E(fma, 64), E(mul, 64), E(max, 64), E(max3, 64), E(cvt_ub, 64), E(pk_mul, 64), E(pk_add, 64), E(pk_fma, 64), E(and_b32, 64), E(lshl, 64),
     E(bfe, 64), E(add_u32, 64), E(cnd_vcc, 64), E(cnd_sgpr, 64), E(cmp, 64), E(cmp_cnd, 128), E(or3, 64), E(lshl_sdwa, 64),
-    E(mad_u64, 64), E(ffbh, 64), E(bcnt, 64), E(rcp, 64), E(mov_dpp, 64), E(s_and, 64), E(s_add, 64), E(s_nop, 64), E(fma_salu, 128), E(mix4, 256),
+    E(mad_u64, 64), E(ffbh, 64), E(bcnt, 64), E(rcp, 64), E(mov_dpp, 64), E(s_and, 64), E(s_add, 64), E(s_nop, 64), E(fma_salu, 128), E(mix4, 256), E(mul_lo, 64), E(mul_u24, 64), E(lshl_or, 64), E(sub_u32, 64),
 };
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
