@@ -361,7 +361,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     float t = 0.0f;
     uint32_t prim = TRX_INVALID, out_index = 0, sp = 0, steps = 0;
     uint32_t trip = 0; // traversal-loop trips of this wave (uniform)
-    uint32_t esc_trip0 = 0;
     uint32_t tlas_sp = TRX_INVALID, bvh_off = 0;
     // instance transforms (TLAS): the instance being walked / the one the current hit was found in, and the
     // world-space ray (origin, direction as given) to come back to when the BLAS is left
@@ -496,8 +495,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     chunk_next = chunk << 6;
                     chunk_left = min(64u, P.n_items - chunk_next);
                     cur_tile = chunk;
-                    esc_trip0 = trip; // escalation clock of the unordered passes restarts with every chunk
-                    if (!ordered && (P.variant >> 7) & 1u) __builtin_amdgcn_s_setprio(0);
                     if (ordered) {
                         // chunk -> bucket (heaviest first) -> tile
                         uint32_t j = (uint32_t)__popcll(__ballot(chunk >= end_a));
@@ -821,14 +818,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             const bool act = has_ray;
             uint2 tri = make_uint2(0u, 0u);
             trip++;
-            if (!ordered && ((P.variant >> 7) & 1u)) {
-                // experiment: without a learnt order nobody knows which tiles are the long ones until they have been
-                // running for a while - a wave raises its own issue priority as its chunk grows old
-                const uint32_t age = trip - esc_trip0;
-                if (age == 24u) __builtin_amdgcn_s_setprio(1);
-                else if (age == 48u) __builtin_amdgcn_s_setprio(2);
-                else if (age == 96u) __builtin_amdgcn_s_setprio(3);
-            }
             if (act) {
                 // BLAS-only: a lane at the top of the loop always holds a node group (triangle groups are drained
                 // in the trip that found them; only the TLAS walk parks them on the stack)
