@@ -622,10 +622,12 @@ def test_fixed_seed_slice_of_the_fuzzer(trx, orc):
     assert cases == 40 and not failures, failures[:3]
 
 
-def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path):
-    """bench.py's N > 1 path end to end on one GPU: two ranks (gloo, shard gather staged through
+@pytest.mark.parametrize("world,streams,batch", [(2, 2, 4), (8, 8, 8)])
+def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path, world, streams, batch):
+    """bench.py's N > 1 path end to end on one GPU: `world` ranks (gloo, shard gather staged through
     host memory) trace their tile shards on device 0 in batches; the frame rank 0 ends up with is
-    checked against the oracle here."""
+    checked against the oracle here.  world = 8 with bench.py's own defaults for 8 GPUs (8 streams, 8 frames per
+    gather) is the geometry the driver's scaling run uses."""
     import json
     import socket
     import subprocess
@@ -636,25 +638,25 @@ def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path):
     port = s.getsockname()[1]
     s.close()
     dump = str(tmp_path / "frame.npy")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
-           "--warmup", "2", "--tris", "150000", "--width", "256", "--height", "136", "--dist-backend", "gloo",
-           "--dump-frame", dump, "--streams", "2", "--gather-batch", "4"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps",
+           str(batch + 2), "--warmup", "2", "--tris", "150000", "--width", "256", "--height", "136", "--dist-backend", "gloo",
+           "--dump-frame", dump, "--streams", str(streams), "--gather-batch", str(batch)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["value"] > 0
-    assert d["scaling"] == "strong" and d["config"]["frames_in_flight"] == 2
-    assert d["config"]["frames_per_gather"] == 4   # 6 timed frames = one full batch + a partial one
+    assert d["n_gpus"] == world and d["value"] > 0
+    assert d["scaling"] == "strong" and d["config"]["frames_in_flight"] == streams
+    assert d["config"]["frames_per_gather"] == batch   # batch + 2 timed frames = one full batch + a partial one
     ph = d["phases_ms_per_frame"]                    # per-phase times of the N > 1 loop
-    assert ph["collective_world_size"] == 2 and ph["trace"] > 0 and ph["gather"] > 0 and ph["assemble"] > 0
+    assert ph["collective_world_size"] == world and ph["trace"] > 0 and ph["gather"] > 0 and ph["assemble"] > 0
     g = np.load(dump + ".scene.npz")
     osc = orc.Scene(g["nodes"], g["tri_verts"], g["instance_offsets"], int(g["tlas_start"]))
     want, _ = osc.trace_primary(orc.view_from_bytes(g["view"].tobytes()), int(g["width"]), int(g["height"]), sem=3)
     from tray_racing_amd import dist as D
     import torch
-    assert_hits_equal(D.int64_to_hits(torch.from_numpy(np.load(dump))), want, "2-rank bench frame")
+    assert_hits_equal(D.int64_to_hits(torch.from_numpy(np.load(dump))), want, "%d-rank bench frame" % world)
 
 
 def test_scheduling_variants_and_streams_do_not_change_results(trx, orc):
