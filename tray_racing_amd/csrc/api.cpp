@@ -1591,23 +1591,40 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             CwBvh &bvh = built[bi];
             const uint32_t tri_offset = (uint32_t)(tri_out.size() / 9);
             blas_tri_start.push_back(tri_offset);
-            // permute triangles into primitive_indices order (mod.rs:38-43)
-            for (size_t k = 0; k < bvh.primitive_indices.size(); k++) {
-                const uint32_t pi = bvh.primitive_indices[k];
-                const float *v = verts + (first + pi) * 9;
-                tri_out.insert(tri_out.end(), v, v + 9);
-                tri_source.push_back((uint32_t)(first + pi));
-                // the box this entry was built with: the triangle's own, or its clipped part after pre-splitting
-                float bx[6];
-                if (!bvh.primitive_boxes.empty()) {
-                    for (int a = 0; a < 3; a++) { bx[a] = bvh.primitive_boxes[k].mn[a]; bx[3 + a] = bvh.primitive_boxes[k].mx[a]; }
-                } else {
-                    for (int a = 0; a < 3; a++) {
-                        bx[a] = std::min(v[a], std::min(v[3 + a], v[6 + a]));
-                        bx[3 + a] = std::max(v[a], std::max(v[3 + a], v[6 + a]));
+            // permute triangles into primitive_indices order (mod.rs:38-43); the entries are independent, so a large
+            // BLAS is filled by every core
+            {
+                const size_t np = bvh.primitive_indices.size();
+                const size_t t0i = tri_out.size(), s0i = tri_source.size(), b0i = box_out.size();
+                tri_out.resize(t0i + np * 9);
+                tri_source.resize(s0i + np);
+                box_out.resize(b0i + np * 6);
+                auto fill = [&](size_t k0, size_t k1) {
+                    for (size_t k = k0; k < k1; k++) {
+                        const uint32_t pi = bvh.primitive_indices[k];
+                        const float *v = verts + (first + pi) * 9;
+                        std::memcpy(&tri_out[t0i + k * 9], v, 36);
+                        tri_source[s0i + k] = (uint32_t)(first + pi);
+                        // the box this entry was built with: the triangle's own, or its clipped part after pre-splitting
+                        float *bx = &box_out[b0i + k * 6];
+                        if (!bvh.primitive_boxes.empty()) {
+                            for (int a = 0; a < 3; a++) { bx[a] = bvh.primitive_boxes[k].mn[a]; bx[3 + a] = bvh.primitive_boxes[k].mx[a]; }
+                        } else {
+                            for (int a = 0; a < 3; a++) {
+                                bx[a] = std::min(v[a], std::min(v[3 + a], v[6 + a]));
+                                bx[3 + a] = std::max(v[a], std::max(v[3 + a], v[6 + a]));
+                            }
+                        }
                     }
+                };
+                const int nt = (int)std::min<size_t>((size_t)std::max(1, threads > 0 ? threads : usable_threads()), np / 65536 + 1);
+                if (nt <= 1) {
+                    fill(0, np);
+                } else {
+                    std::vector<std::thread> pool;
+                    for (int t = 0; t < nt; t++) pool.emplace_back(fill, np * t / nt, np * (t + 1) / nt);
+                    for (auto &th : pool) th.join();
                 }
-                box_out.insert(box_out.end(), bx, bx + 6);
             }
             // global triangle buffer: offset primitive_base_idx (mod.rs:44-48)
             for (CwbvhNode &n : bvh.nodes) n.primitive_base_idx += tri_offset;
