@@ -622,12 +622,13 @@ def test_fixed_seed_slice_of_the_fuzzer(trx, orc):
     assert cases == 40 and not failures, failures[:3]
 
 
-@pytest.mark.parametrize("world,streams,batch", [(2, 2, 4), (8, 8, 8)])
+@pytest.mark.parametrize("world,streams,batch", [(2, 2, 4), (4, 8, 8)])
 def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path, world, streams, batch):
     """bench.py's N > 1 path end to end on one GPU: `world` ranks (gloo, shard gather staged through
     host memory) trace their tile shards on device 0 in batches; the frame rank 0 ends up with is
-    checked against the oracle here.  world = 8 with bench.py's own defaults for 8 GPUs (8 streams, 8 frames per
-    gather) is the geometry the driver's scaling run uses."""
+    checked against the oracle here.  world = 4 runs bench.py's own defaults for more than two GPUs (8 streams, 8
+    frames per gather); more ranks than that cannot share one GPU box: its process guard allows 6 processes on the
+    card, and this test process is one of them."""
     import json
     import socket
     import subprocess
