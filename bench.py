@@ -76,6 +76,17 @@ def usable_cores():
     return n
 
 
+def cpu_model():
+    """Host CPU as /proc/cpuinfo names it (the cpu_baseline leg says what it was timed on)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -404,6 +415,27 @@ def main():
             }
             dscene.close()
             del dv, dc, dflat
+        # (i) the same frame over a tree from the ploc_cwbvh pipeline with the reference's command-line defaults for
+        #     BvhBuildParams (src/main.rs:85-124,571-585: search distance 14, depth threshold 2, 64-bit codes, reinsertion
+        #     0.15, 3 primitives per leaf) - obvhs' own values for the preset name are not in the reference tree, so the
+        #     headline runs this library's medium_build; this leg says what the other builder's tree costs to traverse
+        if args.scene == "bistro" and args.tris == 0:
+            tp0 = time.time()
+            pflat = T.flat_build_params(verts, counts, T.build_params(), use_tlas=False, threads=threads)
+            pbuild = time.time() - tp0
+            pscene = T.Scene(pflat, device=local_rank)
+            pst = pscene.count_primary(view, w, h, sem=args.sem)
+            pp = [pscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
+            legs["ploc_pipeline"] = {
+                "params": "reference command-line defaults (ploc_search_distance 14, search_depth_threshold 2, "
+                          "sort_precision 64, reinsertion_batch_ratio 0.15, max_prims_per_leaf 3)",
+                "build_seconds": round(pbuild, 2), "nodes": int(pflat.n_nodes),
+                "nodes_per_ray": round(pst.n_node / pst.n_rays, 2), "tris_per_ray": round(pst.n_tri / pst.n_rays, 2),
+                "min_ms": round(sum(q[0] for q in pp) / 3, 4), "mean_ms": round(sum(q[1] for q in pp) / 3, 4),
+                "mrays_at_mean": round(n_rays_total / (sum(q[1] for q in pp) / 3) / 1e3, 1),
+            }
+            pscene.close()
+            del pflat
         # (f) compulsory footprint: distinct nodes / triangles one frame touches
         fn, ft = scene.footprint(view, w, h, sem=args.sem)
         legs["footprint"] = {"nodes": fn, "tris": ft, "bytes": NODE_BYTES * fn + TRI_BYTES * ft + HIT_BYTES * n_rays_total}
@@ -576,6 +608,7 @@ def main():
             "value": round(n_rays_total * n_frames / secs / 1e6, 3),
             "unit": "Mrays/s",
             "cores": cores,
+            "cpu_model": cpu_model(),
             "kind": "port",
             "sample": "%d full %dx%d frame(s) of the same workload, %.1f s, OpenMP over 8x8 tiles" % (
                 n_frames, w, h, secs),

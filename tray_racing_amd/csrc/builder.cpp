@@ -590,11 +590,9 @@ struct Reinserter {
         parent[from] = p;
         nodes[p].box = nodes[to].box;
         grow(nodes[p].box, nodes[from].box);
-        // primitive counts stay exact (the re-layout needs them): the old path loses `from`, the new gains it
-        const uint32_t moved_prims = nodes[from].count;
-        nodes[p].count = nodes[to].count + moved_prims;
-        for (uint32_t a = g; a != kNone; a = parent[a]) nodes[a].count -= moved_prims;
-        for (uint32_t a = tp; a != kNone; a = parent[a]) nodes[a].count += moved_prims;
+        // Primitive counts are NOT kept up to date while nodes move: the searches only ask whether a node is a leaf
+        // (count == 1, which no move changes; an inner node's stale count stays >= 2), and walking both root paths for
+        // every move was a third of the sequential part of a batch.  recount() restores them once, for the re-layout.
         refit_up(g);
         refit_up(tp);
     }
@@ -609,7 +607,7 @@ struct Reinserter {
         if (n < 8 || batch_ratio <= 0.f) return 0;
         static const size_t kBatch = getenv("TRX_REINSERT_BATCH") ? (size_t)atoi(getenv("TRX_REINSERT_BATCH")) : 128;
         threads = std::max(1, std::min(threads, std::min(usable_threads(), 32))); // the workers spin between batches: never more than the cores
-        BigVec<std::pair<float, uint32_t>> cand;
+        BigVec<Cand> cand, cand_tmp;
         std::vector<uint32_t> found(kBatch);
         std::vector<uint32_t> touched_at(n, 0u); // batch stamp of the last move that re-linked this node
         uint32_t stamp = 0;
@@ -645,15 +643,7 @@ struct Reinserter {
             });
         Scratch scratch;
         for (int it = 0; it < iterations; it++) {
-            cand.clear();
-            for (uint32_t i = 1; i < n; i++)
-                if (parent[i] != 0) cand.emplace_back(half_area(nodes[i].box), i);
-            const size_t take = std::min(cand.size(), (size_t)std::max(1.0, (double)n * batch_ratio));
-            auto larger = [](const std::pair<float, uint32_t> &a, const std::pair<float, uint32_t> &b) {
-                return a.first > b.first || (a.first == b.first && a.second < b.second);
-            };
-            if (take < cand.size()) std::nth_element(cand.begin(), cand.begin() + take, cand.end(), larger);
-            std::sort(cand.begin(), cand.begin() + take, larger);
+            const size_t take = select_candidates(cand, cand_tmp, batch_ratio, threads);
             uint32_t moved_now = 0;
             for (size_t begin = 0; begin < take; begin += kBatch) {
                 sh.begin = begin;
@@ -699,17 +689,9 @@ struct Reinserter {
         const size_t n = nodes.size();
         uint32_t moved = 0;
         if (n < 8 || batch_ratio <= 0.f) return 0;
-        BigVec<std::pair<float, uint32_t>> cand;
+        BigVec<Cand> cand, cand_tmp;
         for (int it = 0; it < iterations; it++) {
-            cand.clear();
-            for (uint32_t i = 1; i < n; i++)
-                if (parent[i] != 0) cand.emplace_back(half_area(nodes[i].box), i);
-            size_t take = std::min(cand.size(), (size_t)std::max(1.0, (double)n * batch_ratio));
-            auto larger = [](const std::pair<float, uint32_t> &a, const std::pair<float, uint32_t> &b) {
-                return a.first > b.first || (a.first == b.first && a.second < b.second);
-            };
-            if (take < cand.size()) std::nth_element(cand.begin(), cand.begin() + take, cand.end(), larger);
-            std::sort(cand.begin(), cand.begin() + take, larger);
+            const size_t take = select_candidates(cand, cand_tmp, batch_ratio, std::min(threads, usable_threads()));
             // one at a time, each search on the tree as the previous move left it (sequential: the searches
             // cost little next to the memory passes around them, and stale searches lose tree quality)
             uint32_t moved_now = 0;
@@ -729,7 +711,103 @@ struct Reinserter {
         return moved;
     }
 
-    void relayout(int threads) { relayout_dfs(nodes, 0u, threads); }
+    // exact primitive counts of every subtree, children before parents (iterative post-order from the root)
+    void recount() {
+        constexpr uint64_t kSecondVisit = 1ull << 32; // both children are done
+        std::vector<uint64_t> todo;
+        todo.push_back(0u);
+        while (!todo.empty()) {
+            const uint64_t e = todo.back();
+            todo.pop_back();
+            const uint32_t i = (uint32_t)e;
+            if (e & kSecondVisit) {
+                nodes[i].count = nodes[nodes[i].left].count + nodes[nodes[i].right].count;
+            } else if (nodes[i].count > 1) {
+                todo.push_back(kSecondVisit | i);
+                todo.push_back(nodes[i].right);
+                todo.push_back(nodes[i].left);
+            }
+        }
+    }
+    void relayout(int threads) {
+        recount();
+        relayout_dfs(nodes, 0u, threads);
+    }
+
+    // The `take` candidates of an iteration - the nodes with the largest area, largest first, ties by index - chosen
+    // and ordered on `threads` cores: the order is total, so the result is the sequential one whatever the thread count.
+    typedef std::pair<float, uint32_t> Cand;
+    static bool larger(const Cand &a, const Cand &b) { return a.first > b.first || (a.first == b.first && a.second < b.second); }
+    template <class F>
+    static void on_threads(int threads, F f) {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; t++) pool.emplace_back(f, t);
+        f(0);
+        for (auto &th : pool) th.join();
+    }
+    size_t select_candidates(BigVec<Cand> &cand, BigVec<Cand> &tmp, float batch_ratio, int threads) const {
+        const size_t n = nodes.size();
+        threads = std::max(1, std::min(threads, 64));
+        if (n < (size_t)1 << 16) threads = 1;
+        // every node but the root and its children, in index order
+        std::vector<size_t> first(threads + 1, 0);
+        auto range = [&](int t) { return std::make_pair(1 + (n - 1) * (size_t)t / threads, 1 + (n - 1) * (size_t)(t + 1) / threads); };
+        on_threads(threads, [&](int t) {
+            size_t c = 0;
+            for (size_t i = range(t).first; i < range(t).second; i++) c += parent[i] != 0;
+            first[t + 1] = c;
+        });
+        for (int t = 0; t < threads; t++) first[t + 1] += first[t];
+        cand.resize(first[threads]);
+        on_threads(threads, [&](int t) {
+            size_t w = first[t];
+            for (size_t i = range(t).first; i < range(t).second; i++)
+                if (parent[i] != 0) cand[w++] = Cand(half_area(nodes[i].box), (uint32_t)i);
+        });
+        const size_t take = std::min(cand.size(), (size_t)std::max(1.0, (double)n * batch_ratio));
+        if (take < cand.size()) std::nth_element(cand.begin(), cand.begin() + take, cand.end(), larger);
+        if (threads == 1 || take < (size_t)1 << 16) {
+            std::sort(cand.begin(), cand.begin() + take, larger);
+            return take;
+        }
+        // sample sort: splitters from an evenly spaced sample, one bucket per thread, buckets sorted concurrently
+        const int buckets = threads;
+        std::vector<Cand> sample;
+        const size_t per = 64, ns = per * (size_t)buckets;
+        for (size_t k = 0; k < ns; k++) sample.push_back(cand[take * k / ns]);
+        std::sort(sample.begin(), sample.end(), larger);
+        std::vector<Cand> split;
+        for (int b = 1; b < buckets; b++) split.push_back(sample[per * (size_t)b]);
+        auto bucket_of = [&](const Cand &c) { // elements before the first splitter go to bucket 0, and so on
+            return (int)(std::upper_bound(split.begin(), split.end(), c, larger) - split.begin());
+        };
+        auto chunk = [&](int t) { return std::make_pair(take * (size_t)t / threads, take * (size_t)(t + 1) / threads); };
+        std::vector<size_t> counts((size_t)threads * buckets, 0);
+        on_threads(threads, [&](int t) {
+            size_t *c = &counts[(size_t)t * buckets];
+            for (size_t i = chunk(t).first; i < chunk(t).second; i++) c[bucket_of(cand[i])]++;
+        });
+        std::vector<size_t> offset((size_t)threads * buckets, 0), bucket_begin(buckets + 1, 0);
+        size_t run = 0;
+        for (int b = 0; b < buckets; b++) {
+            bucket_begin[b] = run;
+            for (int t = 0; t < threads; t++) {
+                offset[(size_t)t * buckets + b] = run;
+                run += counts[(size_t)t * buckets + b];
+            }
+        }
+        bucket_begin[buckets] = run;
+        tmp.resize(take);
+        on_threads(threads, [&](int t) {
+            size_t *o = &offset[(size_t)t * buckets];
+            for (size_t i = chunk(t).first; i < chunk(t).second; i++) tmp[o[bucket_of(cand[i])]++] = cand[i];
+        });
+        on_threads(threads, [&](int t) {
+            std::sort(tmp.begin() + bucket_begin[t], tmp.begin() + bucket_begin[t + 1], larger);
+            std::copy(tmp.begin() + bucket_begin[t], tmp.begin() + bucket_begin[t + 1], cand.begin() + bucket_begin[t]);
+        });
+        return take;
+    }
 };
 
 // ---- BVH2 -> BVH8 collapse (Ylitie et al. 2017, section 4.2) ------------------
@@ -748,9 +826,47 @@ struct Collapser {
     Collapser(const BigVec<Node2> &nodes, const BuildParams &p, CwBvh &o)
         : n2(nodes), dec(nodes.size() * 7), params(p), out(o) {}
 
-    void compute_costs() {
+    // Subtrees of at most `grain` primitives met on the way down from the root, in pre-order (disjoint blocks of the
+    // pre-order array), and the nodes above them.
+    void split_top(uint32_t grain, std::vector<uint32_t> &subtrees, std::vector<uint32_t> &top) const {
+        std::vector<uint32_t> todo{0u};
+        while (!todo.empty()) {
+            const uint32_t ni = todo.back();
+            todo.pop_back();
+            if (n2[ni].count <= grain) {
+                subtrees.push_back(ni);
+                continue;
+            }
+            top.push_back(ni);
+            todo.push_back(n2[ni].right);
+            todo.push_back(n2[ni].left);
+        }
+    }
+
+    void compute_costs(int threads) {
+        if (threads <= 1 || n2.size() < ((size_t)1 << 16)) {
+            cost_range(0, n2.size());
+            return;
+        }
+        std::vector<uint32_t> subtrees, top;
+        split_top(std::max<uint32_t>(1024u, n2[0].count / (uint32_t)(threads * 16)), subtrees, top);
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t k = next.fetch_add(1); k < subtrees.size(); k = next.fetch_add(1))
+                cost_range(subtrees[k], (size_t)subtrees[k] + 2 * (size_t)n2[subtrees[k]].count - 1);
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+        std::sort(top.begin(), top.end());
+        for (size_t k = top.size(); k-- > 0;) cost_range(top[k], (size_t)top[k] + 1);
+    }
+
+    // the decisions of nodes [begin, end) of the pre-order array, last first; every child outside the range is done
+    void cost_range(size_t begin, size_t end) {
         // children have larger indices than their parent (pre-order layout)
-        for (size_t ni = n2.size(); ni-- > 0;) {
+        for (size_t ni = end; ni-- > begin;) {
             const Node2 &nd = n2[ni];
             Decision *d = &dec[ni * 7];
             float area = half_area(nd.box);
@@ -884,7 +1000,106 @@ struct Collapser {
         return e;
     }
 
-    void emit(uint32_t out_idx, uint32_t ni) {
+    // Where emit writes: the CwBvh itself, or the private buffers of a subtree task.
+    struct Sink {
+        std::vector<CwbvhNode> *nodes;
+        std::vector<uint32_t> *prims;
+    };
+    struct Task {
+        std::vector<CwbvhNode> nodes; // [0] the subtree's root, then its descendants in emission order
+        std::vector<uint32_t> prims;
+    };
+    const std::vector<uint32_t> *task_roots = nullptr; // sorted BVH2 indices of the subtrees emitted as tasks
+    std::vector<Task> *tasks = nullptr;
+
+    // The inner (CWBVH-node) children of the node that BVH2 node `ni` becomes, in slot order.
+    void inner_children(uint32_t ni, uint32_t *inner, int &n_inner) const {
+        uint32_t children[8];
+        int count = 0;
+        if (n2[ni].count == 1)
+            children[count++] = ni;
+        else
+            get_children(ni, 0, children, count);
+        Child slots[8];
+        order_children(n2[ni].box, children, count, slots);
+        n_inner = 0;
+        for (int s = 0; s < 8; s++)
+            if (slots[s].used && slots[s].inner) inner[n_inner++] = slots[s].n2;
+    }
+
+    // Emission on every core.  The layout emit() produces is sequential by construction (a node's children are
+    // allocated when it is visited, its primitives appended then), but a subtree's descendants and primitives end up
+    // contiguous, so: subtrees of bounded size are emitted privately and concurrently, with indices relative to their
+    // own start, and the sequential pass over the few nodes above them splices each one in where the recursion
+    // reaches it, shifting its child_base / primitive_base indices.  Byte-identical to the sequential emission.
+    void emit_all(int threads) {
+        out.nodes.resize(1);
+        Sink global{&out.nodes, &out.primitive_indices};
+        const uint32_t grain = std::max<uint32_t>(4096u, n2[0].count / (uint32_t)(std::max(threads, 1) * 16));
+        if (threads <= 1 || n2[0].count <= grain || n2.size() < ((size_t)1 << 16)) {
+            emit(global, 0, 0);
+            return;
+        }
+        std::vector<uint32_t> roots;
+        std::vector<uint32_t> todo{0u};
+        while (!todo.empty()) { // the collapsed tree from the root down to subtrees of at most `grain` primitives
+            const uint32_t ni = todo.back();
+            todo.pop_back();
+            if (n2[ni].count <= grain) {
+                roots.push_back(ni);
+                continue;
+            }
+            uint32_t inner[8];
+            int n_inner = 0;
+            inner_children(ni, inner, n_inner);
+            for (int k = 0; k < n_inner; k++) todo.push_back(inner[k]);
+        }
+        std::sort(roots.begin(), roots.end());
+        std::vector<Task> done(roots.size());
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t k = next.fetch_add(1); k < roots.size(); k = next.fetch_add(1)) {
+                Task &t = done[k];
+                t.nodes.resize(1);
+                Sink local{&t.nodes, &t.prims};
+                emit(local, 0, roots[k]);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+        task_roots = &roots;
+        tasks = &done;
+        emit(global, 0, 0);
+        task_roots = nullptr;
+        tasks = nullptr;
+    }
+
+    // Puts a finished subtree where the sequential emission would have written it: root at out_idx, descendants and
+    // primitives appended, indices shifted from the task's own numbering.
+    void splice(Sink sink, uint32_t out_idx, const Task &t) {
+        const uint32_t node_shift = (uint32_t)sink.nodes->size() - 1u; // task index j >= 1 lands at size + (j - 1)
+        const uint32_t prim_shift = (uint32_t)sink.prims->size();
+        const size_t at = sink.nodes->size();
+        sink.nodes->resize(at + t.nodes.size() - 1);
+        for (size_t j = 0; j < t.nodes.size(); j++) {
+            CwbvhNode nd = t.nodes[j];
+            nd.child_base_idx += node_shift;
+            nd.primitive_base_idx += prim_shift;
+            (*sink.nodes)[j == 0 ? out_idx : at + j - 1] = nd;
+        }
+        sink.prims->insert(sink.prims->end(), t.prims.begin(), t.prims.end());
+    }
+
+    void emit(Sink sink, uint32_t out_idx, uint32_t ni) {
+        if (task_roots && sink.nodes == &out.nodes) {
+            auto it = std::lower_bound(task_roots->begin(), task_roots->end(), ni);
+            if (it != task_roots->end() && *it == ni) {
+                splice(sink, out_idx, (*tasks)[(size_t)(it - task_roots->begin())]);
+                return;
+            }
+        }
         const Node2 &nd = n2[ni];
         uint32_t children[8];
         int count = 0;
@@ -895,8 +1110,8 @@ struct Collapser {
         Child slots[8];
         order_children(nd.box, children, count, slots);
 
-        uint32_t child_base = (uint32_t)out.nodes.size();
-        uint32_t prim_base = (uint32_t)out.primitive_indices.size();
+        uint32_t child_base = (uint32_t)sink.nodes->size();
+        uint32_t prim_base = (uint32_t)sink.prims->size();
 
         CwbvhNode node;
         std::memset(&node, 0, sizeof(node));
@@ -944,16 +1159,16 @@ struct Collapser {
                 static const uint8_t unary[4] = {0, 0x20, 0x60, 0xE0};
                 node.child_meta[s] = (uint8_t)(total_tris | unary[np]);
                 total_tris += np;
-                for (uint32_t p : prims) out.primitive_indices.push_back(p);
+                for (uint32_t p : prims) sink.prims->push_back(p);
             }
         }
-        out.nodes[out_idx] = node;
+        (*sink.nodes)[out_idx] = node;
         // inner children are stored contiguously in slot order
-        out.nodes.resize(out.nodes.size() + n_inner);
+        sink.nodes->resize(sink.nodes->size() + n_inner);
         uint32_t k = 0;
         for (int s = 0; s < 8; s++) {
             if (slots[s].used && slots[s].inner) {
-                emit(child_base + k, slots[s].n2);
+                emit(sink, child_base + k, slots[s].n2);
                 k++;
             }
         }
@@ -1026,15 +1241,14 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
     }
 
     Collapser col(b2.nodes, params, out);
-    col.compute_costs();
+    col.compute_costs(threads);
     lap("collapse dp");
     out.sah_cost = col.dec[0].cost / std::max(half_area(b2.nodes[0].box), 1e-30f);
     if (verbose) fprintf(stderr, "[trx build] n=%llu sah8=%.3f\n", (unsigned long long)n, out.sah_cost);
     if (b2.nodes[0].count > 1) col.dec[0].type = kInternal; // the root is always a node
     out.nodes.reserve(n / 4 + 16);
     out.primitive_indices.reserve(n);
-    out.nodes.resize(1);
-    col.emit(0, 0);
+    col.emit_all(threads);
     lap("emit");
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
