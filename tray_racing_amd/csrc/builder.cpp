@@ -626,24 +626,27 @@ struct Reinserter {
             }
         };
         std::vector<std::thread> pool;
-        for (int t = 1; t < threads; t++)
-            pool.emplace_back([&]() {
-                Scratch scratch;
-                uint32_t seen = 0;
-                for (;;) {
-                    uint32_t g;
-                    while ((g = sh.generation.load(std::memory_order_acquire)) == seen) {
-                        if (sh.quit.load(std::memory_order_acquire)) return;
-                        std::this_thread::yield();
-                    }
-                    seen = g;
-                    search_some(scratch);
-                    sh.done.fetch_add(1, std::memory_order_acq_rel);
-                }
-            });
         Scratch scratch;
         for (int it = 0; it < iterations; it++) {
+            // (the workers spin between batches, so they only live while batches are searched: spinning beside the
+            // threads of the selection would burn the CPU quota a container grants)
             const size_t take = select_candidates(cand, cand_tmp, batch_ratio, threads);
+            sh.quit.store(false, std::memory_order_release);
+            for (int t = 1; t < threads; t++)
+                pool.emplace_back([&, start = sh.generation.load()]() {
+                    Scratch scratch;
+                    uint32_t seen = start;
+                    for (;;) {
+                        uint32_t g;
+                        while ((g = sh.generation.load(std::memory_order_acquire)) == seen) {
+                            if (sh.quit.load(std::memory_order_acquire)) return;
+                            std::this_thread::yield();
+                        }
+                        seen = g;
+                        search_some(scratch);
+                        sh.done.fetch_add(1, std::memory_order_acq_rel);
+                    }
+                });
             uint32_t moved_now = 0;
             for (size_t begin = 0; begin < take; begin += kBatch) {
                 sh.begin = begin;
@@ -676,11 +679,12 @@ struct Reinserter {
                     moved_now++;
                 }
             }
+            sh.quit.store(true, std::memory_order_release);
+            for (auto &th : pool) th.join();
+            pool.clear();
             moved += moved_now;
             if (moved_now == 0) break;
         }
-        sh.quit.store(true, std::memory_order_release);
-        for (auto &th : pool) th.join();
         if (moved) relayout(threads);
         return moved;
     }
