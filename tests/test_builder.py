@@ -92,6 +92,21 @@ def test_max_prims_per_leaf(trx, max_prims):
         trx.flat_build(verts, max_prims_per_leaf=4)
 
 
+def test_large_builds_take_the_parallel_paths_and_stay_deterministic(trx, orc):
+    """Above 65 536 BVH2 nodes the collapse and the emission run over subtrees concurrently and splice the results,
+    and above 65 536 reinsertion candidates the selection is a parallel sample sort (builder.cpp `emit_all`,
+    `compute_costs`, `select_candidates`): one thread and several must produce the same bytes, and a valid tree."""
+    verts, counts = trx.gen_scene("bistro", 240000, 1)
+    for build in (lambda t: trx.flat_build_params(verts, counts, trx.build_params(), threads=t),
+                  lambda t: trx.flat_build(verts, counts, preset="medium_build", threads=t),
+                  lambda t: trx.flat_build(verts, counts, preset="medium_build", split=0.3, threads=t)):
+        a, b = build(1), build(6)
+        assert a.n_nodes > 16000 and a.nodes.tobytes() == b.nodes.tobytes()
+        assert (a.tri_source == b.tri_source).all() and a.tri_verts.tobytes() == b.tri_verts.tobytes()
+        assert orc.Scene.from_flat(b).validate(boxes=b.tri_boxes) == (0, "")   # tri_boxes: entries of the pre-split build are clipped
+    trx.flat_build(verts[:4], preset="medium_build", split=0.0)   # process-wide settings back to their defaults
+
+
 def test_build_is_deterministic_across_thread_counts(trx):
     verts, counts = trx.gen_scene("kitchen", 30000, 1)
     a = trx.flat_build(verts, counts, threads=1)
