@@ -26,9 +26,6 @@
 #ifndef TRX_NODE_UNROLL
 #define TRX_NODE_UNROLL 2
 #endif
-#ifndef TRX_TRI_PAIRS
-#define TRX_TRI_PAIRS 0 // 1: per-lane triangle rounds test two triangles at once with packed f32 math (measured: no gain, +12 VGPRs)
-#endif
 
 #pragma clang fp contract(off)
 
@@ -183,35 +180,6 @@ __device__ __forceinline__ bool intersect_tri(const Ray &r, const float4 a, cons
     return false;
 }
 
-#if TRX_TRI_PAIRS
-// Two triangles against one ray with packed f32 math (v_pk_mul_f32 / v_pk_add_f32 are two IEEE operations
-// each): component k of every value is exactly what intersect_tri computes for triangle k.  Returns tt
-// (untested against t) and whether the barycentric / determinant test accepted it.
-__device__ __forceinline__ void intersect_tri2(const Ray &r, const float4 a0, const float4 b0, const float4 c0,
-                                               const float4 a1, const float4 b1, const float4 c1, f32x2 &tt, bool &ok0,
-                                               bool &ok1) {
-    const f32x2 e1x = {b0.x, b1.x}, e1y = {b0.y, b1.y}, e1z = {b0.z, b1.z};
-    const f32x2 e2x = {c0.x, c1.x}, e2y = {c0.y, c1.y}, e2z = {c0.z, c1.z};
-    const f32x2 ngx = {a0.w, a1.w}, ngy = {b0.w, b1.w}, ngz = {c0.w, c1.w};
-    const f32x2 ox = {r.ox, r.ox}, oy = {r.oy, r.oy}, oz = {r.oz, r.oz};
-    const f32x2 dx = {r.dx, r.dx}, dy = {r.dy, r.dy}, dz = {r.dz, r.dz};
-    const f32x2 cx = f32x2{a0.x, a1.x} - ox, cy = f32x2{a0.y, a1.y} - oy, cz = f32x2{a0.z, a1.z} - oz;
-    const f32x2 rx = dy * cz - dz * cy;
-    const f32x2 ry = dz * cx - dx * cz;
-    const f32x2 rz = dx * cy - dy * cx;
-    const f32x2 det = (ngx * dx + ngy * dy) + ngz * dz;
-    const f32x2 inv_det = {1.0f / det.x, 1.0f / det.y};
-    const f32x2 u = ((rx * e2x + ry * e2y) + rz * e2z) * inv_det;
-    const f32x2 v = ((rx * e1x + ry * e1y) + rz * e1z) * inv_det;
-    const f32x2 one = {1.0f, 1.0f};
-    const f32x2 w = one - u - v;
-    tt = ((ngx * cx + ngy * cy) + ngz * cz) * inv_det;
-    const uint32_t h0 = __float_as_uint(u.x) | __float_as_uint(v.x) | __float_as_uint(w.x);
-    const uint32_t h1 = __float_as_uint(u.y) | __float_as_uint(v.y) | __float_as_uint(w.y);
-    ok0 = inv_det.x != 0.0f && (h0 & 0x80000000u) == 0;
-    ok1 = inv_det.y != 0.0f && (h1 & 0x80000000u) == 0;
-}
-#endif
 
 __device__ __forceinline__ void finish_ray_dir(Ray &r, float dx, float dy, float dz) {
     r.dx = dx == 0.0f ? TRX_F32_EPSILON : dx;
@@ -708,39 +676,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     coop = mx > P.tri_coop_ratio * ((total + 63u) >> 6);
                 }
                 if (!coop) {
-#if TRX_TRI_PAIRS
-                    // per-lane rounds, two triangles at a time (highest bit first, committed in that order)
-                    while (tri.y != 0u) {
-                        const uint32_t l0 = 31u - (uint32_t)__clz((int)tri.y);
-                        tri.y &= ~(1u << l0);
-                        const bool two = tri.y != 0u;
-                        const uint32_t l1 = two ? 31u - (uint32_t)__clz((int)tri.y) : l0;
-                        tri.y &= ~(1u << l1);
-                        const uint32_t g0 = tri.x + l0, g1 = tri.x + l1;
-                        const float4 *tp0 = P.tris + (size_t)g0 * 3, *tp1 = P.tris + (size_t)g1 * 3;
-                        float4 a0 = tp0[0], b0 = tp0[1], c0 = tp0[2], a1 = tp1[0], b1 = tp1[1], c1 = tp1[2];
-                        asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w), "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(c0.x), "+v"(c0.y), "+v"(c0.z), "+v"(c0.w));
-                        asm volatile("" : "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w), "+v"(c1.x), "+v"(c1.y), "+v"(c1.z), "+v"(c1.w));
-                        if (COUNT) {
-                            c_tri += two ? 2u : 1u;
-                            if (lane_rank(__ballot(1)) == 0) c_wtri++;
-                            if (P.touch_tris) P.touch_tris[g0] = P.touch_tris[g1] = 1;
-                        }
-                        f32x2 tt;
-                        bool ok0, ok1;
-                        intersect_tri2(r, a0, b0, c0, a1, b1, c1, tt, ok0, ok1);
-                        if (ok0 && tt.x >= r.tmin && (tie_first ? (tt.x < t) : (tt.x <= t))) {
-                            t = tt.x;
-                            prim = g0;
-                            if (TLAS) hit_inst = cur_inst;
-                        }
-                        if (two && ok1 && tt.y >= r.tmin && (tie_first ? (tt.y < t) : (tt.y <= t))) {
-                            t = tt.y;
-                            prim = g1;
-                            if (TLAS) hit_inst = cur_inst;
-                        }
-                    }
-#else
                     while (tri.y != 0u) {
                         const uint32_t local = 31u - (uint32_t)__builtin_clz(tri.y); // tri.y != 0
                         tri.y &= ~(1u << local);
@@ -760,7 +695,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             if (TLAS) hit_inst = cur_inst;
                         }
                     }
-#endif
                 } else {
                     const uint32_t excl = incl - cnt;
                     lds_grp[lane] = tri;
