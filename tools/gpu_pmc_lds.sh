@@ -15,7 +15,8 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if "k_trace" not in row["Kernel_Name"]:
             continue
-        c = tot.setdefault((row["Kernel_Name"].split("(")[0][-40:], row["Counter_Name"]), [0.0, 0])
+        import re
+        c = tot.setdefault((re.search(r"k_trace<[^>]*>", row["Kernel_Name"]).group(0), row["Counter_Name"]), [0.0, 0])
         c[0] += float(row["Counter_Value"]); c[1] += 1
 for (k, n), (s, c) in sorted(tot.items()):
     print("PMC_LDS %s %s %s per launch %.4g (%d launches)" % (sys.argv[2], k, n, s / c, c))
