@@ -1,0 +1,79 @@
+"""The bench line's contract, checked on the committed line of the round (profiles/r02_bench_default.json is the
+verbatim output of `python bench.py` on the GPU box) and on bench.py's own argument defaults: the keys the driver
+reads, BASELINE.json's metric spelled exactly, the roofline and cpu_baseline objects, and the internal consistency
+the review asked for (kernel time x steps ~ timed region, fractions below 1 where they must be)."""
+import importlib.util
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def line():
+    path = os.path.join(ROOT, "profiles", "r02_bench_default.json")
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+def test_driver_keys_and_metric(line):
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert line["metric"] == base["metric"] and line["unit"] == "Mrays/s"
+    for key, typ in [("value", float), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)]:
+        assert isinstance(line[key], typ), key
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["scaling"] in ("weak", "strong")
+    assert line["vs_baseline"] is None and base["published"] == {}      # no published number for this metric
+    assert line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+    assert "configs[2]" in line["config"]["workload"] and line["dtype"] == "f32"
+
+
+def test_value_is_the_one_frame_in_flight_metric(line):
+    rays = 1920 * 1080
+    assert line["config"]["frames_in_flight"] == 1 and line["config"]["frames_per_launch"] == 1
+    assert line["value"] == pytest.approx(rays / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+    # hipEvent time per launch x steps accounts for the timed region (launch gaps are the rest)
+    assert 0.95 < line["kernel_ms_mean"] * line["steps"] / line["timed_region_ms"] <= 1.0
+    assert line["kernel_ms_min"] <= line["kernel_ms_mean"] <= line["ms_per_step"]
+    assert line["parity_vs_oracle_full_frame"] is True
+
+
+def test_roofline_objects(line):
+    r = line["roofline"]
+    assert r["bound"] == "valu" and r["unit"] == "Ginstr/s" and r["source"].startswith("live")
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3) and 0 < r["frac"] < 1
+    assert r["achieved"] == pytest.approx(r["valu_wave_insts_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-3)
+    assert 0 < r["issue_stage"]["frac"] < 1 and r["traffic"] > 0
+    h = line["roofline_hbm"]
+    assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["peak"] == 8000.0
+    per_ray = 80 * h["nodes_per_ray"] + 48 * h["tris_per_ray"] + 8       # algorithmic bytes per ray
+    assert h["bytes_per_launch"] == pytest.approx(per_ray * 1920 * 1080, rel=1e-3)
+    assert h["achieved"] == pytest.approx(h["bytes_per_launch"] / (line["kernel_ms_mean"] * 1e-3) / 1e9, rel=1e-3)
+    assert h["traffic"] < 0.1 * h["bytes_per_launch"]                    # served by the caches, not HBM
+    assert h["compulsory_bytes"] < h["traffic"] * 4 and h["peak_measured"] > 3000
+
+
+def test_cpu_baseline_and_legs(line):
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["cores"] >= 1 and c["value"] > 0
+    assert "frame" in c["sample"] and c["cpu_model"]
+    legs = line["legs"]
+    assert legs["reference_protocol"]["passes"] == 3 and legs["reference_protocol"]["frames"] >= 20
+    assert legs["cold_order_ms"]["mean"] > line["kernel_ms_mean"]         # the learnt order is what the steady state gains
+    assert legs["moving_camera_ms"]["mean"] < legs["cold_order_ms"]["mean"]
+    assert legs["ploc_pipeline"]["nodes_per_ray"] > 0 and legs["dense_scene"]["nodes_per_ray"] > 25
+
+
+def test_default_arguments_finish_in_minutes():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import sys
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        a = mod.parse()
+    finally:
+        sys.argv = argv
+    assert a.gpus == 1 and a.steps * 0.5e-3 < 5 and a.warmup < a.steps and a.cpu_seconds <= 30
+    assert mod.baseline_metric() == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
