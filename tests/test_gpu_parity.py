@@ -390,6 +390,35 @@ def test_device_pointers_streams_and_runner(trx, orc):
     assert ms > 0 and blas_s >= 0 and tlas_ms >= 0
 
 
+def test_bench_primary_times_what_hip_events_around_the_same_launches_see(trx, orc):
+    """trx_bench_primary (the reference's timing loop: a warm-up dispatch, then a timestamp pair per frame, min and mean,
+    src/rt_gpu/rt_gpu_software.rs:289-302,339-344,376) against an independent measurement: torch events on the stream
+    around trx_trace_primary_dev launches of the same frame.  Same kernel, same tile-order state: the two agree."""
+    import torch
+    w, h = 1920, 1080
+    flat, view, osc, ov = make_scene(trx, orc, "kitchen", 56939, w, h)
+    sc = trx.Scene(flat)
+    try:
+        mn, mean = sc.bench_primary(view, w, h, sem=3, warmup=6, frames=30)
+        assert 0 < mn <= mean < 1.5 * mn and 0.05 < mn < 5.0          # a 1080p kitchen-class frame is a fraction of a ms
+        out = torch.empty(w * h, dtype=torch.int64, device="cuda")
+        evs = []
+        for k in range(36):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            sc.trace_primary_dev(view, w, h, out.data_ptr(), sem=3)
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs[6:])
+        assert ts[0] == pytest.approx(mn, rel=0.15) and sum(ts) / len(ts) == pytest.approx(mean, rel=0.25)
+        # and fewer frames or no warm-up only change the statistics, not the order of magnitude
+        mn1, mean1 = sc.bench_primary(view, w, h, sem=3, warmup=0, frames=3)
+        assert mn1 == pytest.approx(mn, rel=0.3) and mn1 <= mean1
+    finally:
+        sc.close()
+
+
 # ---- BASELINE.json sizes ------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("name,w,h,tlas", [("kitchen", 1920, 1080, False), ("bistro", 1920, 1080, False)])
