@@ -347,6 +347,12 @@ int trx_trace_occluded(trx_scene *scene, const trx_ray *rays, uint64_t n_rays, u
  * triangle (with pre-splitting several entries can name the same one). */
 int trx_traverse1(trx_scene *scene, const trx_ray *ray, uint32_t semantics,
                   trx_rayhit *out);
+/* The same answer for n rays in ONE launch: what rt_cpu::start's pixel loop (src/rt_cpu/rt_cpu.rs:35-92) should call
+ * instead of n device round trips - generate the frame's rays, traverse them here, shade from the RayHits (which
+ * carry geometry_id / instance_id exactly like trx_traverse1's).  Host buffers; out_ms (may be NULL) is the hipEvent
+ * time of the traversal. */
+int trx_traverse_batch(trx_scene *scene, const trx_ray *rays, uint64_t n_rays, uint32_t semantics,
+                       trx_rayhit *out, float *out_ms);
 
 /* Benchmark loop of the reference (warm-up dispatch + timestamp pair per
  * frame, min and mean over frames: src/rt_gpu/rt_gpu_software.rs:289-302,

@@ -101,6 +101,13 @@ def test_traversable_surface_with_instances(trx, orc):
         assert np.float32(h.t) == want["t"][i] and h.instance_id == winst[i]
         b = offs.index(int(flat.instance_offsets[winst[i]]))
         assert h.geometry_id == b and h.primitive_id == want["prim"][i] - flat.blas_tri_start[b]
+    # the batch form answers every ray exactly as the single-ray form does, in one launch
+    got, ms = sc.traverse_batch(rays, sem=3)
+    assert ms > 0 and got.shape[0] == rays.shape[0]
+    for i in range(rays.shape[0]):
+        h = sc.traverse(rays["origin"][i], rays["direction"][i], sem=3)
+        assert (got["primitive_id"][i], got["geometry_id"][i], got["instance_id"][i]) == (h.primitive_id, h.geometry_id, h.instance_id)
+        assert got["t"][i : i + 1].view(np.uint32)[0] == np.float32(h.t).view(np.uint32)
     for k in (0, 3, 9):
         assert np.array_equal(sc.instance_transform(k), flat.instance_transforms[k])
     with pytest.raises(trx.TrxError):

@@ -390,6 +390,31 @@ def test_device_pointers_streams_and_runner(trx, orc):
     assert ms > 0 and blas_s >= 0 and tlas_ms >= 0
 
 
+def test_traverse_batch_is_traverse_for_every_ray(trx, orc):
+    """trx_traverse_batch: obvhs RayHits (geometry_id, primitive_id local to the geometry, RayHit::none() for a miss) for
+    a whole frame of rays in one launch, against the oracle - two-level scene with geometry ranges, and a one-level
+    scene where geometry_id stays 0 and primitive_id is the global triangle."""
+    for tlas in (True, False):
+        flat, view, osc, ov = make_scene(trx, orc, "bistro", 12000, 48, 40, tlas=tlas)   # a street: some rays reach the sky
+        sc = trx.Scene(flat)
+        rays = osc.primary_rays(ov, 48, 40)
+        want, _ = osc.trace_rays(rays, sem=3)
+        got, ms = sc.traverse_batch(rays, sem=3)
+        miss = want["prim"] == 0xFFFFFFFF
+        assert miss.any() and (~miss).any() and ms > 0
+        assert (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+        assert (got["primitive_id"][miss] == 0xFFFFFFFF).all() and (got["geometry_id"][miss] == 0xFFFFFFFF).all()
+        if tlas:
+            g = np.searchsorted(flat.blas_tri_start, want["prim"][~miss], side="right") - 1
+            assert (got["geometry_id"][~miss] == g).all()
+            assert (got["primitive_id"][~miss] == want["prim"][~miss] - flat.blas_tri_start[g]).all()
+        else:
+            assert (got["geometry_id"][~miss] == 0).all() and (got["primitive_id"][~miss] == want["prim"][~miss]).all()
+        empty, _ = sc.traverse_batch(rays[:0], sem=3)
+        assert empty.shape[0] == 0
+        sc.close()
+
+
 def test_bench_primary_times_what_hip_events_around_the_same_launches_see(trx, orc):
     """trx_bench_primary (the reference's timing loop: a warm-up dispatch, then a timestamp pair per frame, min and mean,
     src/rt_gpu/rt_gpu_software.rs:289-302,339-344,376) against an independent measurement: torch events on the stream

@@ -1192,6 +1192,27 @@ int thread_ray_lane(int device, ThreadRayLane **out) {
 }
 } // namespace
 
+// {t, global triangle} (+ the TLAS primitive it was found in) as obvhs' RayHit: (geometry_id, primitive_id local to
+// that geometry) like src/cwbvh.rs:151-160 when the geometry ranges are known, RayHit::none() for a miss.
+static void to_rayhit(const trx_scene *s, const trx_hit h, uint32_t inst, trx_rayhit *out) {
+    out->t = h.t;
+    out->instance_id = 0xFFFFFFFFu;
+    if (h.prim == 0xFFFFFFFFu) { // RayHit::none()
+        out->primitive_id = out->geometry_id = 0xFFFFFFFFu;
+        return;
+    }
+    out->primitive_id = h.prim;
+    out->geometry_id = 0;
+    if (s->blas_tri_start.size() > 1) {
+        auto it = std::upper_bound(s->blas_tri_start.begin(), s->blas_tri_start.end(), h.prim);
+        uint32_t g = (uint32_t)(it - s->blas_tri_start.begin()) - 1;
+        out->geometry_id = g;
+        out->primitive_id = h.prim - s->blas_tri_start[g];
+        out->instance_id = g;
+    }
+    if (s->tlas) out->instance_id = inst; // the TLAS primitive the hit was found in
+}
+
 int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *out) {
     if (!s || !ray || !out) return fail(TRX_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(s->device));
@@ -1207,23 +1228,25 @@ int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *ou
     if (!rc && hipMemcpyAsync(&rec, lane->d_hit, s->tlas ? 12 : 8, hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "copy failed");
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "sync failed");
     if (rc) return rc;
-    const trx_hit h = rec.h;
-    out->t = h.t;
-    out->instance_id = 0xFFFFFFFFu;
-    if (h.prim == 0xFFFFFFFFu) { // RayHit::none()
-        out->primitive_id = out->geometry_id = 0xFFFFFFFFu;
-        return TRX_OK;
+    to_rayhit(s, rec.h, rec.inst, out);
+    return TRX_OK;
+}
+
+// Traversable::traverse for a batch: one launch, then the same {t, prim} -> RayHit mapping as trx_traverse1.
+int trx_traverse_batch(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t sem, trx_rayhit *out, float *out_ms) {
+    if (!s || (n && (!rays || !out))) return fail(TRX_ERR_INVALID, "null argument");
+    if (n == 0) return TRX_OK;
+    std::vector<trx_hit> hits;
+    std::vector<uint32_t> inst;
+    try {
+        hits.resize(n);
+        if (s->tlas) inst.resize(n);
+    } catch (const std::exception &) {
+        return fail(TRX_ERR_OOM, "host allocation failed");
     }
-    out->primitive_id = h.prim;
-    out->geometry_id = 0;
-    if (s->blas_tri_start.size() > 1) { // (geometry_id, local primitive_id) like src/cwbvh.rs:151-160
-        auto it = std::upper_bound(s->blas_tri_start.begin(), s->blas_tri_start.end(), h.prim);
-        uint32_t g = (uint32_t)(it - s->blas_tri_start.begin()) - 1;
-        out->geometry_id = g;
-        out->primitive_id = h.prim - s->blas_tri_start[g];
-        out->instance_id = g;
-    }
-    if (s->tlas) out->instance_id = rec.inst; // the TLAS primitive the hit was found in
+    int rc = trx_trace_rays_inst(s, rays, n, sem, hits.data(), s->tlas ? inst.data() : nullptr, out_ms);
+    if (rc) return rc;
+    for (uint64_t i = 0; i < n; i++) to_rayhit(s, hits[i], s->tlas ? inst[i] : 0xFFFFFFFFu, &out[i]);
     return TRX_OK;
 }
 

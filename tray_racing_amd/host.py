@@ -13,6 +13,7 @@ from . import _lib as L
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("prim", "<u4")])
 RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("tmin", "<f4"), ("direction", "<f4", 3), ("tmax", "<f4")])
+RAYHIT_DTYPE = np.dtype([("primitive_id", "<u4"), ("geometry_id", "<u4"), ("instance_id", "<u4"), ("t", "<f4")])  # obvhs RayHit
 MISS_PRIM = 0xFFFFFFFF
 
 
@@ -314,6 +315,14 @@ class Scene:
         out = L.RayHit()
         L.check(self._lib.trx_traverse1(self._h, C.byref(ray), sem, C.byref(out)))
         return out
+
+    def traverse_batch(self, rays, sem=L.SEM_HLSL):
+        """Traversable::traverse for a whole batch in one launch: (RAYHIT_DTYPE array, ms)."""
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        out = np.empty(rays.shape[0], dtype=RAYHIT_DTYPE)
+        ms = C.c_float()
+        L.check(self._lib.trx_traverse_batch(self._h, _ptr(rays), rays.shape[0], sem, _ptr(out), C.byref(ms)))
+        return out, ms.value
 
     def count_primary(self, view, width, height, sem=L.SEM_HLSL, shard=(0, 1)):
         st = L.Stats()
