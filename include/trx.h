@@ -374,6 +374,10 @@ int trx_debug_wave_timeline(trx_scene *scene, const trx_view *view, uint32_t wid
 int trx_debug_wave_phases(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
                           uint32_t semantics, uint64_t *out_records, uint32_t max_waves,
                           uint32_t *out_waves);
+/* The same 8-word records for the AO pass of the frame (frame 0, eps 0.01; its primary pass runs first, unrecorded). */
+int trx_debug_wave_timeline_ao(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                               uint32_t semantics, uint64_t *out_records, uint32_t max_waves,
+                               uint32_t *out_waves);
 
 /* Diagnostics (counting kernel): the compulsory footprint of one primary frame — how many distinct nodes were
  * fetched and distinct triangles tested (80 * nodes + 48 * tris + 8 * rays bytes). */
@@ -402,7 +406,9 @@ uint32_t trx_set_kernel_variant(uint32_t variant);
  * trx_shard{r, N, TRX_LAYOUT_SHARD} of every frame of a batch straight into its block of a gather buffer laid out
  * [N][m][R] (R = trx_shard_tiles(w, h, {0, N}) * 64 records, the same on every rank), ONE in-place all-gather per
  * batch completes the m frames on every rank, and trx_assemble_frames de-interleaves them into row-major frames.
- * RCCL (librccl.so) is loaded on first use; a single-GPU host never touches it. */
+ * RCCL (librccl.so) is loaded on first use; a single-GPU host never touches it.  The environment variable
+ * TRX_RCCL_LIBRARY, when set, names the library to load instead of the system's librccl.so; a library that cannot be
+ * loaded makes every trx_comm_* call return TRX_ERR_NO_DEVICE with the loader's message. */
 typedef struct trx_comm trx_comm;
 /* 128 opaque bytes (ncclUniqueId): produced on rank 0, handed to the other ranks by the host's own means. */
 int trx_comm_unique_id(void *out_id128);
@@ -414,6 +420,10 @@ int trx_comm_world_size(const trx_comm *comm); /* as the communicator reports it
  * d_flat holds world blocks of records_per_rank records, this rank's block (already written by its trace launches)
  * at rank * records_per_rank.  For a batch of m frames records_per_rank = m * R. */
 int trx_gather_shards(trx_comm *comm, trx_hit *d_flat, uint64_t records_per_rank, void *stream);
+/* The same gather to ONE rank (SURVEY 8(e)'s alternative: ncclSend / ncclRecv in one group): rank `root` receives the
+ * other ranks' blocks into d_flat, every other rank sends its own block and receives nothing, so a host that
+ * consumes the frames on one GPU moves 1/world of the all-gather's bytes.  Only the root may then assemble. */
+int trx_gather_shards_root(trx_comm *comm, trx_hit *d_flat, uint64_t records_per_rank, int root, void *stream);
 /* De-interleave a gathered [world][n_frames][records_per_frame] buffer into n_frames row-major width x height
  * frames (d_frames: n_frames * width * height records), enqueued on `stream`.  Needs no communicator: with
  * world == 1 it turns one shard-layout frame into an image-layout one. */

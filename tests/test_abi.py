@@ -199,9 +199,35 @@ def test_multi_gpu_entry_points_validate_their_arguments(trx):
     assert lib.trx_comm_create(ident, 0, 0, 0, C.byref(comm)) == -1
     assert lib.trx_comm_unique_id(None) == -1
     assert lib.trx_gather_shards(None, None, 64, None) == -1
+    assert lib.trx_gather_shards_root(None, None, 64, 0, None) == -1
     assert lib.trx_assemble_frames(None, 64, 8, 8, 1, 1, None, None) == -1
     assert lib.trx_comm_world_size(None) == 0
     lib.trx_comm_destroy(None)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """RCCL is loaded on first use; a host whose loader cannot find it gets TRX_ERR_NO_DEVICE and the loader's message
+    from every trx_comm_* call (the library once called dlerror() twice there and crashed in strlen(NULL)).  The loader's
+    answer is cached per process, hence the child process."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import tray_racing_amd as T\n"
+        "lib = T.load()\n"
+        "ident = (C.c_ubyte * 128)()\n"
+        "rc = lib.trx_comm_unique_id(ident)\n"
+        "msg = lib.trx_last_error()\n"
+        "comm = C.c_void_p()\n"
+        "rc2 = lib.trx_comm_create(ident, 0, 1, 0, C.byref(comm))\n"
+        "print(rc, rc2, msg.decode())\n" % ROOT)
+    env = dict(os.environ, TRX_RCCL_LIBRARY="/nonexistent/librccl-missing.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-600:]
+    rc, rc2, msg = out.stdout.strip().split(" ", 2)
+    assert int(rc) == -2 and int(rc2) == -2, out.stdout
+    assert "librccl.so not found" in msg and "librccl-missing.so" in msg
 
 
 def test_build_device_setter(trx, has_gpu):

@@ -125,12 +125,14 @@ SIGNATURES = {
     "trx_debug_footprint": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "trx_debug_tri_histogram": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P]),
     "trx_debug_wave_phases": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, _u32, C.POINTER(_u32)]),
+    "trx_debug_wave_timeline_ao": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, _u32, C.POINTER(_u32)]),
     "trx_shard_tiles": (_u32, [_u32, _u32, Shard]),
     "trx_comm_unique_id": (_i, [_P]),
     "trx_comm_create": (_i, [_P, _i, _i, _i, C.POINTER(_P)]),
     "trx_comm_destroy": (None, [_P]),
     "trx_comm_world_size": (_i, [_P]),
     "trx_gather_shards": (_i, [_P, _P, _u64, _P]),
+    "trx_gather_shards_root": (_i, [_P, _P, _u64, _i, _P]),
     "trx_assemble_frames": (_i, [_P, _u64, _u32, _u32, _u32, _u32, _P, _P]),
     "trx_bvh_build_tris": (_i, [_P, _u64, _u32, _i, C.POINTER(_P)]),
     "trx_bvh_build_aabbs": (_i, [_P, _u64, _u32, _i, C.POINTER(_P)]),

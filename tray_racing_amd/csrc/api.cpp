@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <new>
 #include <string>
@@ -311,6 +312,9 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     if (sem & ~7u) return fail(TRX_ERR_INVALID, "unknown semantics bits 0x%x", sem);
     HIP_TRY(hipSetDevice(s->device));
     std::lock_guard<std::mutex> lock(s->mu);
+    if (s->d_inst_xform && mode == kModeAo && !p.primary_inst)
+        return fail(TRX_ERR_INVALID, "this scene has instance transforms: the AO pass needs the primary pass's instance ids "
+                                     "(trx_trace_ao_inst_dev) to take the hit normal into world space");
     // A stream keeps its slot: its launches are ordered anyway, and the slot's tile-order feedback
     // stays with the caller's frame loop.  Otherwise take an unused slot, else the oldest one, and
     // make the stream wait for that slot's last kernel.
@@ -369,9 +373,6 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.inst = s->d_inst;
     p.inst_xform = s->d_inst_xform;
     p.tlas_start = s->tlas_start;
-    if (s->d_inst_xform && mode == kModeAo && !p.primary_inst)
-        return fail(TRX_ERR_INVALID, "this scene has instance transforms: the AO pass needs the primary pass's instance ids "
-                                     "(trx_trace_ao_inst_dev) to take the hit normal into world space");
     p.ctr = slot.ctr;
     p.spill = slot.spill;
     p.tie_first = (sem & TRX_SEM_TIE_FIRST) ? 1u : 0u;
@@ -449,7 +450,11 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         p.cost = s->dbg_cost;
         p.tile_iters = s->dbg_iters;
     }
-    HIP_TRY(launch_trace(p, mode, s->tlas, sem, count, grid, stream));
+    bool pipe = false;
+#ifdef TRX_DEV_TUNE
+    pipe = (p.tune & 0x1000u) != 0u;
+#endif
+    HIP_TRY(launch_trace(p, mode, s->tlas, sem, count, pipe, grid, stream));
     HIP_TRY(hipEventRecord(slot.done, stream));
     slot.used = true;
     if (ctr_out) *ctr_out = slot.ctr;
@@ -649,10 +654,23 @@ int trx_scene_set_instance_transforms(trx_scene *s, const float *object_to_world
     if (!s) return fail(TRX_ERR_INVALID, "null scene");
     std::lock_guard<std::recursive_mutex> host_lock(s->host_mu);
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipDeviceSynchronize()); // no kernel may be reading the table while it changes
+    // The new table is built and uploaded first, the pointer is swapped under the launch mutex (enqueue() reads it
+    // there, so no launch can pick up a table that is about to be freed), and the old table is freed only after
+    // every kernel enqueued before the swap has drained.
+    auto swap_table = [&](float4 *fresh) -> int {
+        float4 *old = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(s->mu);
+            old = s->d_inst_xform;
+            s->d_inst_xform = fresh;
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        if (old) (void)hipFree(old);
+        return TRX_OK;
+    };
     if (!object_to_world || n == 0) { // back to identity
-        if (s->d_inst_xform) (void)hipFree(s->d_inst_xform);
-        s->d_inst_xform = nullptr;
+        const int rc = swap_table(nullptr);
+        if (rc) return rc;
         s->inst_o2w.clear();
         s->inst_w2o.clear();
         return TRX_OK;
@@ -688,8 +706,8 @@ int trx_scene_set_instance_transforms(trx_scene *s, const float *object_to_world
         (void)hipFree(d);
         return fail(TRX_ERR_NO_DEVICE, "upload of the instance transforms failed: %s", hipGetErrorString(e));
     }
-    if (s->d_inst_xform) (void)hipFree(s->d_inst_xform);
-    s->d_inst_xform = d;
+    const int rc_swap = swap_table(d);
+    if (rc_swap) return rc_swap;
     s->inst_o2w.assign(object_to_world, object_to_world + (size_t)n * 16);
     s->inst_w2o.swap(w2o);
     return TRX_OK;
@@ -1316,7 +1334,7 @@ int trx_debug_tile_profile(trx_scene *s, const trx_view *view, uint32_t w, uint3
 // Diagnostics: per-wave records of one primary frame: [start, end] wall-clock stamps (100 MHz ticks) and, in
 // TRX_STAMPS builds, the shader cycles spent in {refill, node fetch, node test, triangle phase, pop} + loop trips.
 static int wave_records(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint64_t *out,
-                        uint32_t fields, uint32_t max_waves, uint32_t *out_waves) {
+                        uint32_t fields, uint32_t max_waves, uint32_t *out_waves, bool ao = false) {
     if (!s || !out || !out_waves) return fail(TRX_ERR_INVALID, "null argument");
     std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the shared scratch / events
     HIP_TRY(hipSetDevice(s->device));
@@ -1324,10 +1342,17 @@ static int wave_records(trx_scene *s, const trx_view *view, uint32_t w, uint32_t
     if (rc) return rc;
     const size_t n = (size_t)s->cu_count * 32;
     const size_t words = n * kWaveTimeStride;
+    if (ao) { // the AO pass is the one recorded: its input first, without records
+        rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, nullptr);
+        if (rc) return rc;
+    }
     HIP_TRY(hipDeviceSynchronize());
     if (!s->d_wave_times) HIP_TRY(hipMalloc(&s->d_wave_times, words * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(s->d_wave_times, 0, words * sizeof(unsigned long long)));
-    rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, nullptr);
+    if (ao)
+        rc = trx_trace_ao_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, 0u, 0.01f, s->d_scratch_a, s->d_scratch_b, nullptr);
+    else
+        rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, nullptr);
     hipError_t e = hipDeviceSynchronize();
     std::vector<unsigned long long> host(words);
     if (e == hipSuccess) e = hipMemcpy(host.data(), s->d_wave_times, words * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -1348,6 +1373,11 @@ static int wave_records(trx_scene *s, const trx_view *view, uint32_t w, uint32_t
 int trx_debug_wave_timeline(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem,
                             uint64_t *out_times, uint32_t max_waves, uint32_t *out_waves) {
     return wave_records(s, view, w, h, sem, out_times, 2, max_waves, out_waves);
+}
+
+int trx_debug_wave_timeline_ao(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem,
+                               uint64_t *out_records, uint32_t max_waves, uint32_t *out_waves) {
+    return wave_records(s, view, w, h, sem, out_records, (uint32_t)kWaveTimeStride, max_waves, out_waves, true);
 }
 
 int trx_debug_wave_phases(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem,
@@ -1576,7 +1606,9 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             const auto t0 = std::chrono::steady_clock::now();
             int nthreads = threads > 0 ? threads : usable_threads();
             if (nthreads < 1) nthreads = 1;
-            const uint64_t kSmall = 65536;
+            // objects the GPU stage would take (trx_set_build_device: >= kDevicePlocMinPrims primitives) are never
+            // handed to the one-thread host pool
+            const uint64_t kSmall = bp.ploc_device >= 0 ? std::min<uint64_t>(65536, kDevicePlocMinPrims - 1) : 65536;
             std::vector<size_t> small;
             for (size_t i = 0; i < counts.size(); i++) {
                 if (counts[i] > kSmall || counts.size() == 1 || nthreads == 1)
@@ -1589,7 +1621,8 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
                 one.threads = 1;
                 one.ploc_device = -1; // the many small BLASes of a TLAS scene stay on the host cores
                 std::atomic<size_t> next{0};
-                std::atomic<bool> failed{false};
+                std::mutex err_mu;
+                std::exception_ptr first_error; // rethrown as it was (a builder failure is not an allocation failure)
                 auto worker = [&]() {
                     try {
                         for (size_t k = next.fetch_add(1); k < small.size(); k = next.fetch_add(1)) {
@@ -1597,14 +1630,16 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
                             build_cwbvh_from_tris(verts + firsts[i] * 9, counts[i], one, built[i]);
                         }
                     } catch (...) {
-                        failed = true;
+                        std::lock_guard<std::mutex> g(err_mu);
+                        if (!first_error) first_error = std::current_exception();
+                        next.store(small.size()); // the other workers stop taking objects
                     }
                 };
                 std::vector<std::thread> pool;
                 const int n = (int)std::min<size_t>((size_t)nthreads, small.size());
                 for (int t = 0; t < n; t++) pool.emplace_back(worker);
                 for (auto &th : pool) th.join();
-                if (failed) throw std::bad_alloc();
+                if (first_error) std::rethrow_exception(first_error);
             }
             blas_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }

@@ -605,7 +605,7 @@ struct Reinserter {
         const size_t n = nodes.size();
         uint32_t moved = 0;
         if (n < 8 || batch_ratio <= 0.f) return 0;
-        static const size_t kBatch = getenv("TRX_REINSERT_BATCH") ? (size_t)atoi(getenv("TRX_REINSERT_BATCH")) : 128;
+        constexpr size_t kBatch = 128; // candidates searched against the same tree (2 048 is faster and loses a third of the gain)
         threads = std::max(1, std::min(threads, std::min(usable_threads(), 32))); // the workers spin between batches: never more than the cores
         BigVec<Cand> cand, cand_tmp;
         std::vector<uint32_t> found(kBatch);

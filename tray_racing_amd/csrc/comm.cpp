@@ -33,6 +33,9 @@ typedef int (*AllGatherFn)(const void *, void *, size_t, int /*ncclDataType_t*/,
 typedef int (*CommDestroyFn)(NcclComm);
 typedef const char *(*GetErrorStringFn)(int);
 typedef int (*CommCountFn)(NcclComm, int *);
+typedef int (*SendFn)(const void *, size_t, int, int, NcclComm, hipStream_t);
+typedef int (*RecvFn)(void *, size_t, int, int, NcclComm, hipStream_t);
+typedef int (*GroupFn)(void);
 
 struct Rccl {
     void *handle = nullptr;
@@ -42,6 +45,9 @@ struct Rccl {
     CommDestroyFn comm_destroy = nullptr;
     GetErrorStringFn get_error_string = nullptr;
     CommCountFn comm_count = nullptr;
+    SendFn send = nullptr;
+    RecvFn recv = nullptr;
+    GroupFn group_start = nullptr, group_end = nullptr;
     std::string error;
 };
 
@@ -49,12 +55,19 @@ Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (r.handle) break;
+        // TRX_RCCL_LIBRARY (documented in trx.h): the library to load instead of the system's librccl.so
+        const char *named = getenv("TRX_RCCL_LIBRARY");
+        if (named && *named) {
+            r.handle = dlopen(named, RTLD_NOW | RTLD_GLOBAL);
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (r.handle) break;
+            }
         }
         if (!r.handle) {
-            r.error = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+            const char *why = dlerror(); // one call: dlerror() clears the message it returns
+            r.error = std::string("librccl.so not found: ") + (why ? why : "no loader message");
             return;
         }
         r.get_unique_id = (GetUniqueIdFn)dlsym(r.handle, "ncclGetUniqueId");
@@ -63,6 +76,10 @@ Rccl &rccl() {
         r.comm_destroy = (CommDestroyFn)dlsym(r.handle, "ncclCommDestroy");
         r.get_error_string = (GetErrorStringFn)dlsym(r.handle, "ncclGetErrorString");
         r.comm_count = (CommCountFn)dlsym(r.handle, "ncclCommCount");
+        r.send = (SendFn)dlsym(r.handle, "ncclSend");
+        r.recv = (RecvFn)dlsym(r.handle, "ncclRecv");
+        r.group_start = (GroupFn)dlsym(r.handle, "ncclGroupStart");
+        r.group_end = (GroupFn)dlsym(r.handle, "ncclGroupEnd");
         if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy) r.error = "librccl.so lacks an expected symbol";
     });
     return r;
@@ -151,6 +168,30 @@ int trx_gather_shards(trx_comm *comm, trx_hit *d_flat, uint64_t records_per_rank
     const int rc = r.all_gather(d_flat + (uint64_t)comm->rank * records_per_rank, d_flat, (size_t)records_per_rank, kNcclInt64,
                                 comm->comm, (hipStream_t)stream);
     if (rc != 0) return trx::fail_msg(TRX_ERR_NO_DEVICE, "ncclAllGather: %s", r.get_error_string ? r.get_error_string(rc) : "error");
+    return TRX_OK;
+}
+
+int trx_gather_shards_root(trx_comm *comm, trx_hit *d_flat, uint64_t records_per_rank, int root, void *stream) {
+    if (!comm || !d_flat) return trx::fail_msg(TRX_ERR_INVALID, "null argument");
+    if (root < 0 || root >= comm->world) return trx::fail_msg(TRX_ERR_INVALID, "root %d of %d", root, comm->world);
+    if (records_per_rank == 0 || comm->world == 1) return TRX_OK; // the root's own block is already in place
+    Rccl &r = rccl();
+    if (!r.send || !r.recv || !r.group_start || !r.group_end)
+        return trx::fail_msg(TRX_ERR_NO_DEVICE, "librccl.so lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+    // every rank's block goes to the root over its own xGMI link (world - 1 point-to-point transfers in one group);
+    // the other ranks move 1/world of what the all-gather moves and receive nothing
+    int rc = r.group_start();
+    if (rc == 0) {
+        if (comm->rank == root) {
+            for (int src = 0; src < comm->world && rc == 0; src++)
+                if (src != root) rc = r.recv(d_flat + (uint64_t)src * records_per_rank, (size_t)records_per_rank, kNcclInt64, src, comm->comm, (hipStream_t)stream);
+        } else {
+            rc = r.send(d_flat + (uint64_t)comm->rank * records_per_rank, (size_t)records_per_rank, kNcclInt64, root, comm->comm, (hipStream_t)stream);
+        }
+        const int rc_end = r.group_end();
+        if (rc == 0) rc = rc_end;
+    }
+    if (rc != 0) return trx::fail_msg(TRX_ERR_NO_DEVICE, "ncclSend/ncclRecv: %s", r.get_error_string ? r.get_error_string(rc) : "error");
     return TRX_OK;
 }
 

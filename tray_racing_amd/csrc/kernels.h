@@ -109,8 +109,8 @@ struct TraceParams {
 // Resident waves the persistent kernel should be launched with on `device`.
 int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count);
 
-// Enqueues one traversal kernel.  sem: trx_semantics bits.
-hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, int grid,
+// Enqueues one traversal kernel.  sem: trx_semantics bits; pipe: the pipelined walk (BLAS-only scenes; ignored with a TLAS).
+hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, bool pipe, int grid,
                         hipStream_t stream);
 
 } // namespace trx

@@ -298,8 +298,13 @@ __device__ __forceinline__ void flush_pending(const TraceParams &P, const uint2 
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int MODE, bool TLAS, int NODE, bool COUNT>
+// PIPE (BLAS-only walks): the fetch of a ray's NEXT node is issued right after the node test that names it, before
+// the triangle phase of the node just tested, so the two memory round trips of a step overlap (the next node does
+// not depend on the triangles' results, only its test does: it reads the shrunken t).  A ray then occupies its lane
+// for one trip more (its last trip has triangle work only), which is why coherent, issue-bound frames do not want it.
+template <int MODE, bool TLAS, int NODE, bool PIPE, bool COUNT>
 __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceParams P) {
+    static_assert(!(PIPE && TLAS), "the pipelined walk is BLAS-only");
     // one stack region per wave of the workgroup; waves never synchronise with each other
     extern __shared__ float4 lds_dyn[];
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -335,6 +340,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint32_t cur_inst = TRX_INVALID, hit_inst = TRX_INVALID;
     float wox = 0.0f, woy = 0.0f, woz = 0.0f, wdx = 0.0f, wdy = 0.0f, wdz = 0.0f;
     uint2 cur = make_uint2(0u, 0u);
+    // pipelined walk: node in flight / fetched for this lane, and the triangle group its last node test left
+    bool fetched = false;
+    uint4 pn0 = make_uint4(0u, 0u, 0u, 0u), pn1 = pn0, pn2 = pn0, pn3 = pn0, pn4 = pn0;
+    uint2 ptri = make_uint2(0u, 0u);
     uint32_t overflow = 0; // sticky, set on the rare paths only (stack past its HBM part, step cap)
     // COUNT only
     uint32_t c_node = 0, c_tri = 0, c_rays = 0, c_hits = 0, c_maxsp = 0, c_over = 0;
@@ -748,151 +757,244 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 
 
 
-        for (;;) {
-            const bool act = has_ray;
-            uint2 tri = make_uint2(0u, 0u);
-            trip++;
-            if (act) {
-                // BLAS-only: a lane at the top of the loop always holds a node group (triangle groups are drained
-                // in the trip that found them; only the TLAS walk parks them on the stack)
-                if (!TLAS || (cur.y & 0xff000000u)) {
+
+        // Finished ray: the hit record (or the any-hit flag) leaves the lane.
+        auto finish_lane = [&]() {
+            if (MODE == kModeRays && P.any_hit != 0u) {
+                reinterpret_cast<uint8_t *>(P.out)[out_index] = prim != TRX_INVALID ? 1u : 0u;
+            } else {
+                trx_hit h;
+                h.t = prim != TRX_INVALID ? t : __builtin_inff();
+                h.prim = prim;
+                P.out[out_index] = h;
+            }
+            if (COUNT) {
+                c_rays++;
+                c_hits += prim != TRX_INVALID;
+            }
+            c_over += overflow;
+            has_ray = false;
+        };
+
+        if constexpr (!PIPE) {
+            for (;;) {
+                const bool act = has_ray;
+                uint2 tri = make_uint2(0u, 0u);
+                trip++;
+                if (act) {
+                    // BLAS-only: a lane at the top of the loop always holds a node group (triangle groups are drained
+                    // in the trip that found them; only the TLAS walk parks them on the stack)
+                    if (!TLAS || (cur.y & 0xff000000u)) {
+                        const uint32_t hits_imask = cur.y;
+                        const uint32_t child_bit = 31u - (uint32_t)__builtin_clz(hits_imask); // hits_imask != 0
+                        const uint32_t child_base = cur.x;
+                        cur.y &= ~(1u << child_bit);
+                        const uint32_t slot = (child_bit - 24u) ^ (r.oct_inv4 & 0xffu);
+                        const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
+                        uint32_t node_index = child_base + rel;
+                        if (TLAS) node_index += bvh_off;
+                        // (tried: when every lane wants the same node - 47 % of the wave-level steps on the bistro-class frame,
+                        // 90 % on the kitchen-class one - one copy through the scalar cache instead of 64 through the vector
+                        // path: no change in frame time)
+                        const uint4 *np = P.nodes + (size_t)node_index * 5;
+                        const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                        stack_push(cur, (cur.y & 0xff000000u) != 0u); // after the loads are on their way
+                        TRX_STAMP(k_fetch);
+                        if (COUNT) {
+                            c_node++;
+                            if (lane_rank(__ballot(1)) == 0) c_wnode++;
+                            if (P.touch_nodes) P.touch_nodes[node_index] = 1;
+    #ifdef TRX_DEV_TUNE
+                            if (P.tune & 0x100u) {
+                                // diagnostics: distinct nodes among the lanes of this wave-level node step
+                                unsigned long long todo = __ballot(1);
+                                const uint32_t first = (uint32_t)__ffsll((long long)todo) - 1u;
+                                uint32_t distinct = 0;
+                                while (todo) {
+                                    const uint32_t l = (uint32_t)__ffsll((long long)todo) - 1u;
+                                    const uint32_t v = (uint32_t)__shfl((int)node_index, (int)l);
+                                    todo &= ~__ballot(node_index == v);
+                                    distinct++;
+                                }
+                                if (lane == first) atomicAdd(&P.ctr->hist_total[min(distinct, 15u)], 1u);
+                            }
+    #endif
+                        }
+                        const uint32_t hitmask = node_intersect<NODE>(r, t, n0, n1, n2, n3, n4);
+                        cur.x = n1.x;
+                        tri.x = n1.y;
+                        cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                        tri.y = hitmask & 0x00ffffffu;
+    #ifdef TRX_DEV_TUNE
+                        if (P.tune & 2u) tri.y = 0u; // ablation (timing only, results wrong): no triangle phase at all
+    #endif
+                    } else {
+                        tri = cur;
+                        cur = make_uint2(0u, 0u);
+                    }
+                    if (TLAS && tlas_sp == TRX_INVALID && tri.y != 0u) {
+                        // a TLAS primitive is an instance (query_tlas.hlsl:410-446): enter its BLAS
+                        const uint32_t local = 31u - (uint32_t)__clz((int)tri.y);
+                        tri.y &= ~(1u << local);
+                        const uint32_t gidx = tri.x + local;
+                        stack_push(tri, tri.y != 0u);
+                        stack_push(cur, (cur.y & 0xff000000u) != 0u);
+                        tlas_sp = sp;
+                        bvh_off = P.inst[gidx];
+                        cur_inst = gidx;
+                        if (P.inst_xform) {
+                            // the ray in the instance's object space; the direction is not renormalised, so t keeps
+                            // its world-space meaning (the TODO at query_tlas.hlsl:433)
+                            const float4 *m = P.inst_xform + (size_t)gidx * 3;
+                            const float4 r0 = m[0], r1 = m[1], r2 = m[2];
+                            r.ox = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
+                            r.oy = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
+                            r.oz = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
+                            const float odx = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
+                            const float ody = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
+                            const float odz = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
+                            finish_ray_dir(r, odx, ody, odz);
+                            lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+                            lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+                        }
+                        cur = make_uint2(0u, 0x80000000u);
+                        tri.y = 0u;
+                    }
+                }
+
+                TRX_STAMP(k_test);
+                triangle_phase(tri);
+                TRX_STAMP(k_tri);
+    #ifdef TRX_STAMPS
+                k_iters++;
+    #endif
+                if (act) {
+                    // a lane whose node group is spent pops the next one, or is finished when its stack is empty
+                    const bool spent = (cur.y & 0xff000000u) == 0u;
+                    bool done = spent && sp == 0u;
+                    if (spent && sp != 0u) {
+                        if (TLAS && sp == tlas_sp) { // back to the TLAS (query_tlas.hlsl:480-486)
+                            tlas_sp = TRX_INVALID;
+                            bvh_off = P.tlas_start;
+                            cur_inst = TRX_INVALID;
+                            if (P.inst_xform) { // "Reset Ray to untransformed version" (query_tlas.hlsl:484)
+                                r.ox = wox; r.oy = woy; r.oz = woz;
+                                finish_ray_dir(r, wdx, wdy, wdz);
+                                lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+                                lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+                            }
+                        }
+                        cur = stack_pop();
+                        if (__builtin_expect(overflow != 0u, 0)) done = true; // past the last stack entry: the sentinel is not a group
+                    }
+                    // step cap (every wave reaches an exit whatever the tree): a ray's steps are bounded by the wave's
+                    // trips since it started; looked at once per 1024 trips, so the common trip pays nothing for it
+                    if (__builtin_expect((trip & 1023u) == 0u, 0)) {
+                        if (trip - steps > kMaxSteps) {
+                            overflow = 1u;
+                            done = true;
+                        }
+                    }
+                    // any-hit query (intersects_bl_bvh, query.hlsl:440-445): the first accepted triangle settles it.
+                    // Until a hit is accepted the walk is the closest-hit walk, so hit / no hit is the same answer.
+                    if (MODE == kModeRays && P.any_hit != 0u && prim != TRX_INVALID) done = true;
+                    if (done && MODE == kModeRays && P.any_hit != 0u) {
+                        reinterpret_cast<uint8_t *>(P.out)[out_index] = prim != TRX_INVALID ? 1u : 0u;
+                        if (COUNT) {
+                            c_rays++;
+                            c_hits += prim != TRX_INVALID;
+                        }
+                        c_over += overflow;
+                        has_ray = false;
+                    } else if (done) {
+                        trx_hit h;
+                        h.t = prim != TRX_INVALID ? t : __builtin_inff();
+                        h.prim = prim;
+                        P.out[out_index] = h;
+                        if (TLAS && P.out_inst) P.out_inst[out_index] = prim != TRX_INVALID ? hit_inst : TRX_INVALID;
+                        if (COUNT) {
+                            c_rays++;
+                            c_hits += prim != TRX_INVALID;
+                        }
+                        c_over += overflow;
+                        has_ray = false;
+                    }
+                }
+                const uint32_t alive = (uint32_t)__popcll(__ballot(has_ray));
+                TRX_STAMP(k_pop);
+                if (alive == 0u || (!exhausted && alive <= keep)) break;
+            }
+
+        } else {
+            // Pipelined walk (BLAS only).  Per trip: (1) lanes whose group names a next node issue its fetch and push
+            // the group's remainder; (2) the triangle phase of the node tested in the PREVIOUS trip runs under those
+            // loads; (3) rays with nothing left to fetch are finished (their last triangles are in); (4) the node test
+            // of the fetched node, with the t the triangles left, and the pop of a spent group.  Stack traffic, node
+            // order, triangle order and the t every test sees are those of the plain walk.
+            for (;;) {
+                const bool act = has_ray;
+                trip++;
+                // (1)
+                if (act && !fetched && (cur.y & 0xff000000u)) {
                     const uint32_t hits_imask = cur.y;
-                    const uint32_t child_bit = 31u - (uint32_t)__builtin_clz(hits_imask); // hits_imask != 0
+                    const uint32_t child_bit = 31u - (uint32_t)__builtin_clz(hits_imask);
                     const uint32_t child_base = cur.x;
                     cur.y &= ~(1u << child_bit);
                     const uint32_t slot = (child_bit - 24u) ^ (r.oct_inv4 & 0xffu);
                     const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
-                    uint32_t node_index = child_base + rel;
-                    if (TLAS) node_index += bvh_off;
-                    // (tried: when every lane wants the same node - 47 % of the wave-level steps on the bistro-class frame,
-                    // 90 % on the kitchen-class one - one copy through the scalar cache instead of 64 through the vector
-                    // path: no change in frame time)
+                    const uint32_t node_index = child_base + rel;
                     const uint4 *np = P.nodes + (size_t)node_index * 5;
-                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                    pn0 = np[0]; pn1 = np[1]; pn2 = np[2]; pn3 = np[3]; pn4 = np[4];
                     stack_push(cur, (cur.y & 0xff000000u) != 0u); // after the loads are on their way
-                    TRX_STAMP(k_fetch);
+                    fetched = true;
                     if (COUNT) {
                         c_node++;
                         if (lane_rank(__ballot(1)) == 0) c_wnode++;
                         if (P.touch_nodes) P.touch_nodes[node_index] = 1;
-#ifdef TRX_DEV_TUNE
-                        if (P.tune & 0x100u) {
-                            // diagnostics: distinct nodes among the lanes of this wave-level node step
-                            unsigned long long todo = __ballot(1);
-                            const uint32_t first = (uint32_t)__ffsll((long long)todo) - 1u;
-                            uint32_t distinct = 0;
-                            while (todo) {
-                                const uint32_t l = (uint32_t)__ffsll((long long)todo) - 1u;
-                                const uint32_t v = (uint32_t)__shfl((int)node_index, (int)l);
-                                todo &= ~__ballot(node_index == v);
-                                distinct++;
-                            }
-                            if (lane == first) atomicAdd(&P.ctr->hist_total[min(distinct, 15u)], 1u);
-                        }
-#endif
                     }
-                    const uint32_t hitmask = node_intersect<NODE>(r, t, n0, n1, n2, n3, n4);
-                    cur.x = n1.x;
-                    tri.x = n1.y;
-                    cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
-                    tri.y = hitmask & 0x00ffffffu;
-#ifdef TRX_DEV_TUNE
-                    if (P.tune & 2u) tri.y = 0u; // ablation (timing only, results wrong): no triangle phase at all
-#endif
-                } else {
-                    tri = cur;
-                    cur = make_uint2(0u, 0u);
                 }
-                if (TLAS && tlas_sp == TRX_INVALID && tri.y != 0u) {
-                    // a TLAS primitive is an instance (query_tlas.hlsl:410-446): enter its BLAS
-                    const uint32_t local = 31u - (uint32_t)__clz((int)tri.y);
-                    tri.y &= ~(1u << local);
-                    const uint32_t gidx = tri.x + local;
-                    stack_push(tri, tri.y != 0u);
-                    stack_push(cur, (cur.y & 0xff000000u) != 0u);
-                    tlas_sp = sp;
-                    bvh_off = P.inst[gidx];
-                    cur_inst = gidx;
-                    if (P.inst_xform) {
-                        // the ray in the instance's object space; the direction is not renormalised, so t keeps
-                        // its world-space meaning (the TODO at query_tlas.hlsl:433)
-                        const float4 *m = P.inst_xform + (size_t)gidx * 3;
-                        const float4 r0 = m[0], r1 = m[1], r2 = m[2];
-                        r.ox = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
-                        r.oy = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
-                        r.oz = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
-                        const float odx = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
-                        const float ody = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
-                        const float odz = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
-                        finish_ray_dir(r, odx, ody, odz);
-                        lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
-                        lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
-                    }
-                    cur = make_uint2(0u, 0x80000000u);
-                    tri.y = 0u;
-                }
-            }
-
-            TRX_STAMP(k_test);
-            triangle_phase(tri);
-            TRX_STAMP(k_tri);
+                TRX_STAMP(k_fetch);
+                // (2)
+                triangle_phase(ptri);
+                ptri = make_uint2(0u, 0u);
+                TRX_STAMP(k_tri);
 #ifdef TRX_STAMPS
-            k_iters++;
+                k_iters++;
 #endif
-            if (act) {
-                // a lane whose node group is spent pops the next one, or is finished when its stack is empty
-                const bool spent = (cur.y & 0xff000000u) == 0u;
-                bool done = spent && sp == 0u;
-                if (spent && sp != 0u) {
-                    if (TLAS && sp == tlas_sp) { // back to the TLAS (query_tlas.hlsl:480-486)
-                        tlas_sp = TRX_INVALID;
-                        bvh_off = P.tlas_start;
-                        cur_inst = TRX_INVALID;
-                        if (P.inst_xform) { // "Reset Ray to untransformed version" (query_tlas.hlsl:484)
-                            r.ox = wox; r.oy = woy; r.oz = woz;
-                            finish_ray_dir(r, wdx, wdy, wdz);
-                            lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
-                            lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+                // (3)
+                if (act) {
+                    bool done = !fetched; // no node left to visit, and the last node's triangles are in
+                    if (MODE == kModeRays && P.any_hit != 0u && prim != TRX_INVALID) done = true;
+                    if (__builtin_expect((trip & 1023u) == 0u, 0)) { // step cap: every wave reaches an exit
+                        if (trip - steps > kMaxSteps) {
+                            overflow = 1u;
+                            done = true;
                         }
                     }
-                    cur = stack_pop();
-                }
-                // step cap (every wave reaches an exit whatever the tree): a ray's steps are bounded by the wave's
-                // trips since it started; looked at once per 1024 trips, so the common trip pays nothing for it
-                if (__builtin_expect((trip & 1023u) == 0u, 0)) {
-                    if (trip - steps > kMaxSteps) {
-                        overflow = 1u;
-                        done = true;
+                    if (done) {
+                        fetched = false; // a fetch still in flight (any-hit, step cap) is simply not looked at
+                        finish_lane();
                     }
                 }
-                // any-hit query (intersects_bl_bvh, query.hlsl:440-445): the first accepted triangle settles it.
-                // Until a hit is accepted the walk is the closest-hit walk, so hit / no hit is the same answer.
-                if (MODE == kModeRays && P.any_hit != 0u && prim != TRX_INVALID) done = true;
-                if (done && MODE == kModeRays && P.any_hit != 0u) {
-                    reinterpret_cast<uint8_t *>(P.out)[out_index] = prim != TRX_INVALID ? 1u : 0u;
-                    if (COUNT) {
-                        c_rays++;
-                        c_hits += prim != TRX_INVALID;
+                const uint32_t alive = (uint32_t)__popcll(__ballot(has_ray));
+                const bool leave = alive == 0u || (!exhausted && alive <= keep);
+                TRX_STAMP(k_pop);
+                // (4)
+                if (fetched) {
+                    const uint32_t hitmask = node_intersect<NODE>(r, t, pn0, pn1, pn2, pn3, pn4);
+                    cur.x = pn1.x;
+                    ptri.x = pn1.y;
+                    cur.y = (hitmask & 0xff000000u) | (pn0.w >> 24);
+                    ptri.y = hitmask & 0x00ffffffu;
+                    fetched = false;
+                    if ((cur.y & 0xff000000u) == 0u && sp != 0u) {
+                        cur = stack_pop();
+                        if (__builtin_expect(overflow != 0u, 0)) cur = make_uint2(0u, 0u); // past the last entry: finish
                     }
-                    c_over += overflow;
-                    has_ray = false;
-                } else if (done) {
-                    trx_hit h;
-                    h.t = prim != TRX_INVALID ? t : __builtin_inff();
-                    h.prim = prim;
-                    P.out[out_index] = h;
-                    if (TLAS && P.out_inst) P.out_inst[out_index] = prim != TRX_INVALID ? hit_inst : TRX_INVALID;
-                    if (COUNT) {
-                        c_rays++;
-                        c_hits += prim != TRX_INVALID;
-                    }
-                    c_over += overflow;
-                    has_ray = false;
                 }
+                TRX_STAMP(k_test);
+                if (leave) break;
             }
-            const uint32_t alive = (uint32_t)__popcll(__ballot(has_ray));
-            TRX_STAMP(k_pop);
-            if (alive == 0u || (!exhausted && alive <= keep)) break;
         }
     }
 
@@ -928,39 +1030,43 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     }
 }
 
-template <int MODE, bool TLAS, int NODE, bool COUNT>
+template <int MODE, bool TLAS, int NODE, bool PIPE, bool COUNT>
 hipError_t launch_one(const TraceParams &p, int grid, hipStream_t stream) {
     // grid = total waves; p.waves_per_block waves share a workgroup (and nothing else)
     const int wpb = (int)p.waves_per_block;
     const size_t lds = (size_t)wpb * kLdsBytesPerWave;
-    hipLaunchKernelGGL((k_trace<MODE, TLAS, NODE, COUNT>), dim3(grid / wpb), dim3(kWave * wpb), lds, stream, p);
+    hipLaunchKernelGGL((k_trace<MODE, TLAS, NODE, PIPE, COUNT>), dim3(grid / wpb), dim3(kWave * wpb), lds, stream, p);
     return hipGetLastError();
 }
 
-template <int MODE, bool TLAS, bool COUNT>
+template <int MODE, bool TLAS, bool PIPE, bool COUNT>
 hipError_t launch_node(const TraceParams &p, int node, int grid, hipStream_t stream) {
     switch (node) {
-    case 0: return launch_one<MODE, TLAS, 0, COUNT>(p, grid, stream);
-    case 1: return launch_one<MODE, TLAS, 1, COUNT>(p, grid, stream);
-    case 2: return launch_one<MODE, TLAS, 2, COUNT>(p, grid, stream);
-    default: return launch_one<MODE, TLAS, 3, COUNT>(p, grid, stream);
+    case 0: return launch_one<MODE, TLAS, 0, PIPE, COUNT>(p, grid, stream);
+    case 1: return launch_one<MODE, TLAS, 1, PIPE, COUNT>(p, grid, stream);
+    case 2: return launch_one<MODE, TLAS, 2, PIPE, COUNT>(p, grid, stream);
+    default: return launch_one<MODE, TLAS, 3, PIPE, COUNT>(p, grid, stream);
     }
 }
 
 template <int MODE>
-hipError_t launch_mode(const TraceParams &p, bool tlas, int node, bool count, int grid, hipStream_t stream) {
-    if (tlas) {
-        if (count) return launch_node<MODE, true, true>(p, node, grid, stream);
-        return launch_node<MODE, true, false>(p, node, grid, stream);
+hipError_t launch_mode(const TraceParams &p, bool tlas, int node, bool count, bool pipe, int grid, hipStream_t stream) {
+    if (tlas) { // the two-level walk is not pipelined
+        if (count) return launch_node<MODE, true, false, true>(p, node, grid, stream);
+        return launch_node<MODE, true, false, false>(p, node, grid, stream);
     }
-    if (count) return launch_node<MODE, false, true>(p, node, grid, stream);
-    return launch_node<MODE, false, false>(p, node, grid, stream);
+    if (pipe) {
+        if (count) return launch_node<MODE, false, true, true>(p, node, grid, stream);
+        return launch_node<MODE, false, true, false>(p, node, grid, stream);
+    }
+    if (count) return launch_node<MODE, false, false, true>(p, node, grid, stream);
+    return launch_node<MODE, false, false, false>(p, node, grid, stream);
 }
 
-template <int MODE, bool TLAS, int NODE, bool COUNT>
+template <int MODE, bool TLAS, int NODE, bool PIPE, bool COUNT>
 int occupancy_one() {
     int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace<MODE, TLAS, NODE, COUNT>, kWave,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_trace<MODE, TLAS, NODE, PIPE, COUNT>, kWave,
                                                      kLdsBytesPerWave) != hipSuccess)
         return 0;
     return blocks;
@@ -979,19 +1085,19 @@ int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
     // occupancy of the variants is within one wave of each other; query one per TLAS flavour
-    int per_cu = tlas ? occupancy_one<kModePrimary, true, 1, false>() : occupancy_one<kModePrimary, false, 1, false>();
+    int per_cu = tlas ? occupancy_one<kModePrimary, true, 1, false, false>() : occupancy_one<kModePrimary, false, 1, false, false>();
     if (per_cu <= 0) per_cu = 8;
     if (per_cu > 32) per_cu = 32;
     return per_cu * prop.multiProcessorCount;
 }
 
-hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, int grid,
+hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, bool pipe, int grid,
                         hipStream_t stream) {
     const int node = node_variant(sem);
     switch (mode) {
-    case kModePrimary: return launch_mode<kModePrimary>(p, tlas, node, count, grid, stream);
-    case kModeAo: return launch_mode<kModeAo>(p, tlas, node, count, grid, stream);
-    case kModeRays: return launch_mode<kModeRays>(p, tlas, node, count, grid, stream);
+    case kModePrimary: return launch_mode<kModePrimary>(p, tlas, node, count, pipe, grid, stream);
+    case kModeAo: return launch_mode<kModeAo>(p, tlas, node, count, pipe, grid, stream);
+    case kModeRays: return launch_mode<kModeRays>(p, tlas, node, count, pipe, grid, stream);
     default: return hipErrorInvalidValue;
     }
 }
