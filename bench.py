@@ -603,10 +603,19 @@ def main():
         osc = O.Scene.from_flat(flat)
         ov = O.view_from_bytes(view)
         cores = usable_cores()
-        hits, ost = osc.trace_primary(ov, w, h, sem=args.sem, threads=cores)  # one full frame
-        n_frames, secs = 1, ost.seconds
+        # two implementations of the same restatement: the scalar one (the checker) and the one whose node test takes
+        # the eight children at once in AVX2 registers - the reference's CPU node test (obvhs) is SIMD as well, so that
+        # is the one `value` quotes; both produce the same bits (asserted here on the timed frame, and in tests/test_oracle.py)
+        O.set_simd(False)
+        hits, ost = osc.trace_primary(ov, w, h, sem=args.sem, threads=cores)  # one full frame, scalar
+        scalar_mrays = n_rays_total / ost.seconds / 1e6
+        simd = O.set_simd(True)
+        hits_simd, sst = osc.trace_primary(ov, w, h, sem=args.sem, threads=cores)
+        simd_equal = bool((hits_simd["t"].view(np.uint32) == hits["t"].view(np.uint32)).all() and
+                          (hits_simd["prim"] == hits["prim"]).all())
+        n_frames, secs = 1, sst.seconds
         while secs < args.cpu_seconds and n_frames < 64:
-            _, s2 = osc.trace_primary(ov, w, h, sem=args.sem, threads=cores, out=hits)
+            _, s2 = osc.trace_primary(ov, w, h, sem=args.sem, threads=cores, out=hits_simd)
             n_frames += 1
             secs += s2.seconds
         gpu = D.int64_to_hits(frame)
@@ -615,6 +624,7 @@ def main():
         # the reference's own CPU figure is a whole frame: ray generation + primary + one AO ray per hit pixel +
         # shading (src/rt_cpu/rt_cpu.rs:35-92,98,113); two frames of that, with the GPU's primary + AO frame beside it
         frame_s = min(osc.render_frame(ov, w, h, sem=args.sem, frame=f, ao_eps=0.01, threads=cores) for f in range(2))
+        O.set_simd(False)
         gpu_frame_ms = min(scene.trace_primary_ao(view, w, h, sem=args.sem, frame=f, ao_eps=0.01)[2] for f in range(4))
         out["cpu_baseline"] = {
             "value": round(n_rays_total * n_frames / secs / 1e6, 3),
@@ -622,6 +632,10 @@ def main():
             "cores": cores,
             "cpu_model": cpu_model(),
             "kind": "port",
+            "implementation": ("AVX2 node test (8 children per instruction), scalar triangle test" if simd else
+                               "scalar (this CPU has no AVX2 + FMA)"),
+            "value_scalar": round(scalar_mrays, 3),                    # the scalar restatement, one frame
+            "simd_equals_scalar": simd_equal,
             "sample": "%d full %dx%d frame(s) of the same workload, %.1f s, OpenMP over 8x8 tiles" % (
                 n_frames, w, h, secs),
             "reference_style_frame_ms": round(frame_s * 1e3, 2),       # primary + AO + shade, wall clock

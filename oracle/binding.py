@@ -59,6 +59,8 @@ def load():
     sigs = {
         "orc_tris_from_verts": (None, [P, u64, P]),
         "orc_set_ao_libm": (None, [i]),
+        "orc_set_simd": (None, [i]),
+        "orc_get_simd": (i, []),
         "orc_tris_from_f16": (None, [P, u64, P]),
         "orc_view_from_camera": (None, [P, P, f, f, f, VP]),
         "orc_octant_inv4": (u32, [P]),
@@ -92,6 +94,14 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def set_simd(on):
+    """The node test over 8 children at once in AVX2 registers (bit-identical results; what cpu_baseline times).
+    Returns whether it took effect (needs AVX2 + FMA)."""
+    lib = load()
+    lib.orc_set_simd(1 if on else 0)
+    return bool(lib.orc_get_simd())
 
 
 def set_ao_libm(on):

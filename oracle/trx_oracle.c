@@ -29,6 +29,10 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define ORC_HAVE_AVX2 1
+#endif
 
 #define F32_MAX 3.402823466e+38f
 #define F32_EPSILON 1.1920929e-7f
@@ -323,8 +327,101 @@ static inline float plane(float q, float adj_inv, float adj_org, uint32_t sem) {
     return q * adj_inv + adj_org;
 }
 
+/* Second implementation of the node test: the eight children at once in AVX2 registers (obvhs' CPU node test
+ * is SIMD too; this is the form the cpu_baseline leg of bench.py times).  Same IEEE operations per child in the
+ * same order - cvt, mul, add (or one fma under ORC_SEM_NODE_FMA), max, max, max, min, min, min, compare - so the
+ * mask is the scalar one bit for bit; the one place vector max/min differ from fmaxf/fminf is a NaN operand
+ * (0 x inf planes of rays with a denormal direction component), and a node that produces one is handed to the
+ * scalar code.  Selected at run time by orc_set_simd(1) when the CPU has AVX2 (and FMA for the fused variant). */
+static int g_simd = 0;
+static uint32_t node_intersect_scalar(const float o[3], const float d[3], const float inv_d[3], uint32_t oct_inv4,
+                                      float max_distance, const uint32_t node[20], uint32_t sem);
+#ifdef ORC_HAVE_AVX2
+__attribute__((target("avx2,fma"))) static inline uint32_t node_intersect_avx2(const float o[3], const float d[3],
+                                                                        const float inv_d[3], uint32_t oct_inv4,
+                                                                        float max_distance, const uint32_t node[20],
+                                                                        uint32_t sem) {
+    const float p[3] = {u2f(node[0]), u2f(node[1]), u2f(node[2])};
+    const uint32_t e_imask = node[3];
+    const float e3[3] = {u2f(extract_byte(e_imask, 0) << 23), u2f(extract_byte(e_imask, 1) << 23),
+                         u2f(extract_byte(e_imask, 2) << 23)};
+    float adj_inv[3], adj_org[3];
+    for (int k = 0; k < 3; k++) {
+        if (sem & ORC_SEM_NODE_RCP) {
+            adj_inv[k] = e3[k] * inv_d[k];
+            adj_org[k] = (p[k] - o[k]) * inv_d[k];
+        } else {
+            adj_inv[k] = e3[k] / d[k];
+            adj_org[k] = (p[k] - o[k]) / d[k];
+        }
+    }
+    __m256 lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+        /* data[2 + k] = {min[0..4], min[4..8], max[0..4], max[4..8]}: 8 bytes each, child j in byte j */
+        const __m128i qmin = _mm_loadl_epi64((const __m128i *)(node + 8 + 4 * k));
+        const __m128i qmax = _mm_loadl_epi64((const __m128i *)(node + 10 + 4 * k));
+        const __m256 fmin = _mm256_cvtepi32_ps(_mm256_cvtepu8_epi32(qmin));
+        const __m256 fmax = _mm256_cvtepi32_ps(_mm256_cvtepu8_epi32(qmax));
+        const __m256 a = _mm256_set1_ps(adj_inv[k]), b = _mm256_set1_ps(adj_org[k]);
+        __m256 tlo, thi;
+        if (sem & ORC_SEM_NODE_FMA) {
+            tlo = _mm256_fmadd_ps(fmin, a, b);
+            thi = _mm256_fmadd_ps(fmax, a, b);
+        } else {
+            tlo = _mm256_add_ps(_mm256_mul_ps(fmin, a), b);
+            thi = _mm256_add_ps(_mm256_mul_ps(fmax, a), b);
+        }
+        /* near / far plane by the sign of the direction (query.hlsl:266-273) */
+        if (d[k] < 0.0f) {
+            lo[k] = thi;
+            hi[k] = tlo;
+        } else {
+            lo[k] = tlo;
+            hi[k] = thi;
+        }
+    }
+    /* any NaN among the 48 planes: let the scalar code (fmaxf / fminf semantics) decide this node */
+    const __m256 sum = _mm256_add_ps(_mm256_add_ps(_mm256_add_ps(lo[0], lo[1]), _mm256_add_ps(lo[2], hi[0])),
+                                     _mm256_add_ps(hi[1], hi[2]));
+    if (_mm256_movemask_ps(_mm256_cmp_ps(sum, sum, _CMP_UNORD_Q)))
+        return node_intersect_scalar(o, d, inv_d, oct_inv4, max_distance, node, sem);
+    const __m256 tmin = _mm256_max_ps(_mm256_max_ps(_mm256_max_ps(lo[0], lo[1]), lo[2]), _mm256_set1_ps(0.0001f));
+    const __m256 tmax = _mm256_min_ps(_mm256_min_ps(_mm256_min_ps(hi[0], hi[1]), hi[2]), _mm256_set1_ps(max_distance));
+    const __m256i hit = _mm256_castps_si256(_mm256_cmp_ps(tmin, tmax, _CMP_LE_OQ));
+    /* child_meta -> bit positions (query.hlsl:249-254,294-297), one child per 32-bit lane */
+    const __m256i meta = _mm256_cvtepu8_epi32(_mm_loadl_epi64((const __m128i *)(node + 6)));
+    const __m256i is_inner = _mm256_cmpeq_epi32(_mm256_and_si256(meta, _mm256_set1_epi32(0x18)), _mm256_set1_epi32(0x18));
+    const __m256i oct = _mm256_and_si256(is_inner, _mm256_set1_epi32((int)(oct_inv4 & 0xffu)));
+    const __m256i bit_index = _mm256_and_si256(_mm256_xor_si256(meta, oct), _mm256_set1_epi32(0x1f));
+    const __m256i child_bits = _mm256_and_si256(_mm256_srli_epi32(meta, 5), _mm256_set1_epi32(7));
+    __m256i bits = _mm256_and_si256(_mm256_sllv_epi32(child_bits, bit_index), hit);
+    bits = _mm256_or_si256(bits, _mm256_permute2x128_si256(bits, bits, 1));
+    bits = _mm256_or_si256(bits, _mm256_shuffle_epi32(bits, 0x4e));
+    bits = _mm256_or_si256(bits, _mm256_shuffle_epi32(bits, 0xb1));
+    return (uint32_t)_mm256_cvtsi256_si32(bits);
+}
+#endif
+
+void orc_set_simd(int on) {
+#ifdef ORC_HAVE_AVX2
+    g_simd = on && __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+#else
+    (void)on;
+    g_simd = 0;
+#endif
+}
+int orc_get_simd(void) { return g_simd; }
+
 uint32_t orc_node_intersect(const float o[3], const float d[3], const float inv_d[3], uint32_t oct_inv4,
                             float max_distance, const uint32_t node[20], uint32_t sem) {
+#ifdef ORC_HAVE_AVX2
+    if (g_simd) return node_intersect_avx2(o, d, inv_d, oct_inv4, max_distance, node, sem);
+#endif
+    return node_intersect_scalar(o, d, inv_d, oct_inv4, max_distance, node, sem);
+}
+
+static uint32_t node_intersect_scalar(const float o[3], const float d[3], const float inv_d[3], uint32_t oct_inv4,
+                                      float max_distance, const uint32_t node[20], uint32_t sem) {
     const float p[3] = {u2f(node[0]), u2f(node[1]), u2f(node[2])};
     const uint32_t e_imask = node[3];
     float ex = u2f(extract_byte(e_imask, 0) << 23);
@@ -416,8 +513,11 @@ orc_hit orc_traverse(const orc_scene *s, const float o[3], const float d_in[3], 
     return orc_traverse_inst(s, o, d_in, tmin, tmax, sem, st, NULL);
 }
 
-orc_hit orc_traverse_inst(const orc_scene *s, const float o_in[3], const float d_in[3], float tmin, float tmax,
-                          uint32_t sem, orc_stats *st, uint32_t *inst_out) {
+/* One body, compiled twice: with the scalar node test, and - inside a function built for AVX2 - with the 8-wide one
+ * inlined into the loop (orc_set_simd).  Everything but the node test is the same scalar code in both. */
+static inline __attribute__((always_inline)) orc_hit traverse_body(const orc_scene *s, const float o_in[3], const float d_in[3],
+                                                                   float tmin, float tmax, uint32_t sem, orc_stats *st,
+                                                                   uint32_t *inst_out, const int simd) {
     float o[3] = {o_in[0], o_in[1], o_in[2]}, d[3], inv_d[3];
     for (int k = 0; k < 3; k++) { /* :334 zero-direction fix, seen by node AND triangle tests */
         d[k] = d_in[k] == 0.0f ? F32_EPSILON : d_in[k];
@@ -457,7 +557,13 @@ orc_hit orc_traverse_inst(const orc_scene *s, const float o_in[3], const float d
             uint32_t child_node_index = child_index_base + relative_index;
             const uint32_t *node = s->nodes + 20 * (uint64_t)(bvh_offset + child_node_index);
             n_node++;
-            uint32_t hitmask = orc_node_intersect(o, d, inv_d, oct_inv4, t, node, sem);
+#ifdef ORC_HAVE_AVX2
+            uint32_t hitmask = simd ? node_intersect_avx2(o, d, inv_d, oct_inv4, t, node, sem)
+                                    : node_intersect_scalar(o, d, inv_d, oct_inv4, t, node, sem);
+#else
+            uint32_t hitmask = node_intersect_scalar(o, d, inv_d, oct_inv4, t, node, sem);
+            (void)simd;
+#endif
             uint32_t imask = extract_byte(node[3], 3);
             cur.x = node[4];
             tri.x = node[5];
@@ -541,6 +647,26 @@ orc_hit orc_traverse_inst(const orc_scene *s, const float o_in[3], const float d
         st->overflow += (uint32_t)overflow;
     }
     return h;
+}
+
+static orc_hit traverse_scalar(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax, uint32_t sem,
+                               orc_stats *st, uint32_t *inst_out) {
+    return traverse_body(s, o, d, tmin, tmax, sem, st, inst_out, 0);
+}
+#ifdef ORC_HAVE_AVX2
+__attribute__((target("avx2,fma"))) static orc_hit traverse_avx2(const orc_scene *s, const float o[3], const float d[3],
+                                                                 float tmin, float tmax, uint32_t sem, orc_stats *st,
+                                                                 uint32_t *inst_out) {
+    return traverse_body(s, o, d, tmin, tmax, sem, st, inst_out, 1);
+}
+#endif
+
+orc_hit orc_traverse_inst(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax, uint32_t sem,
+                          orc_stats *st, uint32_t *inst_out) {
+#ifdef ORC_HAVE_AVX2
+    if (g_simd) return traverse_avx2(s, o, d, tmin, tmax, sem, st, inst_out);
+#endif
+    return traverse_scalar(s, o, d, tmin, tmax, sem, st, inst_out);
 }
 
 /* ---- frames ----------------------------------------------------------------------- */

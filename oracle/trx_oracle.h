@@ -100,6 +100,12 @@ uint32_t orc_uhash(uint32_t a, uint32_t b);
 float orc_hash_noise(uint32_t x, uint32_t y, uint32_t frame);
 void orc_sincos(float theta, float *s, float *c);
 void orc_set_ao_libm(int on); /* measurement aid: libm sinf / cosf in the AO direction */
+/* Node test over the eight children at once in AVX2 registers instead of the scalar loop: the same IEEE operations
+ * per child, so every result is bit-identical (tests/test_oracle.py asserts it on the goldens and on whole frames);
+ * it is what bench.py's cpu_baseline leg times, because the reference's CPU node test (obvhs) is SIMD as well.
+ * Takes effect only on a CPU with AVX2 + FMA; orc_get_simd() says whether it did. */
+void orc_set_simd(int on);
+int orc_get_simd(void);
 
 /* single ray through the CWBVH (BLAS-only when n_instances == 0) */
 orc_hit orc_traverse(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax,

@@ -361,3 +361,79 @@ def test_fixed_seed_slice_of_the_oracle_fuzzer():
     st = fuzz_oracle.run(minutes=2.0, seed=5, max_cases=400, n_rays=1500, verbose=False)
     assert st["cases"] == 400 and st["closer"] == 0 and st["worst_rel"] < 1e-6
     assert st["differing"] + st["missed"] < 1e-4 * st["rays"]
+
+
+def test_simd_node_test_is_bit_identical_to_the_scalar_one(trx, orc):
+    """The AVX2 form of the node test (the one bench.py's cpu_baseline leg times, because obvhs' CPU node test is SIMD
+    too) against the scalar restatement: the node masks themselves on random and on adversarial inputs (zero / denormal
+    / huge direction components, which make 0 x inf planes), every golden frame, random rays under all eight
+    semantics, and a whole primary + AO frame with its node / triangle counts."""
+    if not orc.set_simd(True):
+        orc.set_simd(False)
+        pytest.skip("this CPU has no AVX2 + FMA")
+    try:
+        lib = orc.load()
+        flat, view, osc, ov = make_scene(trx, orc, "bistro", 40000, 160, 90)
+        nodes = np.ascontiguousarray(flat.nodes).view(np.uint32).reshape(-1, 20)
+        rng = np.random.default_rng(11)
+        pts = flat.tri_verts.reshape(-1, 3)
+        lo, hi = pts.min(0), pts.max(0)
+        special = np.array([0.0, -0.0, 1e-42, -1e-42, 1.1920929e-7, 3e38, -3e38, 1.0, -1.0], dtype=np.float32)
+        n_checked = 0
+        for k in range(6000):
+            o = rng.uniform(lo, hi).astype(np.float32)
+            d = rng.normal(size=3).astype(np.float32)
+            if k % 3 == 0:
+                d[rng.integers(3)] = special[rng.integers(len(special))]
+            if k % 7 == 0:
+                d[:] = special[rng.integers(len(special), size=3)]
+            d = np.where(d == 0, np.float32(1.1920929e-7), d).astype(np.float32)   # the zero-direction fix runs before the node test
+            with np.errstate(divide="ignore", over="ignore"):
+                inv = (np.float32(1.0) / d).astype(np.float32)
+            oct4 = lib.orc_octant_inv4(d.ctypes.data_as(C.c_void_p))
+            node = np.ascontiguousarray(nodes[rng.integers(len(nodes))])
+            tmax = np.float32(rng.choice([3.4028234663852886e38, 1.0, 10.0, 0.5]))
+            for sem in ALL_SEMS:
+                args = (o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), inv.ctypes.data_as(C.c_void_p), oct4,
+                        float(tmax), node.ctypes.data_as(C.c_void_p), sem)
+                orc.set_simd(False)
+                want = lib.orc_node_intersect(*args)
+                orc.set_simd(True)
+                assert lib.orc_node_intersect(*args) == want, (k, sem, o, d)
+                n_checked += 1
+        assert n_checked == 6000 * 8
+        # goldens
+        for name in ["cornell_64", "cornell_tlas_48", "soup_52x44"]:
+            g, gsc = load_golden(orc, name)
+            w, h = int(g["width"]), int(g["height"])
+            gv = orc.view_from_bytes(g["view"].tobytes())
+            for sem in (0, 3):
+                prim, st = gsc.trace_primary(gv, w, h, sem=sem)
+                assert_hits_equal(prim, g["orc_primary_sem%d" % sem], "%s sem %d primary (simd)" % (name, sem))
+                assert [st.n_node, st.n_tri, st.n_hits, st.max_stack] == list(g["orc_counts_sem%d" % sem])
+                ao, _ = gsc.trace_ao(gv, w, h, prim, sem=sem, frame=2, ao_eps=0.01)
+                assert_hits_equal(ao, g["orc_ao_sem%d" % sem], "%s sem %d ao (simd)" % (name, sem))
+        g, gsc = load_golden(orc, "ties_rays")
+        for sem in (0, 3):
+            hits, _ = gsc.trace_rays(g["rays"], sem=sem)
+            assert_hits_equal(hits, g["orc_rays_sem%d" % sem], "ties sem %d (simd)" % sem)
+        # random rays (zero direction components included) under every semantics, and a whole frame
+        rays = random_rays(trx, flat, 4000, 5)
+        for sem in ALL_SEMS:
+            orc.set_simd(False)
+            want, wst = osc.trace_rays(rays, sem=sem)
+            orc.set_simd(True)
+            got, gst = osc.trace_rays(rays, sem=sem)
+            assert_hits_equal(got, want, "random rays sem %d (simd)" % sem)
+            assert (gst.n_node, gst.n_tri) == (wst.n_node, wst.n_tri)
+        orc.set_simd(False)
+        want, wst = osc.trace_primary(ov, 160, 90, sem=3)
+        want_ao, _ = osc.trace_ao(ov, 160, 90, want, sem=3, frame=1, ao_eps=0.01)
+        orc.set_simd(True)
+        got, gst = osc.trace_primary(ov, 160, 90, sem=3)
+        got_ao, _ = osc.trace_ao(ov, 160, 90, got, sem=3, frame=1, ao_eps=0.01)
+        assert_hits_equal(got, want, "frame (simd)")
+        assert_hits_equal(got_ao, want_ao, "AO frame (simd)")
+        assert (gst.n_node, gst.n_tri, gst.n_hits) == (wst.n_node, wst.n_tri, wst.n_hits)
+    finally:
+        orc.set_simd(False)

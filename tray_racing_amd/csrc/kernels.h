@@ -18,6 +18,17 @@ constexpr uint32_t kLptShards = 8; // appenders per tile-cost bucket (16 buckets
 #ifndef TRX_MIN_WAVES
 #define TRX_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for
 #endif
+#ifndef TRX_TRI_BATCH
+#define TRX_TRI_BATCH 1
+#endif
+#ifndef TRX_TRI_BATCH_TLAS
+#define TRX_TRI_BATCH_TLAS 1
+#endif
+#ifndef TRX_TRI_BATCH_PIPE
+#define TRX_TRI_BATCH_PIPE 1
+#endif
+// triangles of a lane requested together in a per-lane triangle round: BLAS-only walk / two-level walk / pipelined walk
+constexpr int kTriBatch = TRX_TRI_BATCH, kTriBatchTlas = TRX_TRI_BATCH_TLAS, kTriBatchPipe = TRX_TRI_BATCH_PIPE;
 constexpr int kLdsStack = TRX_LDS_STACK;        // traversal-stack entries per lane kept in LDS
 constexpr int kSpillStack = 64 - TRX_LDS_STACK; // further entries per lane in HBM (total 64 = oracle's ORC_STACK_SIZE)
 // LDS per wave: stack + ray table (2 x float4 per lane) + triangle-phase tables (group, result, prefix, heads)

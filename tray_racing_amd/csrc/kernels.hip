@@ -70,6 +70,15 @@ __device__ __forceinline__ float plane(float q, float a, float b) {
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Four registers with no defined contents (a frozen undef: costs no instruction), for values that only the lanes
+// which go on to load them will read.
+__device__ __forceinline__ float4 unspecified4() {
+    f32x4 v;
+    v = __builtin_nondeterministic_value(v);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 // two planes at once: q * a + b on both halves (separate roundings unless NODE & 2)
 template <int NODE>
@@ -283,6 +292,33 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
     return v;
 }
 
+// Order-preserving image of a float's bits (a < b as floats <=> image(a) < image(b) as unsigned, for non-NaN values
+// with -0.0 below +0.0: callers canonicalise zeros first) and its inverse.
+__device__ __forceinline__ uint32_t ordered_bits(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ uint32_t unordered_bits(uint32_t k) {
+    return k ^ ((k & 0x80000000u) ? 0x80000000u : 0xffffffffu);
+}
+
+// Position of the (j+1)-th highest set bit of m (bits 0..23; m has more than j bits set): rank from the bottom, then
+// a branch-free descent over 12 / 6 / 3 / 1 / 1 bits.
+__device__ __forceinline__ uint32_t select_from_top(uint32_t m, uint32_t j) {
+    uint32_t r = (uint32_t)__popc(m) - j, pos = 0u, c;
+    c = (uint32_t)__popc(m & 0xfffu);
+    if (r > c) { r -= c; pos = 12u; }
+    c = (uint32_t)__popc((m >> pos) & 0x3fu);
+    if (r > c) { r -= c; pos += 6u; }
+    c = (uint32_t)__popc((m >> pos) & 0x7u);
+    if (r > c) { r -= c; pos += 3u; }
+    c = (m >> pos) & 1u;
+    if (r > c) { r -= c; pos += 1u; }
+    c = (m >> pos) & 1u;
+    if (r > c) pos += 1u;
+    return pos;
+}
+
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -305,6 +341,8 @@ __device__ __forceinline__ void flush_pending(const TraceParams &P, const uint2 
 template <int MODE, bool TLAS, int NODE, bool PIPE, bool COUNT>
 __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceParams P) {
     static_assert(!(PIPE && TLAS), "the pipelined walk is BLAS-only");
+    // triangles of a lane requested together in a per-lane triangle round (the two-level walk has fewer registers to spare)
+    constexpr int kBatch = TLAS ? kTriBatchTlas : (PIPE ? kTriBatchPipe : kTriBatch);
     // one stack region per wave of the workgroup; waves never synchronise with each other
     extern __shared__ float4 lds_dyn[];
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -682,32 +720,67 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     incl = wave_scan_add(cnt);
                     total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     const uint32_t mx = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_max(cnt), 63);
-                    coop = mx > P.tri_coop_ratio * ((total + 63u) >> 6);
+                    // per-lane rounds carry kBatch triangles of a lane each, cooperative rounds 64 pairs of the wave
+                    coop = (mx + (uint32_t)kBatch - 1u) / (uint32_t)kBatch > P.tri_coop_ratio * ((total + 63u) >> 6);
                 }
                 if (!coop) {
+                    // Per-lane rounds, up to kBatch triangles of a lane per round: their records are requested
+                    // together (one memory round trip per round instead of one per triangle; on incoherent rays the
+                    // triangle phase is 55-60 % of a trip and most of that is these round trips) and tested in the
+                    // lane's own order, highest bit first, each against the t its predecessor left.
                     while (tri.y != 0u) {
-                        const uint32_t local = 31u - (uint32_t)__builtin_clz(tri.y); // tri.y != 0
-                        tri.y &= ~(1u << local);
-                        const uint32_t gidx = tri.x + local;
-                        const float4 *tp = P.tris + (size_t)gidx * 3;
-                        float4 a = tp[0], b = tp[1], c4 = tp[2];
-                        // keep the three 16-byte loads together: left alone the compiler sinks the v0
-                        // load behind the determinant, serialising two memory latencies per triangle
-                        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c4.x), "+v"(c4.y), "+v"(c4.z), "+v"(c4.w));
-                        if (COUNT) {
-                            c_tri++;
-                            if (lane_rank(__ballot(1)) == 0) c_wtri++;
-                            if (P.touch_tris) P.touch_tris[gidx] = 1;
+                        uint32_t gidx[kBatch];
+                        bool have[kBatch];
+                        float4 ta[kBatch], tb[kBatch], tc[kBatch];
+#pragma unroll
+                        for (int k = 0; k < kBatch; k++) {
+                            have[k] = tri.y != 0u;
+                            const uint32_t local = 31u - (uint32_t)__builtin_clz(tri.y | 1u);
+                            tri.y &= ~(1u << local);
+                            gidx[k] = tri.x + local;
+                            ta[k] = tb[k] = tc[k] = unspecified4(); // no lane without a triangle reads them
+                            if (have[k]) {
+                                const float4 *tp = P.tris + (size_t)gidx[k] * 3;
+                                ta[k] = tp[0];
+                                tb[k] = tp[1];
+                                tc[k] = tp[2];
+                            }
                         }
-                        if (intersect_tri<true>(r, a, b, c4, t, tie_first)) {
-                            prim = gidx;
-                            if (TLAS) hit_inst = cur_inst;
+                        // keep the loads of a round together and ahead of the arithmetic: left alone the compiler
+                        // sinks them behind the first determinant, serialising the memory latencies again
+#pragma unroll
+                        for (int k = 0; k < kBatch; k++)
+                            asm volatile("" : "+v"(ta[k].x), "+v"(ta[k].y), "+v"(ta[k].z), "+v"(ta[k].w), "+v"(tb[k].x), "+v"(tb[k].y), "+v"(tb[k].z), "+v"(tb[k].w), "+v"(tc[k].x), "+v"(tc[k].y), "+v"(tc[k].z), "+v"(tc[k].w));
+#pragma unroll
+                        for (int k = 0; k < kBatch; k++) {
+                            if (have[k]) {
+                                if (COUNT) {
+                                    c_tri++;
+                                    if (lane_rank(__ballot(1)) == 0) c_wtri++;
+                                    if (P.touch_tris) P.touch_tris[gidx[k]] = 1;
+                                }
+                                if (intersect_tri<true>(r, ta[k], tb[k], tc[k], t, tie_first)) {
+                                    prim = gidx[k];
+                                    if (TLAS) hit_inst = cur_inst;
+                                }
+                            }
                         }
                     }
                 } else {
+                    // Cooperative rounds: the wave's (ray, triangle) pairs laid out densely, pair g on lane g % 64.  The
+                    // tester finds its owner (a max-scan over the run heads), picks the owner's j-th triangle, tests it
+                    // against the owner's ray and folds the result into the owner's 64-bit key with ONE LDS atomic min:
+                    // key = {order-preserving image of t, tie word}.  The owner's key starts as its current t with a tie
+                    // word that wins (TIE_FIRST: tt < t commits) or loses (tt <= t commits) every tie, and a pair's
+                    // tie word is its place in the owner's own sequence (highest bit first), so the minimum IS the
+                    // result of the sequential loop "for each triangle in order: if closer, commit": no per-owner
+                    // commit loop, no result table, one barrier-free pass per window.
                     const uint32_t excl = incl - cnt;
                     lds_grp[lane] = tri;
                     lds_pref[lane] = excl;
+                    const uint32_t init_lo = tie_first ? 0u : 0xffu;
+                    unsigned long long *const lds_key = reinterpret_cast<unsigned long long *>(lds_res);
+                    lds_res[lane] = make_uint2(init_lo, ordered_bits(t + 0.0f));
                     if (COUNT) c_tri += cnt;
                     for (uint32_t base = 0; base < total; base += kWave) {
                         // owner of every pair of this window: heads mark where each owner's run starts
@@ -718,13 +791,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         __builtin_amdgcn_wave_barrier();
                         const uint32_t owner1 = wave_scan_max(lds_head[lane]);
                         const uint32_t g = base + lane;
-                        uint2 res = make_uint2(0x7fc00000u, 0u); // NaN: never commits
                         if (g < total) {
                             const uint32_t ol = owner1 - 1u;
                             const uint2 grp = lds_grp[ol];
-                            uint32_t m = grp.y;
-                            for (uint32_t j = g - lds_pref[ol]; j > 0u; j--) m &= ~(1u << (31u - (uint32_t)__clz((int)m)));
-                            const uint32_t gidx = grp.x + (31u - (uint32_t)__clz((int)m));
+                            const uint32_t local = select_from_top(grp.y, g - lds_pref[ol]);
+                            const uint32_t gidx = grp.x + local;
                             if (COUNT && P.touch_tris) P.touch_tris[gidx] = 1;
                             const float4 *tp = P.tris + (size_t)gidx * 3;
                             float4 a = tp[0], b = tp[1], c4 = tp[2];
@@ -733,23 +804,27 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             Ray orr;
                             orr.ox = ro.x; orr.oy = ro.y; orr.oz = ro.z; orr.tmin = ro.w;
                             orr.dx = rd.x; orr.dy = rd.y; orr.dz = rd.z;
-                            float tt = TRX_F32_MAX; // the range / tie test against the owner's t happens at commit
-                            if (intersect_tri(orr, a, b, c4, tt, false)) res = make_uint2(__float_as_uint(tt), gidx);
-                        }
-                        lds_res[lane] = res;
-                        __builtin_amdgcn_wave_barrier();
-                        for (uint32_t q = run_begin; q < run_end; q++) {
-                            const uint2 rr = lds_res[q - base];
-                            const float tt = __uint_as_float(rr.x);
-                            if (tie_first ? (tt < t) : (tt <= t)) {
-                                t = tt;
-                                prim = rr.y;
-                                if (TLAS) hit_inst = cur_inst;
+                            float tt = TRX_F32_MAX; // the tie test against the owner's t is the atomic min
+                            if (intersect_tri(orr, a, b, c4, tt, false)) {
+                                // -0.0 and +0.0 are one value to the sequential compare: they share a key, and the
+                                // tie word's lowest bit remembers which one the pair really produced
+                                const uint32_t neg_zero = __float_as_uint(tt) == 0x80000000u ? 1u : 0u;
+                                const uint32_t lo = ((tie_first ? 31u - local : local) << 1) | neg_zero;
+                                const unsigned long long key = ((unsigned long long)ordered_bits(tt + 0.0f) << 32) | lo;
+                                atomicMin(&lds_key[ol], key);
                             }
                         }
-                        __builtin_amdgcn_wave_barrier();
                         if (COUNT && lane == 0) c_wtri++;
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    const uint2 won = lds_res[lane];
+                    if (cnt != 0u && won.x != init_lo) { // some pair of this lane beat (or tied its way past) the current t
+                        const uint32_t local = tie_first ? 31u - (won.x >> 1) : (won.x >> 1);
+                        t = (won.x & 1u) ? -0.0f : __uint_as_float(unordered_bits(won.y));
+                        prim = tri.x + local;
+                        if (TLAS) hit_inst = cur_inst;
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
 
