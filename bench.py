@@ -54,6 +54,14 @@ VALU_CYCLES = 2.0      # a wave64 VALU instruction issues over 2 cycles on a SIM
 # SDWA, and scalar ALU alike) issue at one per 2.63 cycles per SIMD; only v_fma/mul/add_f32, v_and, v_add_u32 reach 1.62
 ISSUE_CYCLES_MEASURED = 2.63
 VARIANT_COLD = 1 << 20  # trx_set_kernel_variant: tile-order feedback off
+VARIANT_CUT = 1 << 7    # ... every frame treated as a camera cut: probe pass + probe-ordered frame (a first frame)
+# static VALU instruction counts of the two tests in the shipped primary kernel (llvm-objdump of k_trace<0,false,1,...>:
+# the node-test block is 213 vector instructions, one per-lane triangle round - bit select, address, test, commit - 70);
+# roofline.useful_frac prices the COUNTED lane-level tests at these, i.e. what a divergence-free walk would issue
+NODE_TEST_VALU = 213
+TRI_TEST_VALU = 70
+L1_BYTES_PER_CLK_CU = 64.0  # vector L1 (TCP) data path per CU and clock (guide, cache hierarchy)
+CUS = 256
 
 
 def baseline_metric():
@@ -128,6 +136,8 @@ PMC_GROUPS = [
     "FETCH_SIZE",
     "WRITE_SIZE",
     "VALUBusy VALUUtilization SALUBusy",   # rocprofv3's derived metrics (per cent), reported as they come
+    "TA_TA_BUSY_sum GRBM_GUI_ACTIVE",      # texture-address / L1 front end: busy cycles summed over the CUs
+    "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum",   # L1 tag look-ups and what they sent on to L2
 ]
 
 
@@ -360,6 +370,12 @@ def main():
         # (c) the literal HLSL arithmetic (per-node IEEE divides, tt <= t)
         hmin, hmean = scene.bench_primary(view, w, h, sem=0, warmup=3, frames=20)
         legs["sem_hlsl_ms"] = {"min": round(hmin, 4), "mean": round(hmean, 4)}
+        # (c') every frame a camera cut: the probe pass (one centre ray per tile) + a frame in the order it predicts -
+        #      what the first frame of a view costs since round 3; hipEvents bracket both kernels
+        lib.trx_set_kernel_variant(VARIANT_CUT)
+        fmin, fmean = scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20)
+        lib.trx_set_kernel_variant(0)
+        legs["first_frame_ms"] = {"min": round(fmin, 4), "mean": round(fmean, 4)}
         # (d) frames overlapped on 4 streams (independent frames; the tail of one overlaps the next)
         ps = [torch.cuda.Stream() for _ in range(4)]
         pbuf = [torch.empty(n_rays_total, dtype=torch.int64, device="cuda") for _ in ps]
@@ -502,6 +518,30 @@ def main():
             "kernel_ms": round(kernel_ms, 4),
             "valu_wave_insts_per_launch": int(valu) if valu else None,
         }
+        # what a divergence-free walk of the same rays would issue: every COUNTED lane-level node step and triangle test
+        # (the reference's PROFILE_RT counters, rt_gpu_software_query.hlsl:377-379,407-409) at the static instruction
+        # count of the test, 64 lanes to a wave-instruction; issued / useful = divergence + bookkeeping
+        useful = (st.n_node * NODE_TEST_VALU + st.n_tri * TRI_TEST_VALU) / 64.0
+        if args.sim_shards == 1:
+            roof["useful_valu_wave_insts_per_launch"] = int(useful)
+            roof["useful_frac"] = round(useful / (kernel_ms * 1e-3) / 1e9 / peak_ginstr, 4)
+            roof["issued_over_useful"] = round(valu / useful, 3) if valu else None
+            roof["useful_note"] = ("(node steps x %d + triangle tests x %d) / 64 wave-instructions per launch over the "
+                                   "same peak as `frac`" % (NODE_TEST_VALU, TRI_TEST_VALU))
+        # the vector-memory front end: every lane requests its node / triangle bytes through TA / L1 whatever the caches
+        # then serve, so the requested bytes price the L1 data path (64 B per CU and clock), and TA_TA_BUSY says how
+        # long the address unit was occupied
+        l1_peak = CUS * L1_BYTES_PER_CLK_CU * CLOCK_GHZ
+        roof["l1"] = {
+            "bound": "l1", "unit": "GB/s", "achieved": round(req_gbs, 1), "peak": round(l1_peak, 1),
+            "frac": round(req_gbs / l1_peak, 4),
+            "ta_busy_frac": (round(pmc["TA_TA_BUSY_sum"] / (CUS * pmc["GRBM_GUI_ACTIVE"] / 8.0), 4)
+                             if pmc and pmc.get("TA_TA_BUSY_sum") and pmc.get("GRBM_GUI_ACTIVE") else None),
+            "l1_hit_rate": (round(1.0 - pmc["TCP_TCC_READ_REQ_sum"] / pmc["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
+                            if pmc and pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None),
+            "note": "achieved = requested (algorithmic) bytes per second, all of which cross TA / L1; peak = 256 CUs x 64 B "
+                    "per clock x 2.4 GHz; ta_busy_frac = TA_TA_BUSY summed over the CUs / (256 x GPU-active cycles per XCD)",
+        }
         if pmc and pmc.get("SQ_INSTS"):
             # every instruction class shares the SIMD's issue stage: all wave-instructions per second
             # against the issue rate measured for this instruction mix at this occupancy
@@ -532,7 +572,10 @@ def main():
             "achieved": round(req_gbs, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": round(req_gbs / HBM_PEAK_GBS, 4),
+            # NOT a roofline fraction: requested bytes are served by L1 / L2 / Infinity Cache and this ratio passes 1;
+            # the measured fabric traffic below is the HBM-side figure
+            "requested_over_hbm_peak": round(req_gbs / HBM_PEAK_GBS, 4),
+            "measured_over_hbm_peak": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
             "peak_measured": legs.get("hbm_copy_gbs"),
             "bytes_per_launch": int(launch_bytes),
             "compulsory_bytes": legs.get("footprint", {}).get("bytes"),
@@ -546,6 +589,10 @@ def main():
         out = {
             "metric": baseline_metric(),
             "value": round(value, 2),
+            # the same frame under the literal HLSL arithmetic (TRX_SEM_HLSL: per-node IEEE divides, tt <= t), the only
+            # semantics the reference's tree states in full; `value` runs the CPU-path preset (TRX_SEM_CPU)
+            "value_sem_hlsl": (round(n_rays_total / (legs["sem_hlsl_ms"]["mean"] * 1e-3) / 1e6, 2)
+                               if "sem_hlsl_ms" in legs else None),
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -570,7 +617,8 @@ def main():
                 "frames_per_gather": F,
                 "build_seconds": round(build_s, 2),
                 "tile_order": "learnt from the previous frame on the same stream (static camera, as the reference "
-                              "benches); first-frame figure in legs.cold_order_ms",
+                              "benches); a first frame (probe pass + probe-ordered frame) in legs.first_frame_ms, feedback off "
+                              "in legs.cold_order_ms",
             },
             "kernel_ms_mean": round(kernel_ms, 4),
             "kernel_ms_min": round(min(launch_ms), 4),

@@ -159,6 +159,21 @@ def main():
         return e
 
     save("kitchen_tlas_f16_56x40", flat, view, 56, 40, f16_extra)
+    # 5b. stand-ins for the two ref_* fixtures below that need no reference checkout (so they also run on the GPU box):
+    #     a 14-triangle, two-object scene - one box and a ground quad, the triangle count and object split of
+    #     assets/obj/box.obj - through a TLAS with the camera of assets/scenes/box.ron; the Cornell-class box with the
+    #     camera of assets/scenes/cornell_box.ron is fixture 1 above
+    def quad(a, b, c, d):
+        return [a + b + c, a + c + d]
+    bx = [(-1.0, 0.0, -1.0), (1.0, 0.0, -1.0), (1.0, 0.0, 1.0), (-1.0, 0.0, 1.0),
+          (-1.0, 2.0, -1.0), (1.0, 2.0, -1.0), (1.0, 2.0, 1.0), (-1.0, 2.0, 1.0)]
+    box_tris = (quad(bx[0], bx[1], bx[2], bx[3]) + quad(bx[4], bx[7], bx[6], bx[5]) + quad(bx[0], bx[4], bx[5], bx[1]) +
+                quad(bx[1], bx[5], bx[6], bx[2]) + quad(bx[2], bx[6], bx[7], bx[3]) + quad(bx[3], bx[7], bx[4], bx[0]))
+    ground = quad((-6.0, -0.001, -6.0), (6.0, -0.001, -6.0), (6.0, -0.001, 6.0), (-6.0, -0.001, 6.0))
+    verts = np.array(box_tris + ground, dtype=np.float32)
+    counts = np.array([12, 2], dtype=np.uint64)
+    flat = T.flat_build(verts, counts, use_tlas=True)
+    save("box14_tlas_48", flat, T.view_from_camera((3.0, 1.5, 1.4), (-3.9438584, 1.5, -1.7303504), 90.0, 48, 48), 48, 48, None)
     # 6./7. the reference's own small assets (the only geometry it ships), its loader rules and its cameras
     if os.path.exists(os.path.join(REF_ASSETS, "obj", "cornell_box.obj")):
         verts, counts = T.load_meshs(os.path.join(REF_ASSETS, "obj", "cornell_box.obj"))

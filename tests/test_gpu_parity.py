@@ -40,7 +40,7 @@ def load_view(trx, raw):
 
 # ---- golden fixtures -----------------------------------------------------------------------
 
-@pytest.mark.parametrize("name", ["cornell_64", "cornell_tlas_48", "soup_52x44", "ref_cornell_box_64", "ref_box_tlas_48"])
+@pytest.mark.parametrize("name", ["cornell_64", "cornell_tlas_48", "soup_52x44", "box14_tlas_48", "ref_cornell_box_64", "ref_box_tlas_48"])
 def test_golden_images(trx, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     sc = trx.Scene(GoldenFlat(trx, g).flat)

@@ -32,7 +32,7 @@ def assert_matches_bruteforce(osc, rays, got, bf, sem):
     return diff.size
 
 
-@pytest.mark.parametrize("name", ["cornell_64", "cornell_tlas_48", "soup_52x44", "ref_cornell_box_64", "ref_box_tlas_48"])
+@pytest.mark.parametrize("name", ["cornell_64", "cornell_tlas_48", "soup_52x44", "box14_tlas_48", "ref_cornell_box_64", "ref_box_tlas_48"])
 def test_golden_images(orc, name):
     g, osc = load_golden(orc, name)
     w, h = int(g["width"]), int(g["height"])

@@ -108,6 +108,7 @@ struct Slot {
     uint32_t lpt_capacity = 0;
     uint32_t lpt_parity = 0; // set written by the next frame
     uint64_t lpt_key = 0;    // (width, height, shard, mode) the lists were measured for; 0 = none
+    ViewDev lpt_view{};      // view of the last frame that read or wrote the lists (camera-cut detection)
 };
 
 } // namespace
@@ -133,6 +134,7 @@ struct trx_scene {
     uint64_t n_nodes = 0, n_tris = 0;
     uint32_t n_inst = 0, tlas_start = 0;
     bool tlas = false;
+    float scene_diag = 0.f; // diagonal of the root node's box (camera-cut detection scales with it)
     int grid = 0;      // default number of persistent waves
     int cu_count = 0;
     unsigned long long *d_wave_times = nullptr; // diagnostics only (trx_debug_wave_timeline)
@@ -425,7 +427,23 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         key = ((uint64_t)p.width << 40) ^ ((uint64_t)p.height << 20) ^ ((uint64_t)p.shard_count << 8) ^ p.shard_index ^
               ((uint64_t)(mode + 1) << 60) ^ ((uint64_t)p.n_frames << 56);
         uint32_t *set[2] = {slot.lpt, slot.lpt + set_words};
-        if (slot.lpt_key != key) { // new geometry: empty both sets, cold (identity) order this frame
+        // A learnt order belongs to a view.  New image geometry, or a camera cut (the eye jumped by more than 1 % of
+        // the scene's diagonal, the view direction turned by more than 2 degrees, or the projection changed) since the
+        // last frame on this slot: the lists are emptied and this frame runs in natural order while it measures its
+        // tiles, instead of replaying an order learnt for another view.  (A probe pass that predicts the order of such
+        // a frame - one centre ray per tile - was built and measured in round 3: it is bound by the latency of its
+        // longest ray and costs more than the order gains, profiles/r03_probe_cap.log.)  Variant bit 7 treats every
+        // frame as a cut (bench.py's first-frame leg).
+        bool cut = slot.lpt_key != key || ((variant >> 7) & 1u);
+        if (!cut) {
+            const ViewDev &a = slot.lpt_view, &b = p.views[0];
+            const float ex = a.eye[0] - b.eye[0], ey = a.eye[1] - b.eye[1], ez = a.eye[2] - b.eye[2];
+            const float moved2 = ex * ex + ey * ey + ez * ez, lim = 0.01f * s->scene_diag;
+            const float turn = a.view_inv[8] * b.view_inv[8] + a.view_inv[9] * b.view_inv[9] + a.view_inv[10] * b.view_inv[10];
+            cut = !(moved2 <= lim * lim) || !(turn >= 0.99939f) || std::memcmp(a.proj_inv, b.proj_inv, sizeof(a.proj_inv)) != 0;
+        }
+        slot.lpt_view = p.views[0];
+        if (cut) {
             HIP_TRY(hipMemsetAsync(set[0], 0, n_lists * sizeof(uint32_t), stream));
             HIP_TRY(hipMemsetAsync(set[1], 0, n_lists * sizeof(uint32_t), stream));
             slot.lpt_parity = 0;
@@ -451,9 +469,13 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         p.cost = s->dbg_cost;
         p.tile_iters = s->dbg_iters;
     }
-    bool pipe = false;
+    // The pipelined walk (next node's fetch issued under the triangle phase) pays where a node fetch leaves the L2s:
+    // incoherent passes over scenes larger than the eight L2s together (measured: hairball-class AO -4..-6 %, dense
+    // bistro-class -3 %, a 3 MB kitchen-class scene +4 %; coherent primary rays +-1 %: DESIGN.md section 4).
+    bool pipe = mode != kModePrimary && !s->tlas && s->n_nodes * TRX_NODE_BYTES + s->n_tris * sizeof(TriDev) > (32ull << 20);
 #ifdef TRX_DEV_TUNE
-    pipe = (p.tune & 0x1000u) != 0u;
+    if (p.tune & 0x1000u) pipe = true;
+    if (p.tune & 0x10000u) pipe = false;
 #endif
     HIP_TRY(launch_trace(p, mode, s->tlas, sem, count, pipe, grid, stream));
     HIP_TRY(hipEventRecord(slot.done, stream));
@@ -599,6 +621,15 @@ int trx_scene_create(const void *bvh_bytes, uint64_t n_nodes, const void *tri_by
         s->cu_count = prop.multiProcessorCount;
     }
     s->grid = trace_grid_size(device, 0, s->tlas, 0, false);
+    {   // extent of the root node's quantisation frame (255 steps of 2^(e - 127) per axis): the scene's scale
+        const CwbvhNode &root = ((const CwbvhNode *)bvh_bytes)[s->tlas ? tlas_start : 0];
+        double d2 = 0.0;
+        for (int k = 0; k < 3; k++) {
+            const double ext = 255.0 * std::ldexp(1.0, (int)root.e[k] - 127);
+            d2 += ext * ext;
+        }
+        s->scene_diag = (float)std::sqrt(d2);
+    }
     if (s->grid <= 0) return cleanup(fail(TRX_ERR_NO_DEVICE, "could not size the persistent grid"));
     *out = s;
     return TRX_OK;

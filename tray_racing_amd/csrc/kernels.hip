@@ -358,6 +358,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint2 *const lds_pend = reinterpret_cast<uint2 *>(lds_head + kWave);                   // [kLptPend] {tile, list} to append
     uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave) + lane;
     const bool tie_first = P.tie_first != 0;
+    lds_head[lane] = 0u; // run-head table of the cooperative triangle rounds: tags only grow from here
     if (P.wave_times && lane == 0) P.wave_times[kWaveTimeStride * wave_global] = wall_clock64();
 #ifdef TRX_STAMPS
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
@@ -377,6 +378,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // world-space ray (origin, direction as given) to come back to when the BLAS is left
     uint32_t cur_inst = TRX_INVALID, hit_inst = TRX_INVALID;
     float wox = 0.0f, woy = 0.0f, woz = 0.0f, wdx = 0.0f, wdy = 0.0f, wdz = 0.0f;
+    uint32_t head_tag = 0u; // cooperative triangle windows run so far by this wave (x 128), see triangle_phase
     uint2 cur = make_uint2(0u, 0u);
     // pipelined walk: node in flight / fetched for this lane, and the triangle group its last node test left
     bool fetched = false;
@@ -784,12 +786,19 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     if (COUNT) c_tri += cnt;
                     for (uint32_t base = 0; base < total; base += kWave) {
                         // owner of every pair of this window: heads mark where each owner's run starts
-                        lds_head[lane] = 0u;
-                        __builtin_amdgcn_wave_barrier();
+                        // (a head carries the number of its cooperative window in the bits above the lane, so a head
+                        // left by an earlier window or trip always loses the max-scan to this window's: position 0 of a
+                        // window holds a fresh head, and the table is never cleared)
                         const uint32_t run_begin = max(excl, base), run_end = min(excl + cnt, base + kWave);
-                        if (run_begin < run_end) lds_head[run_begin - base] = lane + 1u;
+                        head_tag += 128u;
+                        if (__builtin_expect(head_tag > 0xffff0000u, 0)) { // (never in practice) tags about to wrap: start over
+                            lds_head[lane] = 0u;
+                            __builtin_amdgcn_wave_barrier();
+                            head_tag = 128u;
+                        }
+                        if (run_begin < run_end) lds_head[run_begin - base] = head_tag + lane + 1u;
                         __builtin_amdgcn_wave_barrier();
-                        const uint32_t owner1 = wave_scan_max(lds_head[lane]);
+                        const uint32_t owner1 = wave_scan_max(lds_head[lane]) & 127u;
                         const uint32_t g = base + lane;
                         if (g < total) {
                             const uint32_t ol = owner1 - 1u;
@@ -1105,6 +1114,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     }
 }
 
+
 template <int MODE, bool TLAS, int NODE, bool PIPE, bool COUNT>
 hipError_t launch_one(const TraceParams &p, int grid, hipStream_t stream) {
     // grid = total waves; p.waves_per_block waves share a workgroup (and nothing else)
@@ -1130,9 +1140,11 @@ hipError_t launch_mode(const TraceParams &p, bool tlas, int node, bool count, bo
         if (count) return launch_node<MODE, true, false, true>(p, node, grid, stream);
         return launch_node<MODE, true, false, false>(p, node, grid, stream);
     }
-    if (pipe) {
-        if (count) return launch_node<MODE, false, true, true>(p, node, grid, stream);
-        return launch_node<MODE, false, true, false>(p, node, grid, stream);
+    if constexpr (MODE != kModePrimary) { // coherent primary rays do not gain from the pipelined walk
+        if (pipe) {
+            if (count) return launch_node<MODE, false, true, true>(p, node, grid, stream);
+            return launch_node<MODE, false, true, false>(p, node, grid, stream);
+        }
     }
     if (count) return launch_node<MODE, false, false, true>(p, node, grid, stream);
     return launch_node<MODE, false, false, false>(p, node, grid, stream);
