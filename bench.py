@@ -122,6 +122,10 @@ def parse():
     ap.add_argument("--gather", default="torch", choices=["torch", "abi"],
                     help="N > 1: the shard gather through torch.distributed (default) or through the C ABI "
                          "(trx_comm_* / trx_gather_shards / trx_assemble_frames: RCCL driven by libtrx.so itself)")
+    ap.add_argument("--gather-to", default="all", choices=["all", "root"],
+                    help="N > 1: every rank gets every frame (in-place all-gather, default) or only rank 0 does (ncclSend / "
+                         "ncclRecv through trx_gather_shards_root with --gather abi, torch.distributed.gather otherwise: "
+                         "1/N of the bytes when one GPU consumes the frames)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the shard gather through host memory (lets N ranks share one GPU in tests)")
     ap.add_argument("--dump-frame", default="", help="rank 0 writes the last timed frame (int64 {t, prim} records, "
@@ -247,6 +251,10 @@ def main():
     if world > 1 and args.gather == "abi" and args.dist_backend == "nccl":
         # one communicator per stream's buffer (RCCL orders the collectives of a communicator on its stream)
         fgs = [D.AbiFrameGather.from_process_group(w, h, torch.device("cuda", local_rank), batch=F) for _ in range(n_streams)]
+    elif world > 1 and args.gather == "abi":
+        # test mode (gloo): the shards are staged through host memory below, the frames are assembled by the ABI's kernel
+        fgs = [D.AbiFrameGather.without_communicator(w, h, rank, world, torch.device("cuda", local_rank), batch=F)
+               for _ in range(n_streams)]
     else:
         fgs = [D.FrameGather(w, h, rank, world, "cuda", batch=F) for _ in range(n_streams)] if world > 1 else []
     frames = [torch.empty(F * n_rays_total, dtype=torch.int64, device="cuda") for _ in range(n_streams)]
@@ -299,18 +307,32 @@ def main():
                     events.append(trace(s, fg.slot(f0, m).data_ptr(), shard_cmp, mm, fg.records))
                 e_g0, e_g1, e_a1 = ev(), ev(), ev()
                 e_g0.record(s)
-                if args.dist_backend == "nccl":
+                to_root = args.gather_to == "root"
+                nrec = m * fg.records
+                if args.dist_backend == "nccl" and to_root and args.gather == "abi":
+                    fg.gather(m=m, root=0)                        # world - 1 sends into rank 0, nothing comes back
+                elif args.dist_backend == "nccl" and to_root:
+                    mine = fg.flat[rank * nrec:(rank + 1) * nrec]
+                    dist.gather(mine, [fg.flat[r * nrec:(r + 1) * nrec] for r in range(world)] if rank == 0 else None, dst=0)
+                elif args.dist_backend == "nccl":
                     work = fg.gather(m=m, async_op=True)         # the one collective: 8 B/ray, m frames at once
                     if work is not None:
                         work.wait()                               # stream s (not the host) waits for it
                 else:  # test mode: the same gather staged through host memory
                     s.synchronize()
-                    nrec = m * fg.records
-                    host = torch.empty(world * nrec, dtype=torch.int64)
-                    dist.all_gather_into_tensor(host, fg.flat[rank * nrec:(rank + 1) * nrec].cpu())
-                    fg.flat[: world * nrec].copy_(host)
+                    mine = fg.flat[rank * nrec:(rank + 1) * nrec].cpu()
+                    if to_root:
+                        parts = [torch.empty(nrec, dtype=torch.int64) for _ in range(world)] if rank == 0 else None
+                        dist.gather(mine, parts, dst=0)
+                        if rank == 0:
+                            fg.flat[: world * nrec].copy_(torch.cat(parts))
+                    else:
+                        host = torch.empty(world * nrec, dtype=torch.int64)
+                        dist.all_gather_into_tensor(host, mine)
+                        fg.flat[: world * nrec].copy_(host)
                 e_g1.record(s)
-                fg.assemble(frames[j][: m * n_rays_total], m=m)
+                if not to_root or rank == 0:
+                    fg.assemble(frames[j][: m * n_rays_total], m=m)
                 e_a1.record(s)
                 if phases is not None:
                     phases.append((e_g0, e_g1, e_a1, m))
@@ -347,6 +369,13 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
+    kernel_ms_ranks = None
+    if world > 1:  # every rank's mean kernel time per frame: the spread says how even the tile deal was
+        mine = torch.tensor([sum(launch_ms) / max(len(launch_ms), 1)], dtype=torch.float64,
+                            device="cuda" if args.dist_backend == "nccl" else "cpu")
+        allk = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allk, mine)
+        kernel_ms_ranks = [float(x[0]) for x in allk]
     rays_per_step = st.n_rays if args.sim_shards > 1 else n_rays_total
     value = rays_per_step * args.steps / elapsed / 1e6
     kernel_ms = sum(launch_ms) / len(launch_ms)
@@ -632,6 +661,9 @@ def main():
             nf = sum(p[3] for p in phases)
             out["phases_ms_per_frame"] = {
                 "trace": round(kernel_ms, 4),
+                "trace_ranks_min": round(min(kernel_ms_ranks), 4) if kernel_ms_ranks else None,
+                "trace_ranks_max": round(max(kernel_ms_ranks), 4) if kernel_ms_ranks else None,
+                "gather_to": args.gather_to,
                 "gather": round(sum(a.elapsed_time(b) for a, b, _, _ in phases) / nf, 4),
                 "assemble": round(sum(b.elapsed_time(c) for _, b, c, _ in phases) / nf, 4),
                 "collective_world_size": fgs[0].world_size() if hasattr(fgs[0], "world_size") else dist.get_world_size(),

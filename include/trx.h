@@ -204,6 +204,15 @@ int trx_scene_device(const trx_scene *scene);
  * (src/cwbvh.rs:151-160). */
 int trx_scene_set_geometry_ranges(trx_scene *scene, const uint32_t *blas_tri_start, uint32_t n_blas);
 
+/* ---- entry nodes (TLAS scenes) -------------------------------------------------
+ * In the reference a TLAS primitive is a whole BLAS: the walk enters at node 0 of the BLAS at instance_offsets[k]
+ * (rt_gpu_software_query_tlas.hlsl:439-443).  entry_nodes[k] lets primitive k enter at another node of that BLAS
+ * instead, so a TLAS can reference SUBTREES (re-braiding: a BLAS spanning the scene is opened into the pieces under its
+ * root, trx_set_build_rebraid / trx_flat.instance_entry_nodes).  Several primitives may name the same BLAS; hit records
+ * are unchanged (primitive ids are global, instance ids are TLAS primitives).  NULL / 0 restores node 0 everywhere; an
+ * entry outside its BLAS is refused (TRX_ERR_FORMAT).  Buffers that come from the reference's host never need this. */
+int trx_scene_set_instance_entry_nodes(trx_scene *scene, const uint32_t *entry_nodes, uint32_t n_instances);
+
 /* ---- instance transforms (TLAS scenes) ----------------------------------------
  * The reference's TLAS path carries no transforms yet: "TODO transform ray according to the mesh transform"
  * (src/rt_gpu/rt_gpu_software_query_tlas.hlsl:409,433), "TODO Reset Ray to untransformed version" (:484), and
@@ -499,6 +508,9 @@ typedef struct trx_flat {
                                   * (trx_flat_build_instanced) TLAS primitive k is */
     float *instance_transforms;  /* n_instances * 16 (object-to-world, column-major) in TLAS-primitive order, ready for
                                   * trx_scene_set_instance_transforms; NULL when no transforms were given */
+    uint32_t *instance_entry_nodes; /* n_instances, ready for trx_scene_set_instance_entry_nodes: the node of its BLAS at
+                                     * which TLAS primitive k starts (re-braided TLAS, trx_set_build_rebraid); NULL when
+                                     * every primitive is a whole BLAS (the reference's layout) */
 } trx_flat;
 int trx_flat_build(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects,
                    int use_tlas, uint32_t max_prims_per_leaf, int threads, trx_flat **out);
@@ -535,6 +547,12 @@ void trx_build_params_default(trx_build_params *params); /* the reference's comm
  * tree the host stage returns (same operations in the same order); reinsertion, collapse and encoding follow on the
  * host either way.  A device failure fails the build (TRX_ERR_NO_DEVICE / TRX_ERR_OOM): nothing falls back silently. */
 int trx_set_build_device(int device);
+/* TLAS of trx_flat_build / trx_flat_build_params (process-wide): a BLAS whose box exceeds `area_fraction` of the scene
+ * box's surface area is referenced through the subtrees under its root instead of as a whole, largest first, as long as
+ * the opened node has inner children only; trx_flat.instance_entry_nodes then names each primitive's entry node.
+ * Default 1/4096; 0 = never (every primitive a whole BLAS, as the reference builds it, src/cwbvh.rs:108-137).  Instanced
+ * builds (trx_flat_build_instanced) are never re-braided. */
+int trx_set_build_rebraid(float area_fraction);
 int trx_flat_build_params(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects,
                           int use_tlas, const trx_build_params *params, int threads, trx_flat **out);
 

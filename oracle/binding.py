@@ -28,7 +28,7 @@ class View(C.Structure):
 class SceneC(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_uint64), ("tris", C.c_void_p), ("n_tris", C.c_uint64),
                 ("instance_offsets", C.c_void_p), ("n_instances", C.c_uint32), ("tlas_start", C.c_uint32),
-                ("instance_w2o", C.c_void_p)]
+                ("instance_w2o", C.c_void_p), ("instance_entry", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -131,7 +131,8 @@ def view_from_bytes(raw):
 class Scene:
     """Oracle scene over the flat buffers (nodes [n,20] u32, tri_verts [n,9] f32)."""
 
-    def __init__(self, nodes, tri_verts=None, instance_offsets=None, tlas_start=0, tri_f16=None, instance_w2o=None):
+    def __init__(self, nodes, tri_verts=None, instance_offsets=None, tlas_start=0, tri_f16=None, instance_w2o=None,
+                 instance_entry=None):
         lib = load()
         self.nodes = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 20)
         if tri_f16 is not None:
@@ -147,13 +148,18 @@ class Scene:
         # world-to-object 3x4 (row-major, 12 floats) per TLAS primitive, or None = identity
         self.w2o = None if instance_w2o is None else np.ascontiguousarray(instance_w2o, dtype=np.float32).reshape(-1, 12)
         assert self.w2o is None or self.w2o.shape[0] == self.inst.size
+        # entry node of every TLAS primitive inside its BLAS (re-braided scenes), or None = node 0
+        self.entry = None if instance_entry is None else np.ascontiguousarray(instance_entry, dtype=np.uint32)
+        assert self.entry is None or self.entry.size == self.inst.size
         self.c = SceneC(_ptr(self.nodes), self.nodes.shape[0], _ptr(self.tris), self.tris.shape[0],
                         _ptr(self.inst) if self.inst.size else None, self.inst.size, int(tlas_start),
-                        _ptr(self.w2o) if self.w2o is not None else None)
+                        _ptr(self.w2o) if self.w2o is not None else None,
+                        _ptr(self.entry) if self.entry is not None else None)
 
     @classmethod
     def from_flat(cls, flat):
-        return cls(flat.nodes, flat.tri_verts, flat.instance_offsets, flat.tlas_start)
+        return cls(flat.nodes, flat.tri_verts, flat.instance_offsets, flat.tlas_start,
+                   instance_entry=getattr(flat, "instance_entry", None))
 
     def trace_primary(self, view, w, h, sem=SEM_HLSL, shard=(0, 1), threads=0, out=None):
         hits = out if out is not None else np.zeros(w * h, dtype=HIT_DTYPE)

@@ -598,7 +598,7 @@ static inline __attribute__((always_inline)) orc_hit traverse_body(const orc_sce
                     }
                     oct_inv4 = orc_octant_inv4(d);
                 }
-                cur.x = 0;
+                cur.x = s->instance_entry ? s->instance_entry[global] : 0; /* a subtree of the BLAS, or its root */
                 cur.y = 0x80000000u;
                 break;
             }
@@ -900,14 +900,14 @@ static void box_grow(boxd *a, const boxd *b) {
 
 static boxd validate_node(vctx *c, uint32_t bvh_offset, uint32_t seg_end, uint32_t idx, int is_tlas, int depth);
 
-static boxd validate_blas_root(vctx *c, uint32_t offset) {
+static boxd validate_blas_root(vctx *c, uint32_t offset, uint32_t entry) {
     /* segment end: next larger instance offset or tlas_start */
     uint32_t end = c->s->tlas_start;
     for (uint32_t i = 0; i < c->s->n_instances; i++) {
         uint32_t o = c->s->instance_offsets[i];
         if (o > offset && o < end) end = o;
     }
-    return validate_node(c, offset, end, 0, 0, 0);
+    return validate_node(c, offset, end, entry, 0, 0);
 }
 
 static boxd validate_node(vctx *c, uint32_t bvh_offset, uint32_t seg_end, uint32_t idx, int is_tlas, int depth) {
@@ -970,7 +970,7 @@ static boxd validate_node(vctx *c, uint32_t bvh_offset, uint32_t seg_end, uint32
                         vfail(c, "instance %llu out of range (%llu)", prim, c->s->n_instances);
                         break;
                     }
-                    boxd b = validate_blas_root(c, c->s->instance_offsets[prim]);
+                    boxd b = validate_blas_root(c, c->s->instance_offsets[prim], c->s->instance_entry ? c->s->instance_entry[prim] : 0);
                     box_grow(&child, &b);
                 } else {
                     if (prim >= c->s->n_tris) {

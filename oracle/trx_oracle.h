@@ -69,6 +69,9 @@ typedef struct orc_scene {
      * (the TODOs at query_tlas.hlsl:409,433,484; get_instance_transform, traversable/src/lib.rs:25-27).  NULL =
      * identity, the reference's behaviour. */
     const float *instance_w2o;
+    /* optional: the node of its BLAS at which TLAS primitive k starts its walk (n_instances entries; re-braided
+     * scenes, trx_scene_set_instance_entry_nodes).  NULL = node 0, the reference's rule (query_tlas.hlsl:443). */
+    const uint32_t *instance_entry;
 } orc_scene;
 
 typedef struct orc_stats {

@@ -37,7 +37,12 @@ def test_built_bvh_is_structurally_sound(trx, orc, name, n, tlas):
     if tlas:
         assert flat.has_tlas and flat.tlas_start > 0
         assert (flat.instance_offsets < flat.tlas_start).all()
-        assert len(set(flat.instance_offsets.tolist())) == flat.instance_offsets.size
+        # a TLAS primitive is a BLAS, or - re-braided (trx_set_build_rebraid, the default) - a subtree of one: the
+        # (BLAS, entry node) pairs are distinct, and every BLAS is referenced
+        entry = flat.instance_entry if flat.instance_entry is not None else np.zeros_like(flat.instance_offsets)
+        pairs = set(zip(flat.instance_offsets.tolist(), entry.tolist()))
+        assert len(pairs) == flat.instance_offsets.size
+        assert len(set(flat.instance_offsets.tolist())) == flat.blas_tri_start.size - 1
         assert flat.blas_tri_start[0] == 0 and flat.blas_tri_start[-1] == flat.n_tris
         assert (np.diff(flat.blas_tri_start.astype(np.int64)) > 0).all()
     else:

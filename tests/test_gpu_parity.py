@@ -677,13 +677,16 @@ def test_fixed_seed_slice_of_the_fuzzer(trx, orc):
     assert cases == 40 and not failures, failures[:3]
 
 
-@pytest.mark.parametrize("world,streams,batch", [(2, 2, 4), (4, 8, 8)])
-def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path, world, streams, batch):
+@pytest.mark.parametrize("world,streams,batch,extra", [(2, 2, 4, []), (4, 8, 8, ["--gather", "abi"]),
+                                                        (2, 2, 4, ["--gather", "abi", "--gather-to", "root"])])
+def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path, world, streams, batch, extra):
     """bench.py's N > 1 path end to end on one GPU: `world` ranks (gloo, shard gather staged through
     host memory) trace their tile shards on device 0 in batches; the frame rank 0 ends up with is
     checked against the oracle here.  world = 4 runs bench.py's own defaults for more than two GPUs (8 streams, 8
     frames per gather); more ranks than that cannot share one GPU box: its process guard allows 6 processes on the
-    card, and this test process is one of them."""
+    card, and this test process is one of them.  With `--gather abi` the frames are de-interleaved by the ABI's own
+    kernel (trx_assemble_frames) from the staged shards - RCCL itself needs one GPU per rank - and `--gather-to root`
+    sends them to rank 0 only."""
     import json
     import socket
     import subprocess
@@ -697,7 +700,7 @@ def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path, world, streams, batch
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps",
            str(batch + 2), "--warmup", "2", "--tris", "150000", "--width", "256", "--height", "136", "--dist-backend", "gloo",
-           "--dump-frame", dump, "--streams", str(streams), "--gather-batch", str(batch)]
+           "--dump-frame", dump, "--streams", str(streams), "--gather-batch", str(batch)] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -707,6 +710,8 @@ def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path, world, streams, batch
     assert d["config"]["frames_per_gather"] == batch   # batch + 2 timed frames = one full batch + a partial one
     ph = d["phases_ms_per_frame"]                    # per-phase times of the N > 1 loop
     assert ph["collective_world_size"] == world and ph["trace"] > 0 and ph["gather"] > 0 and ph["assemble"] > 0
+    assert 0 < ph["trace_ranks_min"] <= ph["trace_ranks_max"] and ph["gather_via"] == (extra[1] if extra else "torch")
+    assert ph["gather_to"] == ("root" if "root" in extra else "all")
     g = np.load(dump + ".scene.npz")
     osc = orc.Scene(g["nodes"], g["tri_verts"], g["instance_offsets"], int(g["tlas_start"]))
     want, _ = osc.trace_primary(orc.view_from_bytes(g["view"].tobytes()), int(g["width"]), int(g["height"]), sem=3)

@@ -69,7 +69,8 @@ class Flat(C.Structure):
                 ("tlas_start", C.c_uint32), ("tri_source", C.POINTER(C.c_uint32)),
                 ("blas_tri_start", C.POINTER(C.c_uint32)), ("n_blas", C.c_uint32), ("blas_build_s", C.c_double),
                 ("tlas_build_s", C.c_double), ("tri_boxes", C.POINTER(C.c_float)),
-                ("instance_source", C.POINTER(C.c_uint32)), ("instance_transforms", C.POINTER(C.c_float))]
+                ("instance_source", C.POINTER(C.c_uint32)), ("instance_transforms", C.POINTER(C.c_float)),
+                ("instance_entry_nodes", C.POINTER(C.c_uint32))]
 
 
 class BuildParams(C.Structure):
@@ -141,6 +142,8 @@ SIGNATURES = {
     "trx_set_build_preset": (_i, [C.c_char_p]),
     "trx_set_build_split": (_i, [_f]),
     "trx_set_build_device": (_i, [_i]),
+    "trx_set_build_rebraid": (_i, [_f]),
+    "trx_scene_set_instance_entry_nodes": (_i, [_P, _P, _u32]),
     "trx_bvh_destroy": (None, [_P]),
     "trx_bvh_node_count": (_u64, [_P]),
     "trx_bvh_prim_count": (_u64, [_P]),

@@ -18,6 +18,7 @@
 #include <exception>
 #include <mutex>
 #include <new>
+#include <queue>
 #include <string>
 #include <thread>
 #include <vector>
@@ -47,6 +48,7 @@ struct BuildSettings {
     uint32_t ploc_depth_threshold = 2, ploc_sort_bits = 64;
     int ploc_device = -1;       // >= 0: the PLOC stage of large builds runs on this HIP device (trx_set_build_device)
     bool reinsert_batched = false;
+    float rebraid_area = 1.0f / 4096.0f; // TLAS: open BLAS subtrees whose box exceeds this share of the scene box's area (0 = never)
 };
 BuildSettings g_build;
 std::mutex g_build_mu;
@@ -131,6 +133,8 @@ struct trx_scene {
     uint4 *d_nodes = nullptr;
     float4 *d_tris = nullptr;
     uint32_t *d_inst = nullptr;
+    uint32_t *d_inst_entry = nullptr;        // entry node per TLAS primitive (re-braided scenes), or null
+    std::vector<uint32_t> h_inst;            // host copy of the instance offsets (entry-node validation)
     uint64_t n_nodes = 0, n_tris = 0;
     uint32_t n_inst = 0, tlas_start = 0;
     bool tlas = false;
@@ -373,6 +377,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.nodes = s->d_nodes;
     p.tris = s->d_tris;
     p.inst = s->d_inst;
+    p.inst_entry = s->d_inst_entry;
     p.inst_xform = s->d_inst_xform;
     p.tlas_start = s->tlas_start;
     p.ctr = slot.ctr;
@@ -609,6 +614,7 @@ int trx_scene_create(const void *bvh_bytes, uint64_t n_nodes, const void *tri_by
     HIP_TRY_S(hipMalloc(&s->d_tris, tris.size() * sizeof(TriDev)));
     HIP_TRY_S(hipMemcpy(s->d_tris, tris.data(), tris.size() * sizeof(TriDev), hipMemcpyHostToDevice));
     uint32_t zero = 0;
+    if (n_instances) s->h_inst.assign(instance_offsets, instance_offsets + n_instances);
     HIP_TRY_S(hipMalloc(&s->d_inst, std::max<uint32_t>(n_instances, 4) * sizeof(uint32_t)));
     HIP_TRY_S(hipMemcpy(s->d_inst, n_instances ? instance_offsets : &zero, (n_instances ? n_instances : 1) * sizeof(uint32_t),
                         hipMemcpyHostToDevice));
@@ -642,6 +648,7 @@ void trx_scene_destroy(trx_scene *s) {
     if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_tris) (void)hipFree(s->d_tris);
     if (s->d_inst) (void)hipFree(s->d_inst);
+    if (s->d_inst_entry) (void)hipFree(s->d_inst_entry);
     if (s->d_scratch_a) (void)hipFree(s->d_scratch_a);
     if (s->d_scratch_b) (void)hipFree(s->d_scratch_b);
     if (s->d_scratch_ia) (void)hipFree(s->d_scratch_ia);
@@ -677,6 +684,44 @@ int trx_scene_device(const trx_scene *s) { return s ? s->device : -1; }
 int trx_scene_set_geometry_ranges(trx_scene *s, const uint32_t *blas_tri_start, uint32_t n_blas) {
     if (!s || (!blas_tri_start && n_blas)) return fail(TRX_ERR_INVALID, "null argument");
     s->blas_tri_start.assign(blas_tri_start, blas_tri_start + n_blas + (n_blas ? 1 : 0));
+    return TRX_OK;
+}
+
+// Entry nodes: TLAS primitive k starts its BLAS walk at node entry_nodes[k] of the BLAS at instance_offsets[k] instead
+// of node 0, so one BLAS can be referenced as several subtrees (re-braiding: a BLAS whose box spans the scene no longer
+// makes every ray enter it at the root).  Validated like the node buffer: an entry must lie inside its BLAS segment.
+int trx_scene_set_instance_entry_nodes(trx_scene *s, const uint32_t *entry_nodes, uint32_t n) {
+    if (!s) return fail(TRX_ERR_INVALID, "null scene");
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu);
+    HIP_TRY(hipSetDevice(s->device));
+    uint32_t *fresh = nullptr;
+    if (entry_nodes && n) {
+        if (!s->tlas) return fail(TRX_ERR_INVALID, "entry nodes need a TLAS scene");
+        if (n != s->n_inst) return fail(TRX_ERR_INVALID, "%u entry nodes for %u instances", n, s->n_inst);
+        std::vector<uint32_t> seg(s->h_inst);
+        std::sort(seg.begin(), seg.end());
+        seg.erase(std::unique(seg.begin(), seg.end()), seg.end());
+        for (uint32_t k = 0; k < n; k++) {
+            auto it = std::upper_bound(seg.begin(), seg.end(), s->h_inst[k]);
+            const uint32_t seg_end = it == seg.end() ? s->tlas_start : *it;
+            if ((uint64_t)s->h_inst[k] + entry_nodes[k] >= seg_end)
+                return fail(TRX_ERR_FORMAT, "instance %u: entry node %u leaves its BLAS [%u, %u)", k, entry_nodes[k], s->h_inst[k], seg_end);
+        }
+        HIP_TRY(hipMalloc(&fresh, (size_t)n * sizeof(uint32_t)));
+        const hipError_t e = hipMemcpy(fresh, entry_nodes, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(fresh);
+            return fail(TRX_ERR_NO_DEVICE, "upload of the entry nodes failed: %s", hipGetErrorString(e));
+        }
+    }
+    uint32_t *old = nullptr;
+    {   // swapped under the launch mutex, freed after every kernel enqueued before the swap has drained
+        std::lock_guard<std::mutex> lock(s->mu);
+        old = s->d_inst_entry;
+        s->d_inst_entry = fresh;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (old) (void)hipFree(old);
     return TRX_OK;
 }
 
@@ -1486,6 +1531,13 @@ int trx_set_build_split(float extra_ratio) {
     return TRX_OK;
 }
 
+int trx_set_build_rebraid(float area_fraction) {
+    if (!(area_fraction >= 0.f) || area_fraction > 1.f) return fail(TRX_ERR_INVALID, "rebraid: area fraction in [0, 1]");
+    std::lock_guard<std::mutex> lock(g_build_mu);
+    g_build.rebraid_area = area_fraction;
+    return TRX_OK;
+}
+
 int trx_set_build_preset(const char *name) {
     // {bins, sweep, reinsertion ratio, iterations, pre-split}: build time against tree quality, like the obvhs
     // presets (which switch pre_split on from slow_build upwards); "" restores the defaults
@@ -1724,7 +1776,7 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             first += cnt;
         }
         blas_tri_start.push_back((uint32_t)(tri_out.size() / 9));
-        std::vector<uint32_t> inst, inst_source;
+        std::vector<uint32_t> inst, inst_source, inst_entry;
         std::vector<float> inst_xf;
         uint32_t tlas_start = 0;
         if (use_tlas) {
@@ -1733,6 +1785,75 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             // its magnitude (the ray is taken to object space by the rounded INVERSE, which does not commute
             // exactly with transforming the box forward)
             std::vector<Aabb> tlas_boxes = blas_aabb;
+            // Re-braiding (own builder only; the reference builds its TLAS over whole BLAS boxes, src/cwbvh.rs:114): a
+            // BLAS whose box is large against the scene is referenced through the subtrees under its root instead -
+            // repeatedly, largest box first, as long as the node has inner children only (a leaf child's triangles
+            // could not be reached through any subtree) - so a floor or a shell that spans the scene stops making
+            // every ray walk it from the root.  Each such TLAS primitive carries the node its walk starts at.
+            std::vector<uint32_t> prim_blas, prim_entry;
+            if (!instance_object && settings.rebraid_area > 0.f && counts.size() > 1) {
+                auto area = [](const Aabb &b) {
+                    const double dx = std::max(0.0, (double)b.mx[0] - b.mn[0]), dy = std::max(0.0, (double)b.mx[1] - b.mn[1]),
+                                 dz = std::max(0.0, (double)b.mx[2] - b.mn[2]);
+                    return 2.0 * (dx * dy + dy * dz + dz * dx);
+                };
+                Aabb scene_box = blas_aabb[0];
+                for (const Aabb &b : blas_aabb)
+                    for (int a = 0; a < 3; a++) { scene_box.mn[a] = std::min(scene_box.mn[a], b.mn[a]); scene_box.mx[a] = std::max(scene_box.mx[a], b.mx[a]); }
+                const double limit = (double)settings.rebraid_area * area(scene_box);
+                struct Item { double a; uint32_t blas, entry; Aabb box; };
+                auto less = [](const Item &x, const Item &y) { return x.a < y.a || (x.a == y.a && (x.blas > y.blas || (x.blas == y.blas && x.entry > y.entry))); };
+                std::priority_queue<Item, std::vector<Item>, decltype(less)> heap(less);
+                std::vector<Item> final_items;
+                for (uint32_t b = 0; b < (uint32_t)blas_aabb.size(); b++) heap.push(Item{area(blas_aabb[b]), b, 0u, blas_aabb[b]});
+                // (measured on the san-miguel-class scene, three views, profiles/r03_rebraid_tlas_variants.log: 16 K / 64 K /
+                // 160 K / 225 K primitives = 3.44 / 2.99 / 3.15 / 4.51 ms against 4.73 ms unopened; beyond ~160 K the
+                // TLAS - a plain binned-SAH tree without the BLAS builder's reinsertion pass - becomes the worse upper tree)
+                const size_t max_prims_tlas = blas_aabb.size() + 262144;
+                // // (instance ids stay far below 2^24 triangle-group indices)
+                while (!heap.empty()) {
+                    Item it = heap.top();
+                    heap.pop();
+                    // (the BLAS nodes were moved into `nodes`; BLAS b starts at blas_offset[b])
+                    const CwbvhNode &n = nodes[(size_t)blas_offset[it.blas] + it.entry];
+                    bool openable = it.a > limit && n.imask != 0 && heap.size() + final_items.size() + 8 <= max_prims_tlas;
+                    for (int sl = 0; sl < 8 && openable; sl++)
+                        if (n.child_meta[sl] != 0 && (n.child_meta[sl] & 0x18) != 0x18) openable = false; // a leaf child
+                    if (!openable) {
+                        final_items.push_back(it);
+                        continue;
+                    }
+                    uint32_t rank = 0;
+                    for (int sl = 0; sl < 8; sl++) {
+                        if (!((n.imask >> sl) & 1u)) continue;
+                        // the child's quantised box, decoded exactly (24-bit origin + 8-bit step count x a power of two
+                        // fits a double) and rounded outwards to f32, clipped to the box it was opened from
+                        Aabb cb;
+                        const uint8_t *qlo[3] = {n.child_min_x, n.child_min_y, n.child_min_z}, *qhi[3] = {n.child_max_x, n.child_max_y, n.child_max_z};
+                        for (int a = 0; a < 3; a++) {
+                            const double ex = std::ldexp(1.0, (int)n.e[a] - 127);
+                            const double lo = (double)n.p[a] + qlo[a][sl] * ex, hi = (double)n.p[a] + qhi[a][sl] * ex;
+                            float flo = (float)lo, fhi = (float)hi;
+                            if ((double)flo > lo) flo = std::nextafterf(flo, -INFINITY);
+                            if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
+                            cb.mn[a] = std::max(flo, it.box.mn[a]);
+                            cb.mx[a] = std::min(fhi, it.box.mx[a]);
+                        }
+                        heap.push(Item{area(cb), it.blas, n.child_base_idx + rank, cb});
+                        rank++;
+                    }
+                }
+                if (final_items.size() > blas_aabb.size()) {
+                    // deterministic order: by BLAS, then entry node
+                    std::sort(final_items.begin(), final_items.end(), [](const Item &x, const Item &y) { return x.blas < y.blas || (x.blas == y.blas && x.entry < y.entry); });
+                    tlas_boxes.clear();
+                    for (const Item &it : final_items) {
+                        tlas_boxes.push_back(it.box);
+                        prim_blas.push_back(it.blas);
+                        prim_entry.push_back(it.entry);
+                    }
+                }
+            }
             if (instance_object) {
                 tlas_boxes.assign(n_instances, Aabb{});
                 for (uint32_t k = 0; k < n_instances; k++) {
@@ -1770,6 +1891,12 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             build_cwbvh_from_aabbs(tlas_boxes.data(), tlas_boxes.size(), bpt, tlas);
             tlas_s = tlas.build_seconds;
             for (uint32_t pi : tlas.primitive_indices) {
+                if (!prim_blas.empty()) { // re-braided: TLAS primitive pi is the subtree at node prim_entry[pi] of BLAS prim_blas[pi]
+                    inst.push_back(blas_offset[prim_blas[pi]]);
+                    inst_source.push_back(prim_blas[pi]);
+                    inst_entry.push_back(prim_entry[pi]);
+                    continue;
+                }
                 inst.push_back(blas_offset[instance_object ? blas_of_object[instance_object[pi]] : pi]);
                 inst_source.push_back(pi);
                 if (instance_o2w) inst_xf.insert(inst_xf.end(), instance_o2w + (size_t)pi * 16, instance_o2w + (size_t)pi * 16 + 16);
@@ -1799,7 +1926,8 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
         f->tlas_build_s = tlas_s;
         f->instance_source = (uint32_t *)dup(inst_source.data(), inst_source.size() * 4);
         f->instance_transforms = inst_xf.empty() ? nullptr : (float *)dup(inst_xf.data(), inst_xf.size() * 4);
-        if (!f->instance_source || (!inst_xf.empty() && !f->instance_transforms)) {
+        f->instance_entry_nodes = inst_entry.empty() ? nullptr : (uint32_t *)dup(inst_entry.data(), inst_entry.size() * 4);
+        if (!f->instance_source || (!inst_xf.empty() && !f->instance_transforms) || (!inst_entry.empty() && !f->instance_entry_nodes)) {
             trx_flat_destroy(f);
             return fail(TRX_ERR_OOM, "host allocation failed");
         }
@@ -1826,6 +1954,7 @@ void trx_flat_destroy(trx_flat *f) {
     std::free(f->tri_boxes);
     std::free(f->instance_source);
     std::free(f->instance_transforms);
+    std::free(f->instance_entry_nodes);
     std::free(f);
 }
 

@@ -72,6 +72,7 @@ struct TraceParams {
     const uint4 *nodes;
     const float4 *tris;
     const uint32_t *inst;
+    const uint32_t *inst_entry; // node of its BLAS at which a TLAS primitive's walk starts (null: node 0, the reference's rule)
     const trx_ray *rays;
     const trx_hit *primary;
     trx_hit *out;

@@ -941,7 +941,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
                             lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
                         }
-                        cur = make_uint2(0u, 0x80000000u);
+                        // the walk of the BLAS starts at its node 0 (query_tlas.hlsl:443) - or, for a TLAS primitive that
+                        // stands for a SUBTREE of its BLAS (re-braided scenes, trx_scene_set_instance_entry_nodes), at
+                        // that subtree's node: the group {child_base = entry, one hit} makes the next node step fetch it
+                        cur = make_uint2(P.inst_entry ? P.inst_entry[gidx] : 0u, 0x80000000u);
                         tri.y = 0u;
                     }
                 }

@@ -148,9 +148,16 @@ class AbiFrameGather(FrameGather):
         from . import _lib as L
         self._L, self._C = L, C
         self._comm = C.c_void_p()
+        if id_bytes is None:
+            return  # no communicator: the caller moves the shards itself (tests: staged through gloo), the ABI assembles
         dev = self.device.index if self.device.index is not None else 0
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(id_bytes))
         L.check(L.load().trx_comm_create(buf, rank, world, dev, C.byref(self._comm)))
+
+    @classmethod
+    def without_communicator(cls, width, height, rank, world, device, batch=1):
+        """Only trx_assemble_frames (and the buffer layout) from the ABI; the shards travel by the caller's means."""
+        return cls(width, height, rank, world, device, None, batch=batch)
 
     @staticmethod
     def unique_id():
@@ -172,15 +179,24 @@ class AbiFrameGather(FrameGather):
         return cls(width, height, rank, world, device, bytes(t.cpu().numpy().tobytes()), batch=batch)
 
     def world_size(self):
+        if not self._comm:
+            return self.world   # no communicator of its own (shards staged by the caller)
         return self._L.load().trx_comm_world_size(self._comm)
 
-    def gather(self, local=None, async_op=False, m=1):
+    def gather(self, local=None, async_op=False, m=1, root=None):
+        """root=None: the in-place all-gather (every rank ends up with every shard); root=r: ncclSend / ncclRecv to
+        rank r only (trx_gather_shards_root), after which only rank r may assemble."""
         if local is not None:
             assert m == 1
             self.slot(0, 1).copy_(local)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._L.check(self._L.load().trx_gather_shards(self._comm, self._C.c_void_p(self.flat.data_ptr()), m * self.records,
-                                                      self._C.c_void_p(stream)))
+        lib = self._L.load()
+        if root is None:
+            self._L.check(lib.trx_gather_shards(self._comm, self._C.c_void_p(self.flat.data_ptr()), m * self.records,
+                                                self._C.c_void_p(stream)))
+        else:
+            self._L.check(lib.trx_gather_shards_root(self._comm, self._C.c_void_p(self.flat.data_ptr()), m * self.records,
+                                                     int(root), self._C.c_void_p(stream)))
         return None  # enqueued on the current stream: nothing to wait for on the host
 
     def assemble(self, out=None, m=1):

@@ -72,7 +72,8 @@ class FlatScene:
     """The buffers rt_gpu_software::start receives: bvh_bytes, tri_bytes, instance_bytes, tlas_start."""
 
     def __init__(self, nodes, tri_verts, instance_offsets, tlas_start, tri_source, blas_tri_start,
-                 blas_build_s=0.0, tlas_build_s=0.0, tri_boxes=None, instance_source=None, instance_transforms=None):
+                 blas_build_s=0.0, tlas_build_s=0.0, tri_boxes=None, instance_source=None, instance_transforms=None,
+                 instance_entry=None):
         self.nodes = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 20)
         self.tri_verts = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
         self.instance_offsets = np.ascontiguousarray(instance_offsets, dtype=np.uint32)
@@ -88,6 +89,8 @@ class FlatScene:
         self.instance_source = None if instance_source is None else np.ascontiguousarray(instance_source, dtype=np.uint32)
         self.instance_transforms = None if instance_transforms is None else np.ascontiguousarray(
             instance_transforms, dtype=np.float32).reshape(-1, 16)
+        # node of its BLAS at which TLAS primitive k starts (re-braided TLAS), or None = node 0 (the reference)
+        self.instance_entry = None if instance_entry is None else np.ascontiguousarray(instance_entry, dtype=np.uint32)
 
     @property
     def n_nodes(self):
@@ -141,7 +144,10 @@ def _take_flat(lib, fp):
         ixf = None
         if f.instance_transforms:
             ixf = np.ctypeslib.as_array(f.instance_transforms, shape=(max(f.n_instances, 1), 16))[: f.n_instances].copy()
-        return FlatScene(nodes, tris, inst, f.tlas_start, src, bts, f.blas_build_s, f.tlas_build_s, boxes, isrc, ixf)
+        ient = None
+        if f.instance_entry_nodes:
+            ient = np.ctypeslib.as_array(f.instance_entry_nodes, shape=(max(f.n_instances, 1),))[: f.n_instances].copy()
+        return FlatScene(nodes, tris, inst, f.tlas_start, src, bts, f.blas_build_s, f.tlas_build_s, boxes, isrc, ixf, ient)
     finally:
         lib.trx_flat_destroy(fp)
 
@@ -219,6 +225,8 @@ class Scene:
                                                       flat.blas_tri_start.size - 1))
         if getattr(flat, "instance_transforms", None) is not None:
             self.set_instance_transforms(flat.instance_transforms)
+        if getattr(flat, "instance_entry", None) is not None:
+            L.check(lib.trx_scene_set_instance_entry_nodes(self._h, _ptr(flat.instance_entry), flat.instance_entry.size))
 
     def set_instance_transforms(self, object_to_world):
         """Object-to-world 4x4 (column-major) per TLAS primitive; None restores identity."""
