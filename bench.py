@@ -302,6 +302,8 @@ def main():
             j = state["batch"] % n_streams
             fg, s = fgs[j], streams[j]
             with torch.cuda.stream(s):
+                if args.dist_backend == "gloo":   # test mode: a launch that leaves a record unwritten must not go unnoticed
+                    fg.flat[rank * m * fg.records:(rank + 1) * m * fg.records].fill_(-1)
                 for f0 in range(0, m, L_launch):
                     mm = min(L_launch, m - f0)
                     events.append(trace(s, fg.slot(f0, m).data_ptr(), shard_cmp, mm, fg.records))
@@ -321,15 +323,19 @@ def main():
                 else:  # test mode: the same gather staged through host memory
                     s.synchronize()
                     mine = fg.flat[rank * nrec:(rank + 1) * nrec].cpu()
+                    if (w % 8 == 0 and h % 8 == 0 and (w // 8) * (h // 8) % world == 0) and bool((mine == -1).any()):
+                        raise SystemExit("rank %d batch %d (%d frames, stream %d): %d of %d records of the shard were never "
+                                         "written" % (rank, state["batch"], m, j, int((mine == -1).sum()), nrec))
                     if to_root:
                         parts = [torch.empty(nrec, dtype=torch.int64) for _ in range(world)] if rank == 0 else None
                         dist.gather(mine, parts, dst=0)
                         if rank == 0:
                             fg.flat[: world * nrec].copy_(torch.cat(parts))
                     else:
-                        host = torch.empty(world * nrec, dtype=torch.int64)
-                        dist.all_gather_into_tensor(host, mine)
-                        fg.flat[: world * nrec].copy_(host)
+                        parts = [torch.empty(nrec, dtype=torch.int64) for _ in range(world)]
+                        dist.all_gather(parts, mine)
+                        fg.flat[: world * nrec].copy_(torch.cat(parts))
+                    s.synchronize()   # the staging tensors are pageable and die with this scope: the copy must have left them
                 e_g1.record(s)
                 if not to_root or rank == 0:
                     fg.assemble(frames[j][: m * n_rays_total], m=m)

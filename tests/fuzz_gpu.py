@@ -110,7 +110,8 @@ def one_case(T, O, rng, case):
     if fmt == T.TRI_F16_24:
         packed = T.pack_tris_f16(flat.tri_verts)
         sc = T.Scene(flat, tri_format=fmt, tri_bytes=packed)
-        osc = O.Scene(flat.nodes, None, flat.instance_offsets, int(flat.tlas_start), tri_f16=packed)
+        osc = O.Scene(flat.nodes, None, flat.instance_offsets, int(flat.tlas_start), tri_f16=packed,
+                      instance_entry=flat.instance_entry)
     elif fmt == T.TRI_EDGES_36:   # {v0, e1, e2} handed over as the oracle derives them
         osc = O.Scene.from_flat(flat)
         sc = T.Scene(flat, tri_format=fmt, tri_bytes=osc.tris.copy())

@@ -328,8 +328,10 @@ __device__ __forceinline__ void flush_pending(const TraceParams &P, const uint2 
     __builtin_amdgcn_wave_barrier();
     if (lane < n) {
         const uint2 e = lds_pend[lane];
-        const uint32_t pos = atomicAdd(&P.lpt_write_counts[e.y], 1u);
-        if (pos < P.lpt_cap) P.lpt_write_lists[(size_t)e.y * P.lpt_cap + pos] = e.x;
+        if (e.y < 16u * kLptShards) { // (a list index can only be out of range if LDS was corrupted: never turn that into a stray global atomic)
+            const uint32_t pos = atomicAdd(&P.lpt_write_counts[e.y], 1u);
+            if (pos < P.lpt_cap) P.lpt_write_lists[(size_t)e.y * P.lpt_cap + pos] = e.x;
+        }
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -358,7 +360,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint2 *const lds_pend = reinterpret_cast<uint2 *>(lds_head + kWave);                   // [kLptPend] {tile, list} to append
     uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave) + lane;
     const bool tie_first = P.tie_first != 0;
-    lds_head[lane] = 0u; // run-head table of the cooperative triangle rounds: tags only grow from here
     if (P.wave_times && lane == 0) P.wave_times[kWaveTimeStride * wave_global] = wall_clock64();
 #ifdef TRX_STAMPS
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
@@ -378,7 +379,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // world-space ray (origin, direction as given) to come back to when the BLAS is left
     uint32_t cur_inst = TRX_INVALID, hit_inst = TRX_INVALID;
     float wox = 0.0f, woy = 0.0f, woz = 0.0f, wdx = 0.0f, wdy = 0.0f, wdz = 0.0f;
-    uint32_t head_tag = 0u; // cooperative triangle windows run so far by this wave (x 128), see triangle_phase
     uint2 cur = make_uint2(0u, 0u);
     // pipelined walk: node in flight / fetched for this lane, and the triangle group its last node test left
     bool fetched = false;
@@ -786,22 +786,19 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     if (COUNT) c_tri += cnt;
                     for (uint32_t base = 0; base < total; base += kWave) {
                         // owner of every pair of this window: heads mark where each owner's run starts
-                        // (a head carries the number of its cooperative window in the bits above the lane, so a head
-                        // left by an earlier window or trip always loses the max-scan to this window's: position 0 of a
-                        // window holds a fresh head, and the table is never cleared)
-                        const uint32_t run_begin = max(excl, base), run_end = min(excl + cnt, base + kWave);
-                        head_tag += 128u;
-                        if (__builtin_expect(head_tag > 0xffff0000u, 0)) { // (never in practice) tags about to wrap: start over
-                            lds_head[lane] = 0u;
-                            __builtin_amdgcn_wave_barrier();
-                            head_tag = 128u;
-                        }
-                        if (run_begin < run_end) lds_head[run_begin - base] = head_tag + lane + 1u;
+                        // (the table is cleared for every window.  Tagging the heads with a window number instead, so
+                        // that stale ones lose the max-scan and the clearing store goes, measured -1 % - and, with
+                        // four processes time-sharing the GPU, launches that left whole work queues untraced; the
+                        // mechanism was not established, the variant is gone: profiles/r03_tagged_heads.log)
+                        lds_head[lane] = 0u;
                         __builtin_amdgcn_wave_barrier();
-                        const uint32_t owner1 = wave_scan_max(lds_head[lane]) & 127u;
+                        const uint32_t run_begin = max(excl, base), run_end = min(excl + cnt, base + kWave);
+                        if (run_begin < run_end) lds_head[run_begin - base] = lane + 1u;
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t owner1 = wave_scan_max(lds_head[lane]);
                         const uint32_t g = base + lane;
                         if (g < total) {
-                            const uint32_t ol = owner1 - 1u;
+                            const uint32_t ol = (owner1 - 1u) & 63u; // (owner1 is 1..64; the mask keeps a corrupted table inside this wave's LDS)
                             const uint2 grp = lds_grp[ol];
                             const uint32_t local = select_from_top(grp.y, g - lds_pref[ol]);
                             const uint32_t gidx = grp.x + local;
