@@ -755,3 +755,32 @@ def test_scheduling_variants_and_streams_do_not_change_results(trx, orc):
     finally:
         lib.trx_set_kernel_variant(0)
         sc.close()
+
+
+def test_camera_cuts_reset_the_tile_order_and_never_the_hits(trx, orc):
+    """A learnt tile order belongs to a view: alternating between two unrelated cameras (every frame a cut: natural
+    order while the tiles are measured), drifting slowly (the previous frame's order is replayed), and variant bit 7
+    (every frame treated as a cut) only change WHEN tiles are traced - each frame equals the oracle's."""
+    w, h = 328, 200
+    flat, view, osc, ov = make_scene(trx, orc, "bistro", 150000, w, h)
+    eye, look, fov = trx.scene_camera("bistro")
+    far = trx.view_from_camera((eye[0] + 14.0, eye[1] + 6.0, eye[2] - 5.0), (look[0] - 20.0, look[1] - 3.0, look[2] + 9.0), 55.0, w, h)
+    want = {0: osc.trace_primary(ov, w, h, sem=3)[0], 1: osc.trace_primary(orc.view_from_bytes(bytes(far)), w, h, sem=3)[0]}
+    sc = trx.Scene(flat)
+    lib = trx.load()
+    try:
+        for k in range(8):                       # A B A B ...: a cut every frame
+            got = sc.trace_primary(far if k & 1 else view, w, h, sem=3)[0]
+            assert_hits_equal(got, want[k & 1], "alternating cameras, frame %d" % k)
+        for k in range(4):                       # the same view again: learnt order
+            assert_hits_equal(sc.trace_primary(view, w, h, sem=3)[0], want[0], "static camera, frame %d" % k)
+        for k in range(6):                       # a slow drift: below the cut thresholds, the stale order is replayed
+            v = trx.view_from_camera((eye[0] + 0.01 * k, eye[1], eye[2]), (look[0] + 0.01 * k, look[1], look[2]), fov, w, h)
+            assert_hits_equal(sc.trace_primary(v, w, h, sem=3)[0], osc.trace_primary(orc.view_from_bytes(bytes(v)), w, h, sem=3)[0],
+                              "drifting camera, frame %d" % k)
+        lib.trx_set_kernel_variant(1 << 7)
+        for k in range(3):
+            assert_hits_equal(sc.trace_primary(view, w, h, sem=3)[0], want[0], "every frame a cut, frame %d" % k)
+    finally:
+        lib.trx_set_kernel_variant(0)
+        sc.close()

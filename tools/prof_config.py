@@ -16,6 +16,7 @@ CONFIGS = {
     # name: (scene, mode, width, height, tlas)
     "primary_bistro": ("bistro", "primary", 1920, 1080, False),
     "primary_bistro_dense": ("bistro_dense", "primary", 1920, 1080, False),
+    "primary_kitchen": ("kitchen", "primary", 1920, 1080, False),
     "primary_hairball": ("hairball", "primary", 1920, 1080, False),
     "ao_bistro": ("bistro", "ao", 1920, 1080, False),
     "ao_hairball": ("hairball", "ao", 1920, 1080, False),

@@ -111,6 +111,11 @@ struct Slot {
     uint32_t lpt_parity = 0; // set written by the next frame
     uint64_t lpt_key = 0;    // (width, height, shard, mode) the lists were measured for; 0 = none
     ViewDev lpt_view{};      // view of the last frame that read or wrote the lists (camera-cut detection)
+    // AO passes: per-tile trip counts of the last pass + one set of lists for the next (long rays first, launch_ao_bin)
+    uint32_t *ao_buf = nullptr;
+    uint32_t ao_capacity = 0;
+    uint64_t ao_key = 0;
+    ViewDev ao_view{};
 };
 
 } // namespace
@@ -409,6 +414,15 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         p.tri_coop_ratio = r == 0u ? 2u : r == 7u ? 0u : r;
     }
     p.waves_per_block = wpb;
+    // Decode-once node test on wave-uniform node steps (kernels.hip, node_intersect_dec): pays where almost every step is
+    // uniform - a scene small enough for the L2s, seen by coherent primary rays (kitchen-class frame -4 %, 90 % of its
+    // steps uniform) - is neutral on the bistro-class frame (-1 %, 47 %) and costs 1-2 % on the dense and hairball-class
+    // ones, whose steps rarely are (profiles/r03_decode_once.log): on for scenes up to the eight L2s' 32 MiB.
+    p.uni_decode = (mode == kModePrimary && !s->tlas && s->n_nodes * TRX_NODE_BYTES + s->n_tris * sizeof(TriDev) <= (32ull << 20)) ? 1u : 0u;
+#ifdef TRX_DEV_TUNE
+    if (p.tune & 0x40000u) p.uni_decode = 1u;
+    if (p.tune & 0x80000u) p.uni_decode = 0u;
+#endif
     p.wave_times = s->d_wave_times;
     p.single_queue = (variant >> 21) & 1u;
     // tile order feedback (image modes, whole-tile refills only)
@@ -467,6 +481,47 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
                                             {128, 0, 0}, {128, 32, 8}, {1024, 256, 64}};
         const uint32_t *c = cuts[(variant >> 22) & 7u];
         for (int i = 0; i < 3; i++) p.prio_cut[i] = c[i] ? n_tiles / c[i] : 0u;
+    }
+    // AO passes (whole image or shard, one frame per launch): the rays of a tile are started in scan order unless the last
+    // pass on this slot - same geometry, same view, any frame seed - was as long as its longest ray; then the tiles are
+    // dealt heaviest step class first.  Measured (profiles/r03_ao_long_rays_first.log) on the hairball-class frame, whose
+    // AO rays take 39 steps on average and 340 at most; scenes whose passes are bound by their work never switch it on.
+    if (mode == kModeAo && p.n_frames == 1 && !((variant >> 20) & 1u) && !s->dbg_cost) {
+        const uint32_t n_lists = 16 * kLptShards;
+        const uint32_t list_cap = n_tiles / 2 + 64;
+        const size_t words = (size_t)n_tiles + n_lists + (size_t)n_lists * list_cap;
+        if (slot.ao_capacity != n_tiles) {
+            if (slot.ao_buf) (void)hipFree(slot.ao_buf);
+            slot.ao_buf = nullptr;
+            slot.ao_capacity = 0;
+            slot.ao_key = 0;
+            HIP_TRY(hipMalloc(&slot.ao_buf, words * sizeof(uint32_t)));
+            slot.ao_capacity = n_tiles;
+        }
+        uint32_t *steps = slot.ao_buf, *counts = steps + n_tiles, *lists = counts + n_lists;
+        const uint64_t akey = ((uint64_t)p.width << 40) ^ ((uint64_t)p.height << 20) ^ ((uint64_t)p.shard_count << 8) ^ p.shard_index ^
+                              ((uint64_t)p.compact << 62);
+        bool cut = slot.ao_key != akey || ((variant >> 7) & 1u);
+        if (!cut) {
+            const ViewDev &a = slot.ao_view, &b = p.views[0];
+            const float ex = a.eye[0] - b.eye[0], ey = a.eye[1] - b.eye[1], ez = a.eye[2] - b.eye[2];
+            const float moved2 = ex * ex + ey * ey + ez * ez, lim = 0.01f * s->scene_diag;
+            const float turn = a.view_inv[8] * b.view_inv[8] + a.view_inv[9] * b.view_inv[9] + a.view_inv[10] * b.view_inv[10];
+            cut = !(moved2 <= lim * lim) || !(turn >= 0.99939f) || std::memcmp(a.proj_inv, b.proj_inv, sizeof(a.proj_inv)) != 0;
+        }
+        slot.ao_view = p.views[0];
+        slot.ao_key = akey;
+        if (cut) {
+            HIP_TRY(hipMemsetAsync(steps, 0, ((size_t)n_tiles + n_lists) * sizeof(uint32_t), stream));
+        } else {
+            // lane slots the pass effectively has: the resident waves at about half their lanes
+            HIP_TRY(launch_ao_bin(steps, counts, lists, list_cap, n_tiles, slot.ctr, (uint32_t)grid * 32u, stream));
+            p.lpt_read_counts = counts;
+            p.lpt_read_lists = lists;
+            p.lpt_cap = list_cap;
+        }
+        HIP_TRY(hipMemsetAsync(&slot.ctr->ao_sum_steps, 0, 16, stream));
+        p.ao_steps = steps;
     }
     if (s->dbg_cost) { // diagnostics: cold tile order, costs / iteration counts into the caller's buffers
         p.lpt_read_counts = nullptr;
@@ -660,6 +715,7 @@ void trx_scene_destroy(trx_scene *s) {
         if (sl.ctr) (void)hipFree(sl.ctr);
         if (sl.spill) (void)hipFree(sl.spill);
         if (sl.lpt) (void)hipFree(sl.lpt);
+        if (sl.ao_buf) (void)hipFree(sl.ao_buf);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -675,6 +731,7 @@ uint64_t trx_scene_device_bytes(const trx_scene *s) {
     for (const Slot &sl : s->slots) {
         bytes += (uint64_t)sl.spill_waves * kSpillStack * kWave * sizeof(uint2);
         if (sl.lpt) bytes += 2ull * (16 * kLptShards + (uint64_t)16 * kLptShards * (sl.lpt_capacity / 2 + 64)) * sizeof(uint32_t);
+        if (sl.ao_buf) bytes += ((uint64_t)sl.ao_capacity + 16 * kLptShards + (uint64_t)16 * kLptShards * (sl.ao_capacity / 2 + 64)) * sizeof(uint32_t);
         if (sl.ctr) bytes += sizeof(SlotCounters);
     }
     return bytes;

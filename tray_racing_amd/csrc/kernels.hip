@@ -150,6 +150,68 @@ __device__ __forceinline__ uint32_t node_intersect(const Ray &r, float max_dista
     return hit_mask;
 }
 
+// The same test over child planes that were converted to floats ONCE for the wave (a wave-uniform node step: every
+// lane visits the same node, so the 48 byte-to-float conversions and the 12 near / far selects of the per-lane test are
+// the same work 64 times over).  dec = [6 planes: min_x max_x min_y max_y min_z max_z][8 children] floats in LDS; a lane
+// picks its near and far plane of an axis by ADDRESS (the sign of its direction) and reads four children at a time -
+// every lane of a sign class reads the same 16 bytes, which LDS broadcasts.  Same values, same operations, same mask.
+template <int NODE>
+__device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_distance, const uint4 n0, const uint4 n1,
+                                                       const float *dec) {
+    const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
+    const uint32_t e_imask = n0.w;
+    const float ex = __uint_as_float((e_imask & 0xffu) << 23);
+    const float ey = __uint_as_float(((e_imask >> 8) & 0xffu) << 23);
+    const float ez = __uint_as_float(((e_imask >> 16) & 0xffu) << 23);
+    float ax, ay, az, bx, by, bz;
+    if (NODE & 1) {
+        ax = ex * r.ix;
+        ay = ey * r.iy;
+        az = ez * r.iz;
+        bx = (px - r.ox) * r.ix;
+        by = (py - r.oy) * r.iy;
+        bz = (pz - r.oz) * r.iz;
+    } else {
+        ax = ex / r.dx;
+        ay = ey / r.dy;
+        az = ez / r.dz;
+        bx = (px - r.ox) / r.dx;
+        by = (py - r.oy) / r.dy;
+        bz = (pz - r.oz) / r.dz;
+    }
+    // plane p of the table starts at float 8 p; near plane of an axis = its max plane when the direction is negative
+    const uint32_t xn = r.dx < 0.0f ? 8u : 0u, yn = r.dy < 0.0f ? 24u : 16u, zn = r.dz < 0.0f ? 40u : 32u;
+    const uint32_t xf = xn ^ 8u, yf = yn ^ 8u, zf = zn ^ 8u;
+    uint32_t hit_mask = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t meta4 = i == 0 ? n1.z : n1.w;
+        const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+        const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+        const uint32_t bit_index4 = (meta4 ^ (r.oct_inv4 & inner_mask4)) & 0x1f1f1f1fu;
+        const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+        const float4 qxn = *reinterpret_cast<const float4 *>(dec + xn + 4 * i), qxf = *reinterpret_cast<const float4 *>(dec + xf + 4 * i);
+        const float4 qyn = *reinterpret_cast<const float4 *>(dec + yn + 4 * i), qyf = *reinterpret_cast<const float4 *>(dec + yf + 4 * i);
+        const float4 qzn = *reinterpret_cast<const float4 *>(dec + zn + 4 * i), qzf = *reinterpret_cast<const float4 *>(dec + zf + 4 * i);
+        const float an[4][3] = {{qxn.x, qyn.x, qzn.x}, {qxn.y, qyn.y, qzn.y}, {qxn.z, qyn.z, qzn.z}, {qxn.w, qyn.w, qzn.w}};
+        const float af[4][3] = {{qxf.x, qyf.x, qzf.x}, {qxf.y, qyf.y, qzf.y}, {qxf.z, qyf.z, qzf.z}, {qxf.w, qyf.w, qzf.w}};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f32x2 tx = plane2<NODE>(f32x2{an[j][0], af[j][0]}, ax, bx);
+            const f32x2 ty = plane2<NODE>(f32x2{an[j][1], af[j][1]}, ay, by);
+            const f32x2 tz = plane2<NODE>(f32x2{an[j][2], af[j][2]}, az, bz);
+            const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0001f);
+            const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), max_distance);
+            if (tmin <= tmax) {
+                const uint32_t child_bits = (child_bits4 >> (8 * j)) & 0xffu;
+                const uint32_t bit_index = (bit_index4 >> (8 * j)) & 0xffu;
+                hit_mask |= child_bits << bit_index;
+            }
+        }
+    }
+    return hit_mask;
+}
+
 // TriDev = {v0, e1 = v0 - v1, e2 = v2 - v0} as three float4; ng = cross(e1, e2) (query.hlsl:93) rides in the
 // w lanes, evaluated at upload exactly as written there.
 template <bool EARLY = false>
@@ -358,6 +420,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint32_t *const lds_pref = reinterpret_cast<uint32_t *>(lds_res + kWave);              // [64] first pair of the lane
     uint32_t *const lds_head = lds_pref + kWave;                                           // [64] run starts of a window
     uint2 *const lds_pend = reinterpret_cast<uint2 *>(lds_head + kWave);                   // [kLptPend] {tile, list} to append
+    float *const lds_dec = reinterpret_cast<float *>(lds_pend + kLptPend);                 // [6][8] decoded child planes of a wave-uniform node step
     uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave) + lane;
     const bool tie_first = P.tie_first != 0;
     if (P.wave_times && lane == 0) P.wave_times[kWaveTimeStride * wave_global] = wall_clock64();
@@ -374,6 +437,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     float t = 0.0f;
     uint32_t prim = TRX_INVALID, out_index = 0, sp = 0, steps = 0;
     uint32_t trip = 0; // traversal-loop trips of this wave (uniform)
+    uint32_t ao_sum = 0, ao_max = 0; // AO passes: trips lived by this lane's finished rays (sum, largest)
     uint32_t tlas_sp = TRX_INVALID, bvh_off = 0;
     // instance transforms (TLAS): the instance being walked / the one the current hit was found in, and the
     // world-space ray (origin, direction as given) to come back to when the BLAS is left
@@ -839,6 +903,15 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 
 
 
+        // AO passes: how many trips the finished ray lived (its node steps), kept per tile as a maximum and per lane as a
+        // sum / maximum: the next AO pass on this slot starts the tiles of long rays first when the longest ray, not the
+        // amount of work, set this pass's length (launch_ao_bin)
+        auto note_ao_steps = [&]() {
+            const uint32_t lived = trip - steps;
+            atomicMax(&P.ao_steps[my_tile], lived);
+            ao_sum += lived;
+            ao_max = max(ao_max, lived);
+        };
         // Finished ray: the hit record (or the any-hit flag) leaves the lane.
         auto finish_lane = [&]() {
             if (MODE == kModeRays && P.any_hit != 0u) {
@@ -853,6 +926,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 c_rays++;
                 c_hits += prim != TRX_INVALID;
             }
+            if (MODE == kModeAo && P.ao_steps) note_ao_steps();
             c_over += overflow;
             has_ray = false;
         };
@@ -862,7 +936,43 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 const bool act = has_ray;
                 uint2 tri = make_uint2(0u, 0u);
                 trip++;
-                if (act) {
+                // Coherent primary rays (BLAS only): when every lane that steps visits the SAME node - 47 % of the wave-level
+                // node steps on the bistro-class frame, 90 % on the kitchen-class one - its 48 quantised plane bytes are
+                // converted once, one byte per lane, parked in LDS as floats and read back by address (node_intersect_dec)
+                constexpr bool kUni = !TLAS && MODE == kModePrimary && !COUNT;
+                bool uni_done = false;
+                if constexpr (kUni) {
+                    if (P.uni_decode) {
+                        uint32_t node_index = 0u, child_bit = 0u;
+                        if (act) {
+                            const uint32_t hits_imask = cur.y;
+                            child_bit = 31u - (uint32_t)__builtin_clz(hits_imask);
+                            const uint32_t slot = (child_bit - 24u) ^ (r.oct_inv4 & 0xffu);
+                            node_index = cur.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
+                        }
+                        const unsigned long long stepping = __ballot(act);
+                        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)node_index, (int)(__ffsll((long long)stepping) - 1));
+                        if (__ballot(act && node_index != first) == 0ull) { // wave-uniform: every lane takes this branch or none does
+                            const uint4 *np = P.nodes + (size_t)first * 5;
+                            // 48 lanes convert one byte each (whether or not they hold a ray), LDS hands the floats to all
+                            if (lane < 48u) lds_dec[lane] = (float)reinterpret_cast<const uint8_t *>(np)[32u + lane];
+                            __builtin_amdgcn_wave_barrier();
+                            if (act) {
+                                const uint4 n0 = np[0], n1 = np[1];
+                                cur.y &= ~(1u << child_bit);
+                                stack_push(cur, (cur.y & 0xff000000u) != 0u);
+                                const uint32_t hitmask = node_intersect_dec<NODE>(r, t, n0, n1, lds_dec);
+                                cur.x = n1.x;
+                                tri.x = n1.y;
+                                cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                                tri.y = hitmask & 0x00ffffffu;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            uni_done = true;
+                        }
+                    }
+                }
+                if (act && !uni_done) {
                     // BLAS-only: a lane at the top of the loop always holds a node group (triangle groups are drained
                     // in the trip that found them; only the TLAS walk parks them on the stack)
                     if (!TLAS || (cur.y & 0xff000000u)) {
@@ -1000,6 +1110,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             c_rays++;
                             c_hits += prim != TRX_INVALID;
                         }
+                        if (MODE == kModeAo && P.ao_steps) note_ao_steps();
                         c_over += overflow;
                         has_ray = false;
                     }
@@ -1085,6 +1196,16 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // ---- epilogue: flags, counters, queue reset ---------------------------------------
     if (P.lpt_write_counts && n_pend) flush_pending(P, lds_pend, n_pend, lane);
     if (c_over) atomicAdd(&P.ctr->overflow, c_over);
+    if (MODE == kModeAo && P.ao_steps) {
+        for (int off = 32; off > 0; off >>= 1) {
+            ao_sum += (uint32_t)__shfl_xor((int)ao_sum, off);
+            ao_max = max(ao_max, (uint32_t)__shfl_xor((int)ao_max, off));
+        }
+        if (lane == 0) {
+            atomicAdd(&P.ctr->ao_sum_steps, (unsigned long long)ao_sum);
+            atomicMax(&P.ctr->ao_max_steps, ao_max);
+        }
+    }
     if (COUNT) {
         atomicAdd(&P.ctr->n_rays, (unsigned long long)c_rays);
         atomicAdd(&P.ctr->n_node, (unsigned long long)c_node);
@@ -1114,6 +1235,25 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     }
 }
 
+
+// One thread per tile of the coming AO pass (see launch_ao_bin in kernels.h).
+__global__ void __launch_bounds__(256) k_ao_bin(uint32_t *steps, uint32_t *counts, uint32_t *lists, uint32_t list_cap,
+                                                uint32_t n_tiles, const SlotCounters *ctr, uint32_t slots) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= n_tiles) return;
+    const uint32_t c = steps[tile];
+    steps[tile] = 0u;
+    // was the last pass as long as its longest ray (rather than as long as its work spread over the lane slots)?
+    if ((unsigned long long)ctr->ao_max_steps * slots <= ctr->ao_sum_steps) return;
+    // class = half-octaves of the step count, 16 classes, 362 steps and more in the heaviest
+    const uint32_t v = max(c, 1u);
+    const uint32_t msb = 31u - (uint32_t)__clz((int)v);
+    const uint32_t kk = 2u * msb + (msb ? (v >> (msb - 1u)) & 1u : 0u);
+    const uint32_t b = kk < 2u ? 0u : min(kk - 2u, 15u);
+    const uint32_t list = b * kLptShards + (tile & (kLptShards - 1u));
+    const uint32_t pos = atomicAdd(&counts[list], 1u);
+    if (pos < list_cap) lists[(size_t)list * list_cap + pos] = tile;
+}
 
 template <int MODE, bool TLAS, int NODE, bool PIPE, bool COUNT>
 hipError_t launch_one(const TraceParams &p, int grid, hipStream_t stream) {
@@ -1176,6 +1316,12 @@ int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count) {
     if (per_cu <= 0) per_cu = 8;
     if (per_cu > 32) per_cu = 32;
     return per_cu * prop.multiProcessorCount;
+}
+
+hipError_t launch_ao_bin(uint32_t *steps, uint32_t *counts, uint32_t *lists, uint32_t list_cap, uint32_t n_tiles,
+                         const SlotCounters *ctr, uint32_t slots, hipStream_t stream) {
+    hipLaunchKernelGGL(k_ao_bin, dim3((n_tiles + 255u) / 256u), dim3(256), 0, stream, steps, counts, lists, list_cap, n_tiles, ctr, slots);
+    return hipGetLastError();
 }
 
 hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, bool pipe, int grid,
