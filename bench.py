@@ -128,6 +128,7 @@ def parse():
                          "1/N of the bytes when one GPU consumes the frames)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the shard gather through host memory (lets N ranks share one GPU in tests)")
+    ap.add_argument("--kernel-variant", default="0", help="trx_set_kernel_variant word (tuning / A-B runs; 0 = the product's defaults)")
     ap.add_argument("--dump-frame", default="", help="rank 0 writes the last timed frame (int64 {t, prim} records, "
                                                       ".npy) here, with the scene's flat buffers next to it (tests)")
     return ap.parse_args()
@@ -215,6 +216,7 @@ def main():
                              % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     lib = T.load()
+    lib.trx_set_kernel_variant(int(args.kernel_variant, 0))
     if args.dist_backend == "gloo":
         local_rank = 0  # test mode: every rank drives GPU 0
     if lib.trx_device_count() <= local_rank:

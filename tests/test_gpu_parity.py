@@ -781,6 +781,13 @@ def test_camera_cuts_reset_the_tile_order_and_never_the_hits(trx, orc):
         lib.trx_set_kernel_variant(1 << 7)
         for k in range(3):
             assert_hits_equal(sc.trace_primary(view, w, h, sem=3)[0], want[0], "every frame a cut, frame %d" % k)
+        # the feedback tunes itself: 24 frames with it, 4 without, then the faster mode holds - whichever mode a frame
+        # runs in, and across the switches, the hits are the oracle's
+        lib.trx_set_kernel_variant(0)
+        for k in range(40):
+            got = sc.trace_primary(view, w, h, sem=3)[0]
+            if k % 3 == 0 or 20 <= k < 34:
+                assert_hits_equal(got, want[0], "self-tuning feedback, frame %d" % k)
     finally:
         lib.trx_set_kernel_variant(0)
         sc.close()

@@ -111,11 +111,6 @@ struct Slot {
     uint32_t lpt_parity = 0; // set written by the next frame
     uint64_t lpt_key = 0;    // (width, height, shard, mode) the lists were measured for; 0 = none
     ViewDev lpt_view{};      // view of the last frame that read or wrote the lists (camera-cut detection)
-    // AO passes: per-tile trip counts of the last pass + one set of lists for the next (long rays first, launch_ao_bin)
-    uint32_t *ao_buf = nullptr;
-    uint32_t ao_capacity = 0;
-    uint64_t ao_key = 0;
-    ViewDev ao_view{};
 };
 
 } // namespace
@@ -343,7 +338,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     const bool same_stream = slot.used && slot.last_stream == stream;
     const uint32_t variant = g_variant.load(std::memory_order_relaxed);
     // tuning overrides (trx_set_kernel_variant): bits 8..15 waves per CU, bits 16..19 waves per workgroup
-    uint32_t wpb = (variant >> 16) & 0xfu;
+    uint32_t wpb = (variant >> 16) & 0x7u; // (bit 19: the tile-order feedback does not tune itself off, see below)
     if (wpb != 1 && wpb != 2 && wpb != 4) wpb = kDefaultWavesPerBlock;
     const uint32_t per_cu = (variant >> 8) & 0xffu;
     int grid = per_cu ? (int)(std::min(per_cu, 32u) * (uint32_t)s->cu_count) : s->grid;
@@ -357,7 +352,13 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         SlotCounters *ctr = nullptr;
         hipEvent_t done = nullptr;
         HIP_TRY(hipMalloc(&ctr, sizeof(SlotCounters)));
-        hipError_t e = hipMemset(ctr, 0, sizeof(SlotCounters));
+        // On the LAUNCH stream: hipMemset returns before a device-side fill has run and orders it on the null stream only,
+        // which a non-blocking user stream does not wait for - the first kernel of a slot could start, take tickets and
+        // count exiting waves, and THEN have its queue heads and exit ticket zeroed under it (chunks dealt twice, the exit
+        // ticket never reaching the grid size, the heads never re-armed: the next launch on the slot finds every queue dry
+        // and writes nothing).  Seen once four processes time-shared the GPU; found by the sentinel check of bench.py's
+        // test mode (profiles/r03_slot_init_race.log).
+        hipError_t e = hipMemsetAsync(ctr, 0, sizeof(SlotCounters), stream);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
         if (e != hipSuccess) {
             (void)hipFree(ctr);
@@ -436,6 +437,8 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         const uint32_t list_cap = n_tiles / 2 + 64; // a list holds ~1/8 of one bucket; overflow only drops the order
         const size_t set_words = n_lists + (size_t)n_lists * list_cap;
         if (slot.lpt_capacity != n_tiles) {
+            // (the slot's previous kernel may still be appending to the old lists: wait for it before they go)
+            if (slot.lpt && slot.used) HIP_TRY(hipEventSynchronize(slot.done));
             if (slot.lpt) (void)hipFree(slot.lpt);
             slot.lpt = nullptr;
             slot.lpt_capacity = 0;
@@ -462,7 +465,10 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
             cut = !(moved2 <= lim * lim) || !(turn >= 0.99939f) || std::memcmp(a.proj_inv, b.proj_inv, sizeof(a.proj_inv)) != 0;
         }
         slot.lpt_view = p.views[0];
+        p.fb_auto = (s->dbg_cost || ((variant >> 19) & 1u)) ? 0u : 1u; // (variant bit 19: feedback always on, for A/B runs)
         if (cut) {
+            // a new view measures afresh: feedback on, phase restarted
+            HIP_TRY(hipMemsetAsync(&slot.ctr->fb_t0, 0, sizeof(unsigned long long) + 6 * sizeof(unsigned int), stream));
             HIP_TRY(hipMemsetAsync(set[0], 0, n_lists * sizeof(uint32_t), stream));
             HIP_TRY(hipMemsetAsync(set[1], 0, n_lists * sizeof(uint32_t), stream));
             slot.lpt_parity = 0;
@@ -481,47 +487,6 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
                                             {128, 0, 0}, {128, 32, 8}, {1024, 256, 64}};
         const uint32_t *c = cuts[(variant >> 22) & 7u];
         for (int i = 0; i < 3; i++) p.prio_cut[i] = c[i] ? n_tiles / c[i] : 0u;
-    }
-    // AO passes (whole image or shard, one frame per launch): the rays of a tile are started in scan order unless the last
-    // pass on this slot - same geometry, same view, any frame seed - was as long as its longest ray; then the tiles are
-    // dealt heaviest step class first.  Measured (profiles/r03_ao_long_rays_first.log) on the hairball-class frame, whose
-    // AO rays take 39 steps on average and 340 at most; scenes whose passes are bound by their work never switch it on.
-    if (mode == kModeAo && p.n_frames == 1 && !((variant >> 20) & 1u) && !s->dbg_cost) {
-        const uint32_t n_lists = 16 * kLptShards;
-        const uint32_t list_cap = n_tiles / 2 + 64;
-        const size_t words = (size_t)n_tiles + n_lists + (size_t)n_lists * list_cap;
-        if (slot.ao_capacity != n_tiles) {
-            if (slot.ao_buf) (void)hipFree(slot.ao_buf);
-            slot.ao_buf = nullptr;
-            slot.ao_capacity = 0;
-            slot.ao_key = 0;
-            HIP_TRY(hipMalloc(&slot.ao_buf, words * sizeof(uint32_t)));
-            slot.ao_capacity = n_tiles;
-        }
-        uint32_t *steps = slot.ao_buf, *counts = steps + n_tiles, *lists = counts + n_lists;
-        const uint64_t akey = ((uint64_t)p.width << 40) ^ ((uint64_t)p.height << 20) ^ ((uint64_t)p.shard_count << 8) ^ p.shard_index ^
-                              ((uint64_t)p.compact << 62);
-        bool cut = slot.ao_key != akey || ((variant >> 7) & 1u);
-        if (!cut) {
-            const ViewDev &a = slot.ao_view, &b = p.views[0];
-            const float ex = a.eye[0] - b.eye[0], ey = a.eye[1] - b.eye[1], ez = a.eye[2] - b.eye[2];
-            const float moved2 = ex * ex + ey * ey + ez * ez, lim = 0.01f * s->scene_diag;
-            const float turn = a.view_inv[8] * b.view_inv[8] + a.view_inv[9] * b.view_inv[9] + a.view_inv[10] * b.view_inv[10];
-            cut = !(moved2 <= lim * lim) || !(turn >= 0.99939f) || std::memcmp(a.proj_inv, b.proj_inv, sizeof(a.proj_inv)) != 0;
-        }
-        slot.ao_view = p.views[0];
-        slot.ao_key = akey;
-        if (cut) {
-            HIP_TRY(hipMemsetAsync(steps, 0, ((size_t)n_tiles + n_lists) * sizeof(uint32_t), stream));
-        } else {
-            // lane slots the pass effectively has: the resident waves at about half their lanes
-            HIP_TRY(launch_ao_bin(steps, counts, lists, list_cap, n_tiles, slot.ctr, (uint32_t)grid * 32u, stream));
-            p.lpt_read_counts = counts;
-            p.lpt_read_lists = lists;
-            p.lpt_cap = list_cap;
-        }
-        HIP_TRY(hipMemsetAsync(&slot.ctr->ao_sum_steps, 0, 16, stream));
-        p.ao_steps = steps;
     }
     if (s->dbg_cost) { // diagnostics: cold tile order, costs / iteration counts into the caller's buffers
         p.lpt_read_counts = nullptr;
@@ -572,7 +537,8 @@ int read_overflow(trx_scene *s, SlotCounters *ctr) {
     unsigned int over = 0;
     HIP_TRY(hipMemcpy(&over, &ctr->overflow, sizeof(over), hipMemcpyDeviceToHost));
     if (over) {
-        HIP_TRY(hipMemset(&ctr->overflow, 0, sizeof(over)));
+        const unsigned int zero = 0; // (a blocking copy, not hipMemset: see the launch-slot set-up in enqueue())
+        HIP_TRY(hipMemcpy(&ctr->overflow, &zero, sizeof(zero), hipMemcpyHostToDevice));
         return fail(TRX_ERR_STACK_OVERFLOW, "%u rays overflowed the %d-entry traversal stack (or the step cap)", over,
                     kLdsStack + kSpillStack);
     }
@@ -715,7 +681,6 @@ void trx_scene_destroy(trx_scene *s) {
         if (sl.ctr) (void)hipFree(sl.ctr);
         if (sl.spill) (void)hipFree(sl.spill);
         if (sl.lpt) (void)hipFree(sl.lpt);
-        if (sl.ao_buf) (void)hipFree(sl.ao_buf);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -731,7 +696,6 @@ uint64_t trx_scene_device_bytes(const trx_scene *s) {
     for (const Slot &sl : s->slots) {
         bytes += (uint64_t)sl.spill_waves * kSpillStack * kWave * sizeof(uint2);
         if (sl.lpt) bytes += 2ull * (16 * kLptShards + (uint64_t)16 * kLptShards * (sl.lpt_capacity / 2 + 64)) * sizeof(uint32_t);
-        if (sl.ao_buf) bytes += ((uint64_t)sl.ao_capacity + 16 * kLptShards + (uint64_t)16 * kLptShards * (sl.ao_capacity / 2 + 64)) * sizeof(uint32_t);
         if (sl.ctr) bytes += sizeof(SlotCounters);
     }
     return bytes;

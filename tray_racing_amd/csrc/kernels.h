@@ -66,10 +66,11 @@ struct SlotCounters {
     // COUNT kernels: per triangle phase, histogram of the largest per-lane triangle count (0..15+) and of the
     // wave's pair total in units of 8 (0..15+)
     unsigned int hist_max[16], hist_total[16];
-    // AO passes: summed and largest trip count of the rays of the last pass on this slot (what decides whether the next
-    // one starts its long rays first)
-    unsigned long long ao_sum_steps;
-    unsigned int ao_max_steps, ao_pad;
+    // self-tuning of the tile-order feedback (k_trace exit protocol): start stamp of the running frame, mode (1 = frames run
+    // without the feedback), frames run in the current phase, whether the phase is a hold (after a decision) or a
+    // measurement, best frame time (100 MHz ticks) seen with / without the feedback
+    unsigned long long fb_t0;
+    unsigned int fb_off, fb_frames, fb_held, fb_t_on, fb_t_off, fb_pad;
 };
 
 struct TraceParams {
@@ -100,7 +101,6 @@ struct TraceParams {
     uint32_t *lpt_write_counts;
     uint32_t *lpt_write_lists;
     uint32_t lpt_cap;
-    uint32_t *ao_steps;     // AO pass: per tile, the largest trip count one of its rays took (atomic max), or null
     uint32_t *cost;         // diagnostics: per-tile cost (wall-clock ticks), or null
     uint32_t prio_cut[3];   // chunks below these (heaviest-first) indices run at s_setprio 3 / 2 / 1
     uint8_t *touch_nodes, *touch_tris; // diagnostics (COUNT kernels): byte set per node fetched / triangle tested, or null
@@ -118,6 +118,7 @@ struct TraceParams {
     unsigned long long *wave_times;  // diagnostics: [8*wave] start, [8*wave+1] end (wall_clock64), [+2..7] phase cycles in TRX_STAMPS builds; or null
     // frames per launch (image modes): frame f = local_tile / tiles_per_frame uses views[f] and writes its
     // records at out + f * frame_stride; one launch then balances n_frames x the tiles
+    uint32_t fb_auto;     // image passes with tile-order feedback: let the slot switch the feedback off where it measures slower with it
     uint32_t uni_decode;  // coherent primary walk: decode the child planes of a node step once per wave when every lane visits the same node
     uint32_t any_hit;     // explicit rays only: stop at the first accepted hit, write one byte (0/1) per ray
     uint32_t n_frames, tiles_per_frame, frame_stride;
@@ -126,12 +127,6 @@ struct TraceParams {
 
 // Resident waves the persistent kernel should be launched with on `device`.
 int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count);
-
-// AO passes, long rays first: files every tile (chunk) of the next AO pass in the list of its step class from the trip
-// counts the previous pass recorded (and clears them) - but only when that pass was bound by its longest ray, i.e. when
-// ctr->ao_max_steps x slots exceeds ctr->ao_sum_steps; otherwise the lists stay empty and the pass runs in scan order.
-hipError_t launch_ao_bin(uint32_t *steps, uint32_t *counts, uint32_t *lists, uint32_t list_cap, uint32_t n_tiles,
-                         const SlotCounters *ctr, uint32_t slots, hipStream_t stream);
 
 // Enqueues one traversal kernel.  sem: trx_semantics bits; pipe: the pipelined walk (BLAS-only scenes; ignored with a TLAS).
 hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, bool pipe, int grid,

@@ -437,7 +437,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     float t = 0.0f;
     uint32_t prim = TRX_INVALID, out_index = 0, sp = 0, steps = 0;
     uint32_t trip = 0; // traversal-loop trips of this wave (uniform)
-    uint32_t ao_sum = 0, ao_max = 0; // AO passes: trips lived by this lane's finished rays (sum, largest)
     uint32_t tlas_sp = TRX_INVALID, bvh_off = 0;
     // instance transforms (TLAS): the instance being walked / the one the current hit was found in, and the
     // world-space ray (origin, direction as given) to come back to when the BLAS is left
@@ -481,7 +480,12 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // list of the heaviest-first concatenation; lane l holds the (exclusive) ends of entries l, l+64.
     uint32_t end_a = 0, end_b = 0;
     bool ordered = false;
-    if (P.lpt_read_counts) {
+    // The feedback machinery tunes itself (exit protocol below): a slot whose frames measured faster WITHOUT it runs without
+    // it - natural order, no tile timing, no list appends - until the next re-evaluation.  Every wave reads the same word.
+    const bool fb_off = P.fb_auto != 0u && P.ctr->fb_off != 0u;
+    if (P.fb_auto && wave_global == 0u && lane == 0u) P.ctr->fb_t0 = wall_clock64(); // (about when the frame's first waves start)
+    const bool lpt_write = P.lpt_write_counts != nullptr && !fb_off;
+    if (P.lpt_read_counts && !fb_off) {
         end_a = P.lpt_read_counts[(15u - (lane >> 3)) * kLptShards + (lane & 7u)];
         end_b = P.lpt_read_counts[(15u - ((lane + 64u) >> 3)) * kLptShards + (lane & 7u)];
         // a list that overflowed its capacity dropped entries: fall back to the natural order
@@ -516,7 +520,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             if (lane == 0) {
                 const uint32_t c = (uint32_t)(wall_clock64() - tile_t0);
                 if (P.cost) P.cost[tile_slot] = c;
-                if (P.lpt_write_counts) {
+                if (lpt_write) {
                     // class = 2*log2(c) in half-octaves, 2.56 us .. 0.49 ms
                     const uint32_t msb = 31u - (uint32_t)__clz((int)(c | 1u));
                     const uint32_t kk = 2u * msb + (msb ? (c >> (msb - 1u)) & 1u : 0u);
@@ -527,7 +531,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     lds_pend[n_pend] = make_uint2(tile_slot, list);
                 }
             }
-            if (P.lpt_write_counts) {
+            if (lpt_write) {
                 n_pend++;
                 if (n_pend == (uint32_t)kLptPend) {
                     flush_pending(P, lds_pend, n_pend, lane);
@@ -593,7 +597,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         else if (chunk < P.prio_cut[2]) __builtin_amdgcn_s_setprio(1);
                         else __builtin_amdgcn_s_setprio(0);
                     }
-                    if ((P.cost || P.lpt_write_counts) && n_idle == (uint32_t)kWave && given == 0u) {
+                    if ((P.cost || lpt_write) && n_idle == (uint32_t)kWave && given == 0u) {
                         tile_slot = cur_tile; // cost is filed under the tile, not the chunk
                         tile_t0 = wall_clock64();
                         s_wnode = c_wnode;
@@ -850,10 +854,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     if (COUNT) c_tri += cnt;
                     for (uint32_t base = 0; base < total; base += kWave) {
                         // owner of every pair of this window: heads mark where each owner's run starts
-                        // (the table is cleared for every window.  Tagging the heads with a window number instead, so
-                        // that stale ones lose the max-scan and the clearing store goes, measured -1 % - and, with
-                        // four processes time-sharing the GPU, launches that left whole work queues untraced; the
-                        // mechanism was not established, the variant is gone: profiles/r03_tagged_heads.log)
+                        // (the table is cleared for every window; tagging the heads with a window number instead, so
+                        // that stale ones lose the max-scan and the clearing store goes, measured -1 % on one pass
+                        // and was not kept)
                         lds_head[lane] = 0u;
                         __builtin_amdgcn_wave_barrier();
                         const uint32_t run_begin = max(excl, base), run_end = min(excl + cnt, base + kWave);
@@ -903,15 +906,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 
 
 
-        // AO passes: how many trips the finished ray lived (its node steps), kept per tile as a maximum and per lane as a
-        // sum / maximum: the next AO pass on this slot starts the tiles of long rays first when the longest ray, not the
-        // amount of work, set this pass's length (launch_ao_bin)
-        auto note_ao_steps = [&]() {
-            const uint32_t lived = trip - steps;
-            atomicMax(&P.ao_steps[my_tile], lived);
-            ao_sum += lived;
-            ao_max = max(ao_max, lived);
-        };
         // Finished ray: the hit record (or the any-hit flag) leaves the lane.
         auto finish_lane = [&]() {
             if (MODE == kModeRays && P.any_hit != 0u) {
@@ -926,7 +920,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 c_rays++;
                 c_hits += prim != TRX_INVALID;
             }
-            if (MODE == kModeAo && P.ao_steps) note_ao_steps();
             c_over += overflow;
             has_ray = false;
         };
@@ -1110,7 +1103,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             c_rays++;
                             c_hits += prim != TRX_INVALID;
                         }
-                        if (MODE == kModeAo && P.ao_steps) note_ao_steps();
                         c_over += overflow;
                         has_ray = false;
                     }
@@ -1194,18 +1186,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     }
 
     // ---- epilogue: flags, counters, queue reset ---------------------------------------
-    if (P.lpt_write_counts && n_pend) flush_pending(P, lds_pend, n_pend, lane);
+    if (lpt_write && n_pend) flush_pending(P, lds_pend, n_pend, lane);
     if (c_over) atomicAdd(&P.ctr->overflow, c_over);
-    if (MODE == kModeAo && P.ao_steps) {
-        for (int off = 32; off > 0; off >>= 1) {
-            ao_sum += (uint32_t)__shfl_xor((int)ao_sum, off);
-            ao_max = max(ao_max, (uint32_t)__shfl_xor((int)ao_max, off));
-        }
-        if (lane == 0) {
-            atomicAdd(&P.ctr->ao_sum_steps, (unsigned long long)ao_sum);
-            atomicMax(&P.ctr->ao_max_steps, ao_max);
-        }
-    }
     if (COUNT) {
         atomicAdd(&P.ctr->n_rays, (unsigned long long)c_rays);
         atomicAdd(&P.ctr->n_node, (unsigned long long)c_node);
@@ -1230,30 +1212,52 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             // the lists this frame consumed become the next frame's (empty) write lists
             if (P.lpt_read_counts)
                 for (uint32_t b = 0; b < 16u * kLptShards; b++) atomicExch(&P.lpt_read_counts[b], 0u);
+            if (P.fb_auto) {
+                // Is the tile-order feedback worth its keep on this slot's frames?  It costs about 2 us a tile (timing, the
+                // list look-up behind the queue atomic, the appends) and repays that many times over where a few tiles set
+                // the frame's critical path - and not at all where every tile costs about the same (a room seen from
+                // inside: the kitchen-class frame runs 12 % faster without it).  So the slot measures: kFbOn frames with the
+                // feedback (the first three relearn the order and do not count), then kFbProbe frames without it, then the
+                // faster mode holds for kFbHold frames before the other is tried again.  Frame time = last wave out minus
+                // first wave in, best of the frames of a phase; a 3 % margin keeps the ordered mode on a tie.
+                constexpr unsigned int kFbOn = 24u, kFbProbe = 4u, kFbHold = 1024u;
+                SlotCounters &c = *P.ctr;
+                const unsigned int dur = (unsigned int)min(wall_clock64() - c.fb_t0, 0xffffffffull);
+                const unsigned int f = c.fb_frames + 1u;
+                if (!fb_off) {
+                    if (f > 3u) c.fb_t_on = c.fb_t_on ? min(c.fb_t_on, dur) : dur;
+                    if (f >= (c.fb_held ? kFbHold : kFbOn)) { // try the other mode
+                        c.fb_off = 1u;
+                        c.fb_frames = 0u;
+                        c.fb_t_off = 0u;
+                        c.fb_held = 0u;
+                    } else {
+                        c.fb_frames = f;
+                    }
+                } else {
+                    if (f > 1u) c.fb_t_off = c.fb_t_off ? min(c.fb_t_off, dur) : dur;
+                    if (!c.fb_held && f >= kFbProbe) {
+                        // decision: stay without the feedback only if that is clearly faster
+                        const bool off_wins = c.fb_t_on != 0u && (unsigned long long)c.fb_t_off * 100ull < (unsigned long long)c.fb_t_on * 97ull;
+                        c.fb_off = off_wins ? 1u : 0u;
+                        c.fb_frames = 0u;
+                        c.fb_held = 1u;
+                        if (!off_wins) c.fb_t_on = 0u; // re-measured after the order is relearnt
+                    } else if (c.fb_held && f >= kFbHold) { // held without it long enough: measure with it again
+                        c.fb_off = 0u;
+                        c.fb_frames = 0u;
+                        c.fb_t_on = 0u;
+                        c.fb_held = 0u;
+                    } else {
+                        c.fb_frames = f;
+                    }
+                }
+            }
             atomicExch(&P.ctr->waves_done, 0u);
         }
     }
 }
 
-
-// One thread per tile of the coming AO pass (see launch_ao_bin in kernels.h).
-__global__ void __launch_bounds__(256) k_ao_bin(uint32_t *steps, uint32_t *counts, uint32_t *lists, uint32_t list_cap,
-                                                uint32_t n_tiles, const SlotCounters *ctr, uint32_t slots) {
-    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= n_tiles) return;
-    const uint32_t c = steps[tile];
-    steps[tile] = 0u;
-    // was the last pass as long as its longest ray (rather than as long as its work spread over the lane slots)?
-    if ((unsigned long long)ctr->ao_max_steps * slots <= ctr->ao_sum_steps) return;
-    // class = half-octaves of the step count, 16 classes, 362 steps and more in the heaviest
-    const uint32_t v = max(c, 1u);
-    const uint32_t msb = 31u - (uint32_t)__clz((int)v);
-    const uint32_t kk = 2u * msb + (msb ? (v >> (msb - 1u)) & 1u : 0u);
-    const uint32_t b = kk < 2u ? 0u : min(kk - 2u, 15u);
-    const uint32_t list = b * kLptShards + (tile & (kLptShards - 1u));
-    const uint32_t pos = atomicAdd(&counts[list], 1u);
-    if (pos < list_cap) lists[(size_t)list * list_cap + pos] = tile;
-}
 
 template <int MODE, bool TLAS, int NODE, bool PIPE, bool COUNT>
 hipError_t launch_one(const TraceParams &p, int grid, hipStream_t stream) {
@@ -1316,12 +1320,6 @@ int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count) {
     if (per_cu <= 0) per_cu = 8;
     if (per_cu > 32) per_cu = 32;
     return per_cu * prop.multiProcessorCount;
-}
-
-hipError_t launch_ao_bin(uint32_t *steps, uint32_t *counts, uint32_t *lists, uint32_t list_cap, uint32_t n_tiles,
-                         const SlotCounters *ctr, uint32_t slots, hipStream_t stream) {
-    hipLaunchKernelGGL(k_ao_bin, dim3((n_tiles + 255u) / 256u), dim3(256), 0, stream, steps, counts, lists, list_cap, n_tiles, ctr, slots);
-    return hipGetLastError();
 }
 
 hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem, bool count, bool pipe, int grid,
