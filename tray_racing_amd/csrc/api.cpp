@@ -391,10 +391,12 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.tie_first = (sem & TRX_SEM_TIE_FIRST) ? 1u : 0u;
     uint32_t refill = variant & 0x7fu;
     // coherent primary rays: refill a wave only when its whole tile is done (mixing tiles costs more
-    // coherence than idle lanes cost); incoherent rays (AO, explicit batches): replace finished rays
-    // once 12 lanes idle (whole-tile refills: bistro-class AO pass 1.59 ms; 20 idle lanes 1.14; 12 idle lanes 1.11,
-    // and 1-3 % under the 20-lane figure on the dense and hairball-class scenes too, gpurun_out/r2e_refill.log)
-    p.refill_idle = refill ? std::min(refill, 64u) : (mode == kModePrimary ? 64u : 12u);
+    // coherence than idle lanes cost; a slot whose frames measure faster with mid-tile refills switches itself, see the
+    // kernel's exit protocol); incoherent rays (AO, explicit batches): replace finished rays
+    // once 16 lanes idle (whole-tile refills: bistro-class AO pass 1.59 ms in round 1; re-swept with the round-3 kernels,
+    // profiles/r03_refill_sweep.log: 12 / 16 / 20 idle lanes = 0.880 / 0.886 / 0.884 ms bistro-class, 0.864 / 0.860 / 0.851
+    // hairball-class, 1.382 / 1.369 / 1.383 dense, 0.402 / 0.383 / 0.389 kitchen-class)
+    p.refill_idle = refill ? std::min(refill, 64u) : (mode == kModePrimary ? 64u : 16u);
     if (p.n_frames > 1) p.refill_idle = 64u; // the kernel takes the frame of a wave from its (whole) tile
     p.variant = variant;
 #ifdef TRX_DEV_TUNE

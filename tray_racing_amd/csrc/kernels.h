@@ -66,11 +66,12 @@ struct SlotCounters {
     // COUNT kernels: per triangle phase, histogram of the largest per-lane triangle count (0..15+) and of the
     // wave's pair total in units of 8 (0..15+)
     unsigned int hist_max[16], hist_total[16];
-    // self-tuning of the tile-order feedback (k_trace exit protocol): start stamp of the running frame, mode (1 = frames run
-    // without the feedback), frames run in the current phase, whether the phase is a hold (after a decision) or a
-    // measurement, best frame time (100 MHz ticks) seen with / without the feedback
+    // self-tuning of the frame schedule (k_trace exit protocol): start stamp of the running frame; the mode this slot's
+    // frames run in (0 = whole tiles, heaviest first from the learnt order; 1 = whole tiles in natural order, no feedback
+    // machinery; 2 = natural order, finished rays replaced once kFbRefill lanes idle); frames run in the current phase;
+    // the phase (0..2 = measuring that mode, 3 = holding the winner); best frame time (100 MHz ticks) seen per mode
     unsigned long long fb_t0;
-    unsigned int fb_off, fb_frames, fb_held, fb_t_on, fb_t_off, fb_pad;
+    unsigned int fb_mode, fb_frames, fb_phase, fb_t[3];
 };
 
 struct TraceParams {

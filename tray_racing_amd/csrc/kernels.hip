@@ -482,7 +482,12 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     bool ordered = false;
     // The feedback machinery tunes itself (exit protocol below): a slot whose frames measured faster WITHOUT it runs without
     // it - natural order, no tile timing, no list appends - until the next re-evaluation.  Every wave reads the same word.
-    const bool fb_off = P.fb_auto != 0u && P.ctr->fb_off != 0u;
+    const uint32_t fb_mode = P.fb_auto != 0u ? (uint32_t)__builtin_amdgcn_readfirstlane((int)P.ctr->fb_mode) : 0u;
+    const bool fb_off = fb_mode != 0u;
+    // (mode 2: a frame whose tiles are ragged - a few rays of a tile run ten times longer than the rest - keeps its lanes
+    // busier by replacing finished rays mid-tile; one frame per launch only, the frame of a batch is taken from whole tiles)
+    constexpr uint32_t kFbRefill = 16u;
+    const uint32_t refill_idle = (fb_mode == 2u && P.n_frames == 1u) ? kFbRefill : P.refill_idle;
     if (P.fb_auto && wave_global == 0u && lane == 0u) P.ctr->fb_t0 = wall_clock64(); // (about when the frame's first waves start)
     const bool lpt_write = P.lpt_write_counts != nullptr && !fb_off;
     if (P.lpt_read_counts && !fb_off) {
@@ -549,7 +554,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             }
             tile_slot = TRX_INVALID;
         }
-        if (!exhausted && n_idle >= P.refill_idle) {
+        if (!exhausted && n_idle >= refill_idle) {
             const uint32_t rank = lane_rank(idle);
             uint32_t given = 0, item = TRX_INVALID;
             while (given < n_idle) {
@@ -730,7 +735,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         // ---- traverse ------------------------------------------------------------
         // The loop is wave-uniform (every lane iterates, work is predicated on `act`), so that the
         // triangle phase can use all 64 lanes whichever lanes own the triangles.
-        const uint32_t keep = kWave - P.refill_idle; // leave when this few lanes remain
+        const uint32_t keep = kWave - refill_idle; // leave when this few lanes remain
         // Stack push / pop.  Fast path: every lane's top is inside the LDS part, so the write needs no
         // predication at all (an entry above a lane's top is free to clobber) and the whole push is one
         // ds_write_b64 plus a conditional increment; lanes past the LDS part (rare: depth > kLdsStack) take the
@@ -1213,44 +1218,50 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             if (P.lpt_read_counts)
                 for (uint32_t b = 0; b < 16u * kLptShards; b++) atomicExch(&P.lpt_read_counts[b], 0u);
             if (P.fb_auto) {
-                // Is the tile-order feedback worth its keep on this slot's frames?  It costs about 2 us a tile (timing, the
-                // list look-up behind the queue atomic, the appends) and repays that many times over where a few tiles set
-                // the frame's critical path - and not at all where every tile costs about the same (a room seen from
-                // inside: the kitchen-class frame runs 12 % faster without it).  So the slot measures: kFbOn frames with the
-                // feedback (the first three relearn the order and do not count), then kFbProbe frames without it, then the
-                // faster mode holds for kFbHold frames before the other is tried again.  Frame time = last wave out minus
-                // first wave in, best of the frames of a phase; a 3 % margin keeps the ordered mode on a tie.
+                // Which schedule suits this slot's frames?  The tile-order feedback costs about 2 us a tile (timing, the list
+                // look-up behind the queue atomic, the appends) and repays that many times over where a few tiles set the
+                // frame's critical path - not on a room seen from inside (the kitchen-class frame runs 13 % faster without
+                // it), and a frame of ragged tiles (the hairball-class one: a few rays of a tile run ten times longer than
+                // the rest) does better still replacing finished rays mid-tile.  So the slot measures: kFbOn frames ordered
+                // (the first three relearn the order and do not count), kFbProbe frames in natural order, kFbProbe with
+                // mid-tile refills; the ordered mode stays unless another is 3 % faster; the winner holds for kFbHold frames,
+                // then everything is measured again.  Frame time = last wave out minus first wave in, best of a phase.
                 constexpr unsigned int kFbOn = 24u, kFbProbe = 4u, kFbHold = 1024u;
                 SlotCounters &c = *P.ctr;
                 const unsigned int dur = (unsigned int)min(wall_clock64() - c.fb_t0, 0xffffffffull);
                 const unsigned int f = c.fb_frames + 1u;
-                if (!fb_off) {
-                    if (f > 3u) c.fb_t_on = c.fb_t_on ? min(c.fb_t_on, dur) : dur;
-                    if (f >= (c.fb_held ? kFbHold : kFbOn)) { // try the other mode
-                        c.fb_off = 1u;
-                        c.fb_frames = 0u;
-                        c.fb_t_off = 0u;
-                        c.fb_held = 0u;
-                    } else {
+                const unsigned int phase = c.fb_phase;
+                if (phase < 3u) {
+                    // measuring mode `phase`: the ordered mode needs three frames to relearn its order, the others one
+                    const unsigned int skip = phase == 0u ? 3u : 1u, len = phase == 0u ? kFbOn : kFbProbe;
+                    if (f > skip) c.fb_t[phase] = c.fb_t[phase] ? min(c.fb_t[phase], dur) : dur;
+                    if (f < len) {
                         c.fb_frames = f;
+                    } else if (phase < 2u && !(phase == 1u && P.n_frames != 1u)) {
+                        c.fb_phase = phase + 1u; // next candidate
+                        c.fb_mode = phase + 1u;
+                        c.fb_frames = 0u;
+                        c.fb_t[phase + 1u] = 0u;
+                    } else {
+                        // decision: the ordered mode unless another is clearly (3 %) faster; of those, the faster
+                        unsigned int best = 0u;
+                        unsigned long long t_best = (unsigned long long)c.fb_t[0] * 97ull;
+                        for (unsigned int m = 1u; m <= phase; m++)
+                            if (c.fb_t[m] != 0u && c.fb_t[0] != 0u && (unsigned long long)c.fb_t[m] * 100ull < t_best) {
+                                best = m;
+                                t_best = (unsigned long long)c.fb_t[m] * 100ull;
+                            }
+                        c.fb_mode = best;
+                        c.fb_phase = 3u;
+                        c.fb_frames = 0u;
                     }
+                } else if (f >= kFbHold) { // held long enough: measure again, from the ordered mode
+                    c.fb_mode = 0u;
+                    c.fb_phase = 0u;
+                    c.fb_frames = 0u;
+                    c.fb_t[0] = 0u;
                 } else {
-                    if (f > 1u) c.fb_t_off = c.fb_t_off ? min(c.fb_t_off, dur) : dur;
-                    if (!c.fb_held && f >= kFbProbe) {
-                        // decision: stay without the feedback only if that is clearly faster
-                        const bool off_wins = c.fb_t_on != 0u && (unsigned long long)c.fb_t_off * 100ull < (unsigned long long)c.fb_t_on * 97ull;
-                        c.fb_off = off_wins ? 1u : 0u;
-                        c.fb_frames = 0u;
-                        c.fb_held = 1u;
-                        if (!off_wins) c.fb_t_on = 0u; // re-measured after the order is relearnt
-                    } else if (c.fb_held && f >= kFbHold) { // held without it long enough: measure with it again
-                        c.fb_off = 0u;
-                        c.fb_frames = 0u;
-                        c.fb_t_on = 0u;
-                        c.fb_held = 0u;
-                    } else {
-                        c.fb_frames = f;
-                    }
+                    c.fb_frames = f;
                 }
             }
             atomicExch(&P.ctr->waves_done, 0u);
