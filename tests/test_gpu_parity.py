@@ -757,6 +757,30 @@ def test_scheduling_variants_and_streams_do_not_change_results(trx, orc):
         sc.close()
 
 
+def test_frame_loop_keeps_one_tile_order_per_pass_kind(trx, orc):
+    """The reference's frame loop runs the primary pass and the AO pass on one queue, so both land on one launch slot:
+    each kind has its own tile-order lists and schedule-tuner state there (the AO pass uses them only when it runs with
+    whole-tile refills - variant bits 0..6 = 64 - its default replaces finished rays mid-tile and files no order).
+    60 frames of both passes - past the tuner's first decisions - equal the oracle's, in both AO refill modes."""
+    w, h = 328, 200
+    flat, view, osc, ov = make_scene(trx, orc, "bistro", 150000, w, h)
+    want_p = osc.trace_primary(ov, w, h, sem=3)[0]
+    want_ao = osc.trace_ao(ov, w, h, want_p, sem=3, frame=3, ao_eps=0.01)[0]
+    sc = trx.Scene(flat)
+    lib = trx.load()
+    try:
+        for variant in (0, 64):
+            lib.trx_set_kernel_variant(variant)
+            for k in range(60):
+                gp, gao, _ = sc.trace_primary_ao(view, w, h, sem=3, frame=3, ao_eps=0.01)
+                if k % 4 == 0 or 22 <= k < 36:
+                    assert_hits_equal(gp, want_p, "frame loop primary, variant %d frame %d" % (variant, k))
+                    assert_hits_equal(gao, want_ao, "frame loop AO, variant %d frame %d" % (variant, k))
+    finally:
+        lib.trx_set_kernel_variant(0)
+        sc.close()
+
+
 def test_camera_cuts_reset_the_tile_order_and_never_the_hits(trx, orc):
     """A learnt tile order belongs to a view: alternating between two unrelated cameras (every frame a cut: natural
     order while the tiles are measured), drifting slowly (the previous frame's order is replayed), and variant bit 7

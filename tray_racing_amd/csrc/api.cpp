@@ -104,13 +104,16 @@ struct Slot {
     bool used = false;
     hipStream_t last_stream = nullptr; // stream of the last launch on this slot
     uint64_t last_use = 0;             // launch counter at that time (oldest slot is recycled first)
-    // tile-cost feedback: the previous frame traced on this slot measured every tile; the next one
-    // with the same image geometry starts its heaviest tiles first
-    uint32_t *lpt = nullptr; // two sets of {16 counts, 16 lists}
-    uint32_t lpt_capacity = 0;
-    uint32_t lpt_parity = 0; // set written by the next frame
-    uint64_t lpt_key = 0;    // (width, height, shard, mode) the lists were measured for; 0 = none
-    ViewDev lpt_view{};      // view of the last frame that read or wrote the lists (camera-cut detection)
+    // tile-cost feedback: the previous frame of a kind (primary / AO) traced on this slot measured every tile; the
+    // next one of that kind with the same image geometry starts its heaviest tiles first.  One state per kind: the
+    // reference's frame loop runs both passes on one queue, and each has its own order.
+    struct Order {
+        uint32_t *lists = nullptr; // two sets of {16 counts, 16 lists}
+        uint32_t capacity = 0;
+        uint32_t parity = 0; // set written by the next frame
+        uint64_t key = 0;    // (width, height, shard, mode) the lists were measured for; 0 = none
+        ViewDev view{};      // view of the last frame that read or wrote the lists (camera-cut detection)
+    } order[2];
 };
 
 } // namespace
@@ -438,51 +441,54 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         const uint32_t n_lists = 16 * kLptShards;
         const uint32_t list_cap = n_tiles / 2 + 64; // a list holds ~1/8 of one bucket; overflow only drops the order
         const size_t set_words = n_lists + (size_t)n_lists * list_cap;
-        if (slot.lpt_capacity != n_tiles) {
+        Slot::Order &ord = slot.order[mode == kModeAo ? 1 : 0];
+        bool fresh = false;
+        if (ord.capacity != n_tiles) {
             // (the slot's previous kernel may still be appending to the old lists: wait for it before they go)
-            if (slot.lpt && slot.used) HIP_TRY(hipEventSynchronize(slot.done));
-            if (slot.lpt) (void)hipFree(slot.lpt);
-            slot.lpt = nullptr;
-            slot.lpt_capacity = 0;
-            slot.lpt_key = 0;
-            HIP_TRY(hipMalloc(&slot.lpt, 2 * set_words * sizeof(uint32_t)));
-            slot.lpt_capacity = n_tiles;
+            if (ord.lists && slot.used) HIP_TRY(hipEventSynchronize(slot.done));
+            if (ord.lists) (void)hipFree(ord.lists);
+            ord.lists = nullptr;
+            ord.capacity = 0;
+            ord.key = 0;
+            HIP_TRY(hipMalloc(&ord.lists, 2 * set_words * sizeof(uint32_t)));
+            ord.capacity = n_tiles;
+            fresh = true;
         }
         key = ((uint64_t)p.width << 40) ^ ((uint64_t)p.height << 20) ^ ((uint64_t)p.shard_count << 8) ^ p.shard_index ^
               ((uint64_t)(mode + 1) << 60) ^ ((uint64_t)p.n_frames << 56);
-        uint32_t *set[2] = {slot.lpt, slot.lpt + set_words};
+        uint32_t *set[2] = {ord.lists, ord.lists + set_words};
         // A learnt order belongs to a view.  New image geometry, or a camera cut (the eye jumped by more than 1 % of
         // the scene's diagonal, the view direction turned by more than 2 degrees, or the projection changed) since the
-        // last frame on this slot: the lists are emptied and this frame runs in natural order while it measures its
-        // tiles, instead of replaying an order learnt for another view.  (A probe pass that predicts the order of such
-        // a frame - one centre ray per tile - was built and measured in round 3: it is bound by the latency of its
-        // longest ray and costs more than the order gains, profiles/r03_probe_cap.log.)  Variant bit 7 treats every
-        // frame as a cut (bench.py's first-frame leg).
-        bool cut = slot.lpt_key != key || ((variant >> 7) & 1u);
+        // last frame of this kind on this slot: this frame runs in natural order while it measures its tiles, instead
+        // of replaying an order learnt for another view, and the schedule tuner starts over (TraceParams::new_view -
+        // no extra command on the stream: the kernel skips the stale lists and its exit wave empties them as after
+        // any frame).  (A probe pass that predicts the order of such a frame - one centre ray per tile - was built
+        // and measured in round 3: it is bound by the latency of its longest ray and costs more than the order
+        // gains, profiles/r03_probe_cap.log.)  Variant bit 7 treats every frame as a cut (bench.py's first-frame leg).
+        bool cut = ord.key != key || ((variant >> 7) & 1u);
         if (!cut) {
-            const ViewDev &a = slot.lpt_view, &b = p.views[0];
+            const ViewDev &a = ord.view, &b = p.views[0];
             const float ex = a.eye[0] - b.eye[0], ey = a.eye[1] - b.eye[1], ez = a.eye[2] - b.eye[2];
             const float moved2 = ex * ex + ey * ey + ez * ez, lim = 0.01f * s->scene_diag;
             const float turn = a.view_inv[8] * b.view_inv[8] + a.view_inv[9] * b.view_inv[9] + a.view_inv[10] * b.view_inv[10];
             cut = !(moved2 <= lim * lim) || !(turn >= 0.99939f) || std::memcmp(a.proj_inv, b.proj_inv, sizeof(a.proj_inv)) != 0;
         }
-        slot.lpt_view = p.views[0];
-        p.fb_auto = (s->dbg_cost || ((variant >> 19) & 1u)) ? 0u : 1u; // (variant bit 19: feedback always on, for A/B runs)
-        if (cut) {
-            // a new view measures afresh: feedback on, phase restarted
-            HIP_TRY(hipMemsetAsync(&slot.ctr->fb_t0, 0, sizeof(unsigned long long) + 6 * sizeof(unsigned int), stream));
+        ord.view = p.views[0];
+        ord.key = key;
+        // (variant bit 19: feedback always on, for A/B runs)
+        p.fb = (s->dbg_cost || ((variant >> 19) & 1u)) ? nullptr : &slot.ctr->fb[mode == kModeAo ? 1 : 0];
+        p.new_view = cut ? 1u : 0u;
+        if (fresh) { // new lists start empty (from then on every frame's exit wave leaves the set it read empty)
             HIP_TRY(hipMemsetAsync(set[0], 0, n_lists * sizeof(uint32_t), stream));
             HIP_TRY(hipMemsetAsync(set[1], 0, n_lists * sizeof(uint32_t), stream));
-            slot.lpt_parity = 0;
-            slot.lpt_key = key;
-        } else {
-            p.lpt_read_counts = set[slot.lpt_parity ^ 1];
-            p.lpt_read_lists = set[slot.lpt_parity ^ 1] + n_lists;
+            ord.parity = 0;
         }
-        p.lpt_write_counts = set[slot.lpt_parity];
-        p.lpt_write_lists = set[slot.lpt_parity] + n_lists;
+        p.lpt_read_counts = set[ord.parity ^ 1];
+        p.lpt_read_lists = set[ord.parity ^ 1] + n_lists;
+        p.lpt_write_counts = set[ord.parity];
+        p.lpt_write_lists = set[ord.parity] + n_lists;
         p.lpt_cap = list_cap;
-        slot.lpt_parity ^= 1;
+        ord.parity ^= 1;
         // priority classes over the heaviest-first order (tuning: variant bits 22..24 pick the cuts)
         // measured on bistro-class 1080p: {32,8,2} 0.566 ms, {64,16,4} 0.572, {128,32,8} 0.585, none 0.630
         static const uint32_t cuts[8][3] = {{32, 8, 2}, {0, 0, 0}, {256, 64, 16}, {64, 16, 4}, {512, 128, 32},
@@ -491,8 +497,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         for (int i = 0; i < 3; i++) p.prio_cut[i] = c[i] ? n_tiles / c[i] : 0u;
     }
     if (s->dbg_cost) { // diagnostics: cold tile order, costs / iteration counts into the caller's buffers
-        p.lpt_read_counts = nullptr;
-        p.lpt_read_lists = nullptr;
+        p.new_view = 1u;
         p.cost = s->dbg_cost;
         p.tile_iters = s->dbg_iters;
     }
@@ -682,7 +687,8 @@ void trx_scene_destroy(trx_scene *s) {
     for (Slot &sl : s->slots) {
         if (sl.ctr) (void)hipFree(sl.ctr);
         if (sl.spill) (void)hipFree(sl.spill);
-        if (sl.lpt) (void)hipFree(sl.lpt);
+        for (auto &o : sl.order)
+            if (o.lists) (void)hipFree(o.lists);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -697,7 +703,8 @@ uint64_t trx_scene_device_bytes(const trx_scene *s) {
     std::lock_guard<std::mutex> lock(const_cast<trx_scene *>(s)->mu);
     for (const Slot &sl : s->slots) {
         bytes += (uint64_t)sl.spill_waves * kSpillStack * kWave * sizeof(uint2);
-        if (sl.lpt) bytes += 2ull * (16 * kLptShards + (uint64_t)16 * kLptShards * (sl.lpt_capacity / 2 + 64)) * sizeof(uint32_t);
+        for (const auto &o : sl.order)
+            if (o.lists) bytes += 2ull * (16 * kLptShards + (uint64_t)16 * kLptShards * (o.capacity / 2 + 64)) * sizeof(uint32_t);
         if (sl.ctr) bytes += sizeof(SlotCounters);
     }
     return bytes;

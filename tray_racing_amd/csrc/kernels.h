@@ -54,6 +54,15 @@ struct alignas(128) QueueHead {
     unsigned int pad[31];
 };
 
+// Self-tuning of the frame schedule (k_trace exit protocol): start stamp of the running frame; the mode the frames run
+// in (0 = whole tiles, heaviest first from the learnt order; 1 = whole tiles in natural order, no feedback machinery;
+// 2 = natural order, finished rays replaced once kFbRefill lanes idle); frames run in the current phase; the phase
+// (0..2 = measuring that mode, 3 = holding the winner); best frame time (100 MHz ticks) seen per mode.
+struct FbState {
+    unsigned long long t0;
+    unsigned int mode, frames, phase, t[3];
+};
+
 struct SlotCounters {
     QueueHead heads[8];      // one work-queue head per XCD, each on its own 128-byte line
     unsigned int waves_done; // exit ticket (self-resetting)
@@ -66,12 +75,8 @@ struct SlotCounters {
     // COUNT kernels: per triangle phase, histogram of the largest per-lane triangle count (0..15+) and of the
     // wave's pair total in units of 8 (0..15+)
     unsigned int hist_max[16], hist_total[16];
-    // self-tuning of the frame schedule (k_trace exit protocol): start stamp of the running frame; the mode this slot's
-    // frames run in (0 = whole tiles, heaviest first from the learnt order; 1 = whole tiles in natural order, no feedback
-    // machinery; 2 = natural order, finished rays replaced once kFbRefill lanes idle); frames run in the current phase;
-    // the phase (0..2 = measuring that mode, 3 = holding the winner); best frame time (100 MHz ticks) seen per mode
-    unsigned long long fb_t0;
-    unsigned int fb_mode, fb_frames, fb_phase, fb_t[3];
+    // self-tuning of the frame schedule, one state per pass kind (0 = primary, 1 = AO: a frame loop runs both on one stream)
+    FbState fb[2];
 };
 
 struct TraceParams {
@@ -119,7 +124,8 @@ struct TraceParams {
     unsigned long long *wave_times;  // diagnostics: [8*wave] start, [8*wave+1] end (wall_clock64), [+2..7] phase cycles in TRX_STAMPS builds; or null
     // frames per launch (image modes): frame f = local_tile / tiles_per_frame uses views[f] and writes its
     // records at out + f * frame_stride; one launch then balances n_frames x the tiles
-    uint32_t fb_auto;     // image passes with tile-order feedback: let the slot switch the feedback off where it measures slower with it
+    FbState *fb;          // image passes with tile-order feedback: the schedule tuner's state (null = feedback always on)
+    uint32_t new_view;    // camera cut: ignore the learnt order (the lists are emptied as usual), restart the tuner
     uint32_t uni_decode;  // coherent primary walk: decode the child planes of a node step once per wave when every lane visits the same node
     uint32_t any_hit;     // explicit rays only: stop at the first accepted hit, write one byte (0/1) per ray
     uint32_t n_frames, tiles_per_frame, frame_stride;

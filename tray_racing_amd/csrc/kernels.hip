@@ -482,15 +482,15 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     bool ordered = false;
     // The feedback machinery tunes itself (exit protocol below): a slot whose frames measured faster WITHOUT it runs without
     // it - natural order, no tile timing, no list appends - until the next re-evaluation.  Every wave reads the same word.
-    const uint32_t fb_mode = P.fb_auto != 0u ? (uint32_t)__builtin_amdgcn_readfirstlane((int)P.ctr->fb_mode) : 0u;
+    const uint32_t fb_mode = (P.fb != nullptr && !P.new_view) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)P.fb->mode) : 0u;
     const bool fb_off = fb_mode != 0u;
     // (mode 2: a frame whose tiles are ragged - a few rays of a tile run ten times longer than the rest - keeps its lanes
     // busier by replacing finished rays mid-tile; one frame per launch only, the frame of a batch is taken from whole tiles)
     constexpr uint32_t kFbRefill = 16u;
     const uint32_t refill_idle = (fb_mode == 2u && P.n_frames == 1u) ? kFbRefill : P.refill_idle;
-    if (P.fb_auto && wave_global == 0u && lane == 0u) P.ctr->fb_t0 = wall_clock64(); // (about when the frame's first waves start)
+    if (P.fb && wave_global == 0u && lane == 0u) P.fb->t0 = wall_clock64(); // (about when the frame's first waves start)
     const bool lpt_write = P.lpt_write_counts != nullptr && !fb_off;
-    if (P.lpt_read_counts && !fb_off) {
+    if (P.lpt_read_counts && !fb_off && !P.new_view) {
         end_a = P.lpt_read_counts[(15u - (lane >> 3)) * kLptShards + (lane & 7u)];
         end_b = P.lpt_read_counts[(15u - ((lane + 64u) >> 3)) * kLptShards + (lane & 7u)];
         // a list that overflowed its capacity dropped entries: fall back to the natural order
@@ -1217,7 +1217,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             // the lists this frame consumed become the next frame's (empty) write lists
             if (P.lpt_read_counts)
                 for (uint32_t b = 0; b < 16u * kLptShards; b++) atomicExch(&P.lpt_read_counts[b], 0u);
-            if (P.fb_auto) {
+            if (P.fb) {
                 // Which schedule suits this slot's frames?  The tile-order feedback costs about 2 us a tile (timing, the list
                 // look-up behind the queue atomic, the appends) and repays that many times over where a few tiles set the
                 // frame's critical path - not on a room seen from inside (the kitchen-class frame runs 13 % faster without
@@ -1227,41 +1227,42 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 // mid-tile refills; the ordered mode stays unless another is 3 % faster; the winner holds for kFbHold frames,
                 // then everything is measured again.  Frame time = last wave out minus first wave in, best of a phase.
                 constexpr unsigned int kFbOn = 24u, kFbProbe = 4u, kFbHold = 1024u;
-                SlotCounters &c = *P.ctr;
-                const unsigned int dur = (unsigned int)min(wall_clock64() - c.fb_t0, 0xffffffffull);
-                const unsigned int f = c.fb_frames + 1u;
-                const unsigned int phase = c.fb_phase;
+                FbState &c = *P.fb;
+                if (P.new_view) c.mode = c.frames = c.phase = c.t[0] = c.t[1] = c.t[2] = 0u; // a new view measures afresh
+                const unsigned int dur = (unsigned int)min(wall_clock64() - c.t0, 0xffffffffull);
+                const unsigned int f = c.frames + 1u;
+                const unsigned int phase = c.phase;
                 if (phase < 3u) {
                     // measuring mode `phase`: the ordered mode needs three frames to relearn its order, the others one
                     const unsigned int skip = phase == 0u ? 3u : 1u, len = phase == 0u ? kFbOn : kFbProbe;
-                    if (f > skip) c.fb_t[phase] = c.fb_t[phase] ? min(c.fb_t[phase], dur) : dur;
+                    if (f > skip) c.t[phase] = c.t[phase] ? min(c.t[phase], dur) : dur;
                     if (f < len) {
-                        c.fb_frames = f;
+                        c.frames = f;
                     } else if (phase < 2u && !(phase == 1u && P.n_frames != 1u)) {
-                        c.fb_phase = phase + 1u; // next candidate
-                        c.fb_mode = phase + 1u;
-                        c.fb_frames = 0u;
-                        c.fb_t[phase + 1u] = 0u;
+                        c.phase = phase + 1u; // next candidate
+                        c.mode = phase + 1u;
+                        c.frames = 0u;
+                        c.t[phase + 1u] = 0u;
                     } else {
                         // decision: the ordered mode unless another is clearly (3 %) faster; of those, the faster
                         unsigned int best = 0u;
-                        unsigned long long t_best = (unsigned long long)c.fb_t[0] * 97ull;
+                        unsigned long long t_best = (unsigned long long)c.t[0] * 97ull;
                         for (unsigned int m = 1u; m <= phase; m++)
-                            if (c.fb_t[m] != 0u && c.fb_t[0] != 0u && (unsigned long long)c.fb_t[m] * 100ull < t_best) {
+                            if (c.t[m] != 0u && c.t[0] != 0u && (unsigned long long)c.t[m] * 100ull < t_best) {
                                 best = m;
-                                t_best = (unsigned long long)c.fb_t[m] * 100ull;
+                                t_best = (unsigned long long)c.t[m] * 100ull;
                             }
-                        c.fb_mode = best;
-                        c.fb_phase = 3u;
-                        c.fb_frames = 0u;
+                        c.mode = best;
+                        c.phase = 3u;
+                        c.frames = 0u;
                     }
                 } else if (f >= kFbHold) { // held long enough: measure again, from the ordered mode
-                    c.fb_mode = 0u;
-                    c.fb_phase = 0u;
-                    c.fb_frames = 0u;
-                    c.fb_t[0] = 0u;
+                    c.mode = 0u;
+                    c.phase = 0u;
+                    c.frames = 0u;
+                    c.t[0] = 0u;
                 } else {
-                    c.fb_frames = f;
+                    c.frames = f;
                 }
             }
             atomicExch(&P.ctr->waves_done, 0u);
