@@ -35,6 +35,11 @@ def timeline(tag):
     print("%s: %d waves, frame %.1f us | end p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f | mean lifetime %.1f us (%.0f%% of frame)" % (
         tag, n.value, total, np.percentile(end, 10), np.percentile(end, 50), np.percentile(end, 90), np.percentile(end, 99),
         end.max(), life.mean(), 100 * life.mean() / total), flush=True)
+    wpb = int(os.environ.get("WPB", "1"))
+    xcd = (np.arange(n.value) // wpb) % 8
+    print("   per XCD (workgroup %% 8): end p50 / max = %s" % ["%.0f/%.0f" % (np.median(end[xcd == x]), end[xcd == x].max()) for x in range(8)], flush=True)
+    late = np.argsort(end)[-6:]
+    print("   last waves out: %s" % ["w%d xcd%d %.0f" % (i, xcd[i], end[i]) for i in late], flush=True)
     ts = np.linspace(0, total, 11)
     print("   alive waves at 0..100%% of the frame: %s" % [int(((start <= x) & (end > x)).sum()) for x in ts], flush=True)
 

@@ -498,6 +498,9 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     }
     if (s->dbg_cost) { // diagnostics: cold tile order, costs / iteration counts into the caller's buffers
         p.new_view = 1u;
+#ifdef TRX_DEV_TUNE
+        if (p.tune & 0x2000000u) p.new_view = 0u; // (tools/gpu_tail.py: the costs of a frame in its LEARNT order)
+#endif
         p.cost = s->dbg_cost;
         p.tile_iters = s->dbg_iters;
     }
@@ -1424,10 +1427,16 @@ int trx_debug_tile_profile(trx_scene *s, const trx_view *view, uint32_t w, uint3
     if (e == hipSuccess && !rc) {
         uint32_t *iters = s->dbg_iters;
         s->dbg_iters = nullptr; // second pass: the normal kernel
+#ifdef TRX_DEV_TUNE
+        { const char *tune = getenv("TRX_TUNE"); if (tune && (strtoul(tune, nullptr, 0) & 0x2000000u)) s->dbg_iters = iters; } // (diag builds: trips / rounds per tile)
+#endif
         for (int i = 0; i < 3 && !rc; i++) rc = trx_trace_primary_dev(s, view, w, h, trx_shard{0, 1, 0, 0}, sem, s->d_scratch_a, nullptr);
         s->dbg_iters = iters;
         if (!rc) e = hipDeviceSynchronize();
         if (e == hipSuccess && !rc) e = hipMemcpy(out_cost, s->dbg_cost, (size_t)n_tiles * 4, hipMemcpyDeviceToHost);
+#ifdef TRX_DEV_TUNE
+        if (e == hipSuccess && !rc && s->dbg_iters) e = hipMemcpy(out_iters, s->dbg_iters, (size_t)n_tiles * 4, hipMemcpyDeviceToHost);
+#endif
     }
     (void)hipDeviceSynchronize();
     (void)hipFree(s->dbg_cost);

@@ -424,6 +424,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave) + lane;
     const bool tie_first = P.tie_first != 0;
     if (P.wave_times && lane == 0) P.wave_times[kWaveTimeStride * wave_global] = wall_clock64();
+#ifdef TRX_TAIL_DIAG
+    // (diagnostic builds only, tools/gpu_tail.py: what was every wave's LAST tile, and when did it start?)
+    unsigned long long diag_t0 = 0ull, diag_chunk = 0ull, diag_tiles = 0ull;
+    uint32_t diag_pl = 0u, diag_cw = 0u;
+#endif
 #ifdef TRX_STAMPS
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
     unsigned long long k_refill = 0, k_fetch = 0, k_test = 0, k_tri = 0, k_pop = 0, k_iters = 0;
@@ -474,6 +479,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint32_t n_pend = 0;                     // tile-list entries parked in lds_pend (uniform)
     uint32_t tile_slot = TRX_INVALID;        // tile being timed (cost feedback)
     unsigned long long tile_t0 = 0;
+    uint32_t tile_trip0 = 0;
     uint32_t cur_tile = 0, my_tile = 0;      // tile of the current chunk (uniform) / of this lane's item
     // Lists are kept per (cost bucket, shard): kLptShards appenders per bucket, because one atomic
     // word saturates near 90 appends/us.  Entry e = (15 - bucket) * kLptShards + shard is the e-th
@@ -506,14 +512,27 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         ordered = intact && (uint32_t)__builtin_amdgcn_readlane((int)end_b, 63) == n_chunks; // complete lists
     }
 
-    // chunks below this index of the heaviest-first order take their successor's ticket late (measured: never / always /
-    // heaviest 3 % / 12 % / 50 %, profiles/r02_late_binding.log; the heavier half is best on every scene)
+    // Chunks below this index of the heaviest-first order take their successor's ticket LATE (when the wave is idle), the
+    // rest a tile ahead (hides the atomic's 1-2 us round trip, which only matters next to a tile of a few us).  Round 2
+    // cut the order in half by position (never / always / heaviest 3 % / 12 % / 50 %, profiles/r02_late_binding.log);
+    // round 3 looked at what the last waves out of a frame had been doing (tools/gpu_tail.py): starting a 20-30 us tile
+    // they had reserved a tile earlier, while hundreds of idle waves found the queues dry and left - the position cut
+    // sits in the middle of the 20-40 us tiles of the bistro-class frame.  The cut is a class now: tiles of 16 trips or more (class 7 and up, about 35 us mid-frame) bind late (profiles/r03_tile_classes.log:
+    // classes 6..9 within 1 % of each other, all ahead of the position cut).
+    constexpr uint32_t kLateClass = 7u;
+    uint32_t late_entry = (15u - kLateClass) * kLptShards + (kLptShards - 1u); // last list of that class in the concatenation
+    uint32_t late_cut = 0u;
 #ifdef TRX_DEV_TUNE
-    const uint32_t late_sel = (P.tune >> 4) & 7u ? (P.tune >> 4) & 7u : 4u; // 1 always, 2 / 3 / 4: heaviest 3 / 12 / 50 %, 5 never
-#else
-    const uint32_t late_sel = 4u;
+    const uint32_t late_sel = (P.tune >> 4) & 7u; // 1 always late, 2 / 3 / 4: heaviest 3 / 12 / 50 % by position, 5 never, 6: class = tune bits 20..23
+    if (late_sel == 6u) late_entry = (15u - ((P.tune >> 20) & 15u)) * kLptShards + (kLptShards - 1u);
 #endif
-    const uint32_t late_cut = late_sel == 1u ? 0xffffffffu : late_sel >= 5u ? 0u : late_sel == 4u ? (n_chunks >> 1) : P.prio_cut[late_sel - 2u];
+    if (ordered)
+        late_cut = late_entry < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)end_a, (int)late_entry)
+                                    : (uint32_t)__builtin_amdgcn_readlane((int)end_b, (int)(late_entry - 64u));
+#ifdef TRX_DEV_TUNE
+    if (late_sel >= 1u && late_sel <= 5u)
+        late_cut = late_sel == 1u ? 0xffffffffu : late_sel == 5u ? 0u : late_sel == 4u ? (n_chunks >> 1) : P.prio_cut[late_sel - 2u];
+#endif
     bool exhausted = false; // wave-uniform
     for (;;) {
         TRX_STAMP(k_pop);
@@ -524,12 +543,37 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             // the whole tile is done: record what it cost (feeds the next frame's tile order)
             if (lane == 0) {
                 const uint32_t c = (uint32_t)(wall_clock64() - tile_t0);
+#ifdef TRX_TAIL_DIAG
+                if (P.cost && (P.tune & 0x2000000u)) {
+                    P.cost[tile_slot] = ((uint32_t)diag_chunk << 16) | min(c, 65535u); // position in the order | cost
+                    if (P.tile_iters && !COUNT) P.tile_iters[tile_slot] = (min(trip - tile_trip0, 4095u) << 20) | (min(diag_pl, 1023u) << 10) | min(diag_cw, 1023u);
+                } else
+#endif
                 if (P.cost) P.cost[tile_slot] = c;
                 if (lpt_write) {
-                    // class = 2*log2(c) in half-octaves, 2.56 us .. 0.49 ms
-                    const uint32_t msb = 31u - (uint32_t)__clz((int)(c | 1u));
-                    const uint32_t kk = 2u * msb + (msb ? (c >> (msb - 1u)) & 1u : 0u);
-                    const uint32_t b = kk < 16u ? 0u : min(kk - 16u, 15u);
+                    // The tile's class for the next frame's order = its WORK, in half-octaves of traversal-loop trips (1, 2,
+                    // 3, 4, 6, 8 ... 256+), not its duration.  How long a tile takes depends on when it ran - at the start
+                    // of the frame with issue priority, mid-frame against four waves a SIMD, in the tail against none - so
+                    // a frame ordered by last frame's durations reshuffles itself every frame (static camera: 43 % of the
+                    // tiles moved by two duration classes or more from one frame to the next, tools/gpu_tail.py); trips
+                    // are a property of the tile and the view, the same every frame.  A least-squares fit of mid-frame tile
+                    // time on trips, per-lane triangle rounds and cooperative rounds explains no more than trips alone
+                    // (residual 28.8 against 29.4 us rms), and classes of weighted work measured slower, so: trips.
+                    // profiles/r03_tile_classes.log: hairball-class frame -6 %, dense -1.8 %, bistro-class -1.5 %.
+                    uint32_t b;
+#ifdef TRX_DEV_TUNE
+                    if (P.tune & 0x4000000u) { // round-2 classes: 2*log2(duration), 2.56 us .. 0.49 ms
+                        const uint32_t msb = 31u - (uint32_t)__clz((int)(c | 1u));
+                        const uint32_t kk = 2u * msb + (msb ? (c >> (msb - 1u)) & 1u : 0u);
+                        b = kk < 16u ? 0u : min(kk - 16u, 15u);
+                    } else
+#endif
+                    {
+                        const uint32_t wk = max(trip - tile_trip0, 1u);
+                        const uint32_t msb = 31u - (uint32_t)__clz((int)wk);
+                        const uint32_t kk = 2u * msb + (msb ? (wk >> (msb - 1u)) & 1u : 0u);
+                        b = kk == 0u ? 0u : min(kk - 1u, 15u);
+                    }
                     const uint32_t list = b * kLptShards + ((wave_global ^ tile_slot) & (kLptShards - 1u));
                     // park the entry in LDS: the appends (returning atomics) are issued together,
                     // one lane each, when the buffer fills or the wave exits, off every tile's path
@@ -605,6 +649,15 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     if ((P.cost || lpt_write) && n_idle == (uint32_t)kWave && given == 0u) {
                         tile_slot = cur_tile; // cost is filed under the tile, not the chunk
                         tile_t0 = wall_clock64();
+                        tile_trip0 = trip;
+#ifdef TRX_TAIL_DIAG
+                        diag_pl = diag_cw = 0u;
+#endif
+#ifdef TRX_TAIL_DIAG
+                        diag_t0 = tile_t0;
+                        diag_chunk = chunk;
+                        diag_tiles++;
+#endif
                         s_wnode = c_wnode;
                         s_wtri = c_wtri;
                     }
@@ -790,14 +843,17 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 // hand-offs), so they only pay when the wave's triangles sit in few lanes: 64 coherent rays testing
                 // the same two triangles are 128 pairs = 2 cooperative rounds, but also just 2 per-lane rounds.
                 bool coop = false;
-                uint32_t incl = 0u, total = 0u;
+                uint32_t incl = 0u, total = 0u, mx = 1u;
                 if (__ballot(cnt >= P.tri_compact_min) != 0ull) {
                     incl = wave_scan_add(cnt);
                     total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    const uint32_t mx = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_max(cnt), 63);
+                    mx = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_max(cnt), 63);
                     // per-lane rounds carry kBatch triangles of a lane each, cooperative rounds 64 pairs of the wave
                     coop = (mx + (uint32_t)kBatch - 1u) / (uint32_t)kBatch > P.tri_coop_ratio * ((total + 63u) >> 6);
                 }
+#ifdef TRX_TAIL_DIAG
+                if (coop) diag_cw += (total + 63u) >> 6; else diag_pl += mx; // cooperative windows / per-lane rounds of the tile
+#endif
                 if (!coop) {
                     // Per-lane rounds, up to kBatch triangles of a lane per round: their records are requested
                     // together (one memory round trip per round instead of one per triangle; on incoherent rays the
@@ -1206,6 +1262,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         // the last wave out re-arms the queue for the next launch on this slot
         if (P.wave_times) {
             P.wave_times[kWaveTimeStride * wave_global + 1] = wall_clock64();
+#ifdef TRX_TAIL_DIAG
+            P.wave_times[kWaveTimeStride * wave_global + 2] = diag_t0;     // start of the wave's last tile
+            P.wave_times[kWaveTimeStride * wave_global + 3] = diag_chunk;  // its position in the frame's order
+            P.wave_times[kWaveTimeStride * wave_global + 4] = diag_tiles;  // tiles the wave traced
+#endif
 #ifdef TRX_STAMPS
             unsigned long long *wt = P.wave_times + kWaveTimeStride * wave_global;
             wt[2] = k_refill; wt[3] = k_fetch; wt[4] = k_test; wt[5] = k_tri; wt[6] = k_pop; wt[7] = k_iters;
