@@ -781,10 +781,11 @@ def test_frame_loop_keeps_one_tile_order_per_pass_kind(trx, orc):
         sc.close()
 
 
-def test_camera_cuts_reset_the_tile_order_and_never_the_hits(trx, orc):
-    """A learnt tile order belongs to a view: alternating between two unrelated cameras (every frame a cut: natural
-    order while the tiles are measured), drifting slowly (the previous frame's order is replayed), and variant bit 7
-    (every frame treated as a cut) only change WHEN tiles are traced - each frame equals the oracle's."""
+def test_camera_cuts_and_schedule_modes_never_change_the_hits(trx, orc):
+    """The tile order is replayed whatever the camera did (a stale order measured no worse than none); a camera cut
+    restarts the schedule tuner.  Alternating between two unrelated cameras (every frame a cut), drifting slowly, variant
+    bit 7 (every frame runs as a first frame: natural order) and the tuner's own mode switches only change WHEN tiles
+    are traced - each frame equals the oracle's."""
     w, h = 328, 200
     flat, view, osc, ov = make_scene(trx, orc, "bistro", 150000, w, h)
     eye, look, fov = trx.scene_camera("bistro")

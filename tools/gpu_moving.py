@@ -21,9 +21,15 @@ buf = torch.empty(w * h, dtype=torch.int64, device="cuda")
 STEP = float(os.environ.get("STEP", "0.05"))
 
 
+ROT = float(os.environ.get("ROT", "0"))  # degrees of yaw per frame about the eye (with STEP=0: a turning camera)
+
+
 def view_at(f):
     off = STEP * f
-    return T.view_from_camera((eye[0] + off, eye[1], eye[2]), (look[0] + off, look[1], look[2]), fov, w, h)
+    a = np.radians(ROT * f)
+    dx, dz = look[0] - eye[0], look[2] - eye[2]
+    lx, lz = eye[0] + dx * np.cos(a) - dz * np.sin(a), eye[2] + dx * np.sin(a) + dz * np.cos(a)
+    return T.view_from_camera((eye[0] + off, eye[1], eye[2]), (lx + off, look[1], lz), fov, w, h)
 
 
 def run(views):

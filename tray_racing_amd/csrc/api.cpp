@@ -457,15 +457,20 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         key = ((uint64_t)p.width << 40) ^ ((uint64_t)p.height << 20) ^ ((uint64_t)p.shard_count << 8) ^ p.shard_index ^
               ((uint64_t)(mode + 1) << 60) ^ ((uint64_t)p.n_frames << 56);
         uint32_t *set[2] = {ord.lists, ord.lists + set_words};
-        // A learnt order belongs to a view.  New image geometry, or a camera cut (the eye jumped by more than 1 % of
-        // the scene's diagonal, the view direction turned by more than 2 degrees, or the projection changed) since the
-        // last frame of this kind on this slot: this frame runs in natural order while it measures its tiles, instead
-        // of replaying an order learnt for another view, and the schedule tuner starts over (TraceParams::new_view -
-        // no extra command on the stream: the kernel skips the stale lists and its exit wave empties them as after
-        // any frame).  (A probe pass that predicts the order of such a frame - one centre ray per tile - was built
-        // and measured in round 3: it is bound by the latency of its longest ray and costs more than the order
-        // gains, profiles/r03_probe_cap.log.)  Variant bit 7 treats every frame as a cut (bench.py's first-frame leg).
-        bool cut = ord.key != key || ((variant >> 7) & 1u);
+        // The order was learnt for an image geometry (the key); it is replayed whatever the camera did since.  Round 3
+        // first emptied the lists at a camera cut - natural order while the new view is measured - and then measured
+        // that choice once the classes were trips instead of durations (profiles/r03_camera_cut.log): a camera turning
+        // 5 / 10 / 20 / 45 degrees PER FRAME runs 0.51 / 0.58 / 0.61 / 0.60 ms replaying the previous frame's order
+        // against 0.58 / 0.63 / 0.62 / 0.61 ms in natural order, one moving 0.5 / 1 / 2 / 4 m per frame 0.46 / 0.48 /
+        // 0.42 / 0.41 ms against 0.61 / 0.61 / 0.52 / 0.50 - a stale order is never worse than none, and far better
+        // for any motion a renderer would call continuous.  What a cut (the eye jumped by more than 1 % of the scene's
+        // diagonal, the view turned by more than 2 degrees, or the projection changed) still does is restart the
+        // schedule tuner, whose choice (ordered / natural order / mid-tile refills) was measured for the old view.
+        // (A probe pass that predicts the order of a first frame - one centre ray per tile - was built and measured
+        // too: bound by the latency of its longest ray, it costs more than the order gains, profiles/r03_probe_cap.log.)
+        // Variant bit 7: every frame runs as the first frame of its geometry (bench.py's first-frame leg).
+        const bool no_order = ord.key != key || ((variant >> 7) & 1u);
+        bool cut = no_order;
         if (!cut) {
             const ViewDev &a = ord.view, &b = p.views[0];
             const float ex = a.eye[0] - b.eye[0], ey = a.eye[1] - b.eye[1], ez = a.eye[2] - b.eye[2];
@@ -477,7 +482,11 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         ord.key = key;
         // (variant bit 19: feedback always on, for A/B runs)
         p.fb = (s->dbg_cost || ((variant >> 19) & 1u)) ? nullptr : &slot.ctr->fb[mode == kModeAo ? 1 : 0];
+        p.no_order = no_order ? 1u : 0u;
         p.new_view = cut ? 1u : 0u;
+#ifdef TRX_DEV_TUNE
+        if (p.tune & 0x8000000u) p.no_order = cut ? 1u : 0u; // (A/B: the round-3 first version, natural order after a cut)
+#endif
         if (fresh) { // new lists start empty (from then on every frame's exit wave leaves the set it read empty)
             HIP_TRY(hipMemsetAsync(set[0], 0, n_lists * sizeof(uint32_t), stream));
             HIP_TRY(hipMemsetAsync(set[1], 0, n_lists * sizeof(uint32_t), stream));
@@ -497,9 +506,9 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         for (int i = 0; i < 3; i++) p.prio_cut[i] = c[i] ? n_tiles / c[i] : 0u;
     }
     if (s->dbg_cost) { // diagnostics: cold tile order, costs / iteration counts into the caller's buffers
-        p.new_view = 1u;
+        p.no_order = 1u;
 #ifdef TRX_DEV_TUNE
-        if (p.tune & 0x2000000u) p.new_view = 0u; // (tools/gpu_tail.py: the costs of a frame in its LEARNT order)
+        if (p.tune & 0x2000000u) p.no_order = 0u; // (tools/gpu_tail.py: the costs of a frame in its LEARNT order)
 #endif
         p.cost = s->dbg_cost;
         p.tile_iters = s->dbg_iters;

@@ -125,7 +125,8 @@ struct TraceParams {
     // frames per launch (image modes): frame f = local_tile / tiles_per_frame uses views[f] and writes its
     // records at out + f * frame_stride; one launch then balances n_frames x the tiles
     FbState *fb;          // image passes with tile-order feedback: the schedule tuner's state (null = feedback always on)
-    uint32_t new_view;    // camera cut: ignore the learnt order (the lists are emptied as usual), restart the tuner
+    uint32_t no_order;    // ignore the lists of the previous frame (they are emptied as usual): first frame of an image geometry
+    uint32_t new_view;    // camera cut: the schedule tuner starts over
     uint32_t uni_decode;  // coherent primary walk: decode the child planes of a node step once per wave when every lane visits the same node
     uint32_t any_hit;     // explicit rays only: stop at the first accepted hit, write one byte (0/1) per ray
     uint32_t n_frames, tiles_per_frame, frame_stride;

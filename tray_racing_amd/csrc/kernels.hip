@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     const uint32_t refill_idle = (fb_mode == 2u && P.n_frames == 1u) ? kFbRefill : P.refill_idle;
     if (P.fb && wave_global == 0u && lane == 0u) P.fb->t0 = wall_clock64(); // (about when the frame's first waves start)
     const bool lpt_write = P.lpt_write_counts != nullptr && !fb_off;
-    if (P.lpt_read_counts && !fb_off && !P.new_view) {
+    if (P.lpt_read_counts && !fb_off && !P.no_order) {
         end_a = P.lpt_read_counts[(15u - (lane >> 3)) * kLptShards + (lane & 7u)];
         end_b = P.lpt_read_counts[(15u - ((lane + 64u) >> 3)) * kLptShards + (lane & 7u)];
         // a list that overflowed its capacity dropped entries: fall back to the natural order
