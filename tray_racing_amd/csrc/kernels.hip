@@ -533,6 +533,14 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     if (late_sel >= 1u && late_sel <= 5u)
         late_cut = late_sel == 1u ? 0xffffffffu : late_sel == 5u ? 0u : late_sel == 4u ? (n_chunks >> 1) : P.prio_cut[late_sel - 2u];
 #endif
+    // ... and so do the last tiles of the order, half as many as there are waves: a ticket reserved a tile ahead there is a
+    // tile that an idle wave could have started (profiles/r03_tile_classes.log section 9: 0 / 1024 / 2048 / 4096 / 8192
+    // tiles with 4096 waves; kitchen-class -2 %, bistro-class -1 %, the others unchanged up to 2048, slower beyond)
+    uint32_t tail_tiles = (gridDim.x * (blockDim.x / kWave)) >> 1;
+#ifdef TRX_DEV_TUNE
+    if (P.tune >> 28) tail_tiles = ((P.tune >> 28) == 15u ? 0u : (P.tune >> 28) * 1024u);
+#endif
+    const uint32_t tail_cut = n_chunks > tail_tiles ? n_chunks - tail_tiles : 0u;
     bool exhausted = false; // wave-uniform
     for (;;) {
         TRX_STAMP(k_pop);
@@ -623,7 +631,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     // wave could have started.  Late binding wins wherever tiles are long or of unknown cost - the heavier
                     // half of the heaviest-first order, and every pass that has no learnt order (first frame, AO, explicit
                     // rays); only the light half of an ordered frame keeps the prefetch
-                    have_pending = ordered && ticket * (P.single_queue ? 1u : 8u) >= late_cut;
+                    have_pending = ordered && ticket * (P.single_queue ? 1u : 8u) >= late_cut && ticket * (P.single_queue ? 1u : 8u) < tail_cut;
                     if (have_pending && lane == 0) pending = atomicAdd(&P.ctr->heads[my_q].taken, 1u);
                     const uint32_t chunk = P.single_queue ? ticket : ticket * 8u + my_q;
                     chunk_next = chunk << 6;
