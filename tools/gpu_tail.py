@@ -83,4 +83,15 @@ print("mid-frame tiles: us = %.2f trips + %.2f per-lane rounds + %.2f cooperativ
     *coef, np.sqrt(np.mean((pred[mid] - us[mid]) ** 2)),
     np.sqrt(np.mean((np.polyval(np.polyfit(trips[mid], us[mid], 1), trips[mid]) - us[mid]) ** 2))))
 print("per tile: trips mean %.1f max %d | per-lane rounds mean %.1f | cooperative rounds mean %.1f" % (trips.mean(), trips.max(), pl.mean(), cw.mean()))
+us0 = prof[0][1]
+fit = np.polyfit(trips[mid], us[mid], 1)
+r0, r1 = us0 - np.polyval(fit, trips), us - np.polyval(fit, trips)
+same_pos = prof[0][0] == pos
+print("two consecutive learnt frames: %.1f %% of the tiles at the same position; residual (us - fit(trips)) correlation frame to frame %.2f (mid-frame tiles), %.2f (positions > 60 %%)" % (
+    100 * same_pos.mean(), np.corrcoef(r0[mid], r1[mid])[0, 1], np.corrcoef(r0[pos > 0.6 * n_tiles], r1[pos > 0.6 * n_tiles])[0, 1]))
+latep = pos > 0.6 * n_tiles
+for name_, x in (("trips", trips), ("per-lane rounds", pl), ("cooperative rounds", cw)):
+    print("  positions > 60 %%: correlation of tile time with %s %.2f" % (name_, np.corrcoef(x[latep], us[latep])[0, 1]))
+worst = np.argsort(-(us * latep))[:10]
+print("  slowest late tiles: " + "; ".join("%.0f us (%d trips, %d+%d rounds, pos %.0f%%, x %d y %d)" % (us[i], trips[i], pl[i], cw[i], 100.0 * pos[i] / n_tiles, i % ((w + 7) // 8), i // ((w + 7) // 8)) for i in worst))
 sc.close()
