@@ -1,0 +1,28 @@
+"""Per-wave lifetimes of one AO pass (trx_debug_wave_timeline_ao): how much of the pass is waves waiting for its longest rays?
+usage: python tools/gpu_timeline_ao.py hairball bistro   (TRX_VARIANT=<kernel variant word>)"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tray_racing_amd as T
+from tray_racing_amd import _lib as L
+lib = L.load()
+lib.trx_set_kernel_variant(int(os.environ.get("TRX_VARIANT", "0"), 0))
+for name in sys.argv[1:]:
+    w, h = 1920, 1080
+    verts, counts = T.gen_scene(name, 0, 1)
+    flat = T.flat_build(verts, counts)
+    eye, look, fov = T.scene_camera(name)
+    view = T.view_from_camera(eye, look, fov, w, h)
+    sc = T.Scene(flat)
+    buf = np.zeros(8 * 8192, dtype=np.uint64)
+    n = C.c_uint32()
+    for _ in range(6):
+        L.check(lib.trx_debug_wave_timeline_ao(sc.handle, C.byref(view), w, h, 3, buf.ctypes.data_as(C.c_void_p), 8192, C.byref(n)))
+    r = buf[: 8 * n.value].reshape(-1, 8).astype(np.int64)
+    t0 = r[:, 0].min()
+    start, end = (r[:, 0] - t0) / 100.0, (r[:, 1] - t0) / 100.0
+    print("%s AO: %d waves, pass %.1f us | end p10 %.1f p50 %.1f p90 %.1f max %.1f | mean lifetime %.1f us (%.0f%%)" % (
+        name, n.value, end.max(), np.percentile(end, 10), np.percentile(end, 50), np.percentile(end, 90), end.max(), (end - start).mean(), 100 * (end - start).mean() / end.max()))
+    ts = np.linspace(0, end.max(), 11)
+    print("   alive at 0..100%%: %s" % [int(((start <= x) & (end > x)).sum()) for x in ts])
+    sc.close()

@@ -51,7 +51,10 @@ for name in names:
         for tune, variant in words:
             os.environ["TRX_TUNE"] = str(tune)
             lib.trx_set_kernel_variant(variant)
-            t_ao = timed(lambda k: sc.trace_ao_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=3, frame=0, ao_eps=0.01))
+            vary = int(os.environ.get("AO_FRAME_VARIES", "0"))  # 1: a new noise seed every pass, as a renderer would
+            t_ao = timed(lambda k: sc.trace_ao_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=3, frame=(k if vary else 0), ao_eps=0.01))
+            if vary:
+                sc.trace_ao_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=3, frame=0, ao_eps=0.01)
             t_rays = timed(lambda k: sc.trace_rays_dev(d_rays.data_ptr(), n, d_hits.data_ptr(), sem=3))
             sc.check()
             a, r = d_ao.cpu().numpy(), d_hits.cpu().numpy()

@@ -975,6 +975,19 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 
 
 
+        // Incoherent passes end when their longest rays do (a third of the hairball-class AO pass's wave time is waves
+        // waiting for them, and dealing the tiles longest ray first does not move that tail: profiles/r03_ao_order.log, tools/gpu_timeline_ao.py), so
+        // a wave that holds an old ray wins the issue arbitration of its SIMD: priority 2 once its oldest ray has run
+        // kOldRay trips, 3 from twice that, looked at every eighth trip.  Worth 1-2 % of an AO pass (four alternating
+        // repetitions on four scenes, all four means lower; the run-to-run spread of an AO pass is +-2 %).
+        constexpr uint32_t kOldRay = 32u;
+        auto old_ray_priority = [&]() {
+            const uint32_t age = has_ray ? trip - steps : 0u;
+            if (__ballot(age >= 2u * kOldRay) != 0ull) __builtin_amdgcn_s_setprio(3);
+            else if (__ballot(age >= kOldRay) != 0ull) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+        };
+
         // Finished ray: the hit record (or the any-hit flag) leaves the lane.
         auto finish_lane = [&]() {
             if (MODE == kModeRays && P.any_hit != 0u) {
@@ -998,6 +1011,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 const bool act = has_ray;
                 uint2 tri = make_uint2(0u, 0u);
                 trip++;
+#ifdef TRX_DEV_TUNE
+                if (!(P.tune & 0x10000000u)) // (A/B: no priority by ray age)
+#endif
+                if (MODE != kModePrimary && (trip & 7u) == 0u) old_ray_priority();
                 // Coherent primary rays (BLAS only): when every lane that steps visits the SAME node - 47 % of the wave-level
                 // node steps on the bistro-class frame, 90 % on the kitchen-class one - its 48 quantised plane bytes are
                 // converted once, one byte per lane, parked in LDS as floats and read back by address (node_intersect_dec)
@@ -1190,6 +1207,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             for (;;) {
                 const bool act = has_ray;
                 trip++;
+#ifdef TRX_DEV_TUNE
+                if (!(P.tune & 0x10000000u)) // (A/B: no priority by ray age)
+#endif
+                if (MODE != kModePrimary && (trip & 7u) == 0u) old_ray_priority();
                 // (1)
                 if (act && !fetched && (cur.y & 0xff000000u)) {
                     const uint32_t hits_imask = cur.y;
