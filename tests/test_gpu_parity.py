@@ -816,3 +816,47 @@ def test_camera_cuts_and_schedule_modes_never_change_the_hits(trx, orc):
     finally:
         lib.trx_set_kernel_variant(0)
         sc.close()
+
+
+def test_literal_division_shortcut_is_exact_at_its_edges(trx, orc):
+    """TRX_SEM_HLSL divides per node like the shader (query.hlsl:237-243); the kernel computes e / d as e * (1/d) where
+    that is the same float (e a power of two, nothing leaves the normal range) and divides otherwise.  Rays whose
+    direction components are denormal, enormous, zero, or just inside the allowed range, and a scene so small that its
+    exponent bytes fall below 21, take the other path - every hit equals the oracle's, which always divides."""
+    w, h = 64, 64
+    flat, _view, osc, _ov = make_scene(trx, orc, "cornell", 0, w, h)
+    rays = random_rays(trx, flat, 4096, 77)
+    d = rays["direction"]
+    rng = np.random.default_rng(5)
+    edge = np.array([1e-39, -1e-39, 1.2e-38, -1.2e-38, 1e-30, 1048576.0, -1048576.0, 1048577.0, 3e6, -2.5e30, 0.0, -0.0,
+                     1.17549435e-38, 5e-324], dtype=np.float64).astype(np.float32)
+    for i in range(64, 2048):                      # one or two edge components per ray, the rest as drawn
+        d[i, rng.integers(0, 3)] = edge[rng.integers(0, edge.size)]
+        if i % 3 == 0:
+            d[i, rng.integers(0, 3)] = edge[rng.integers(0, edge.size)]
+    rays["direction"] = d
+    sc = trx.Scene(flat)
+    try:
+        for sem in (0, 2, 4, 6):                   # every semantics word whose node test divides
+            got, _ = sc.trace_rays(rays, sem=sem)
+            want, _ = osc.trace_rays(rays, sem=sem)
+            assert_hits_equal(got, want, "edge directions, sem %d" % sem)
+    finally:
+        sc.close()
+    # the same tree with every exponent byte lowered by 40 (boxes 2^-40 of their size, some bytes below 21): the shortcut
+    # is off for the whole scene, and whatever the collapsed boxes let through is what the oracle lets through
+    import copy
+    low = copy.copy(flat)
+    low.nodes = flat.nodes.copy()
+    eb = low.nodes.view(np.uint8).reshape(-1, 80)[:, 12:15]
+    eb[:] = np.maximum(eb.astype(np.int32) - 40, 1).astype(np.uint8)
+    assert (eb < 21).any() and (eb >= 21).any()
+    losc = orc.Scene.from_flat(low)
+    sc = trx.Scene(low)
+    try:
+        for sem in (0, 3):
+            got, _ = sc.trace_rays(rays, sem=sem)
+            want, _ = losc.trace_rays(rays, sem=sem)
+            assert_hits_equal(got, want, "lowered exponents, sem %d" % sem)
+    finally:
+        sc.close()

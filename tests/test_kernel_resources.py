@@ -1,0 +1,31 @@
+"""The traversal kernels must not spill: they sit within a few registers of the 128-VGPR budget that four waves a
+SIMD allow, and a spill (scratch memory) is silent - the results stay right and a pass gets slower.  Reads the resource
+metadata the compiler emits with the device assembly (make build/kernels.s)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tray_racing_amd", "csrc")
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_no_product_kernel_spills_or_exceeds_128_vgprs():
+    subprocess.run(["make", "-C", CSRC, "build/kernels.s"], check=True, capture_output=True, timeout=600)
+    text = open(os.path.join(CSRC, "build", "kernels.s")).read()
+    seen = 0
+    for m in re.finditer(r"\.name:\s+(\S*k_trace\S*)\n(.*?)\.wavefront_size", text, re.S):
+        name, body = m.group(1), m.group(2)
+        t = re.search(r"k_traceILi(\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)", name)
+        assert t, name
+        mode, tlas, node, pipe, count = (int(x) for x in t.groups())
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", body).group(1))
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
+        seen += 1
+        if count:
+            continue  # the counting kernels (diagnostics, trx_count_*) may spill: they are never timed
+        assert vgpr <= 128, "k_trace<mode %d, tlas %d, node %d, pipe %d>: %d VGPRs" % (mode, tlas, node, pipe, vgpr)
+        assert scratch == 0, "k_trace<mode %d, tlas %d, node %d, pipe %d> spills %d bytes" % (mode, tlas, node, pipe, scratch)
+    assert seen >= 3 * 2 * 4, "kernel metadata not found (%d kernels)" % seen

@@ -142,6 +142,7 @@ struct trx_scene {
     uint32_t n_inst = 0, tlas_start = 0;
     bool tlas = false;
     float scene_diag = 0.f; // diagonal of the root node's box (camera-cut detection scales with it)
+    bool exp_exact = false; // every node exponent byte is 0 or >= 21 (TraceParams::exp_exact)
     int grid = 0;      // default number of persistent waves
     int cu_count = 0;
     unsigned long long *d_wave_times = nullptr; // diagnostics only (trx_debug_wave_timeline)
@@ -389,6 +390,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.inst_entry = s->d_inst_entry;
     p.inst_xform = s->d_inst_xform;
     p.tlas_start = s->tlas_start;
+    p.exp_exact = s->exp_exact ? 1u : 0u;
     p.ctr = slot.ctr;
     p.spill = slot.spill;
     p.tie_first = (sem & TRX_SEM_TIE_FIRST) ? 1u : 0u;
@@ -675,6 +677,14 @@ int trx_scene_create(const void *bvh_bytes, uint64_t n_nodes, const void *tri_by
             d2 += ext * ext;
         }
         s->scene_diag = (float)std::sqrt(d2);
+    }
+    {   // may the literal-division node test multiply e = 2^(byte - 127) by the ray's 1/d instead of dividing by d?  Exact
+        // while the product stays normal: exponent bytes 0 (e = 0) or >= 21 with |1/d| >= 2^-20 (kernels.hip, pow2)
+        bool ok = true;
+        const CwbvhNode *nodes = (const CwbvhNode *)bvh_bytes;
+        for (uint64_t i = 0; i < n_nodes && ok; i++)
+            for (int k = 0; k < 3; k++) ok = ok && (nodes[i].e[k] == 0 || nodes[i].e[k] >= 21);
+        s->exp_exact = ok;
     }
     if (s->grid <= 0) return cleanup(fail(TRX_ERR_NO_DEVICE, "could not size the persistent grid"));
     *out = s;

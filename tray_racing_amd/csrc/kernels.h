@@ -125,6 +125,7 @@ struct TraceParams {
     // frames per launch (image modes): frame f = local_tile / tiles_per_frame uses views[f] and writes its
     // records at out + f * frame_stride; one launch then balances n_frames x the tiles
     FbState *fb;          // image passes with tile-order feedback: the schedule tuner's state (null = feedback always on)
+    uint32_t exp_exact;   // every exponent byte of the scene's nodes is 0 or >= 21: e / d may be computed as e * (1/d) exactly (kernels.hip, pow2)
     uint32_t no_order;    // ignore the lists of the previous frame (they are emptied as usual): first frame of an image geometry
     uint32_t new_view;    // camera cut: the schedule tuner starts over
     uint32_t uni_decode;  // coherent primary walk: decode the child planes of a node step once per wave when every lane visits the same node

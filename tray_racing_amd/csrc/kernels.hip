@@ -93,7 +93,7 @@ __device__ __forceinline__ float ubyte(uint32_t x, int j) { return (float)((x >>
 template <int NODE>
 __device__ __forceinline__ uint32_t node_intersect(const Ray &r, float max_distance, const uint4 n0,
                                                    const uint4 n1, const uint4 n2, const uint4 n3,
-                                                   const uint4 n4) {
+                                                   const uint4 n4, const bool pow2) {
     const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
     const uint32_t e_imask = n0.w;
     const float ex = __uint_as_float((e_imask & 0xffu) << 23);
@@ -107,6 +107,18 @@ __device__ __forceinline__ uint32_t node_intersect(const Ray &r, float max_dista
         bx = (px - r.ox) * r.ix;
         by = (py - r.oy) * r.iy;
         bz = (pz - r.oz) * r.iz;
+    } else if (pow2) {
+        // The shader divides per node (query.hlsl:237-243).  e is a power of two, and a correctly rounded quotient
+        // scales exactly with powers of two: RN(2^k / d) = 2^k * RN(1 / d) bit for bit, as long as neither side leaves
+        // the normal range - which pow2_exact() below guarantees from the ray (every |d| normal and <= 2^20) and the
+        // scene (every exponent byte 0 or >= 21); overflow to infinity happens to both sides at the same threshold.
+        // Three of the six IEEE divisions of a node step become multiplications by the ray's 1/d.
+        ax = ex * r.ix;
+        ay = ey * r.iy;
+        az = ez * r.iz;
+        bx = (px - r.ox) / r.dx;
+        by = (py - r.oy) / r.dy;
+        bz = (pz - r.oz) / r.dz;
     } else {
         ax = ex / r.dx;
         ay = ey / r.dy;
@@ -157,7 +169,7 @@ __device__ __forceinline__ uint32_t node_intersect(const Ray &r, float max_dista
 // every lane of a sign class reads the same 16 bytes, which LDS broadcasts.  Same values, same operations, same mask.
 template <int NODE>
 __device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_distance, const uint4 n0, const uint4 n1,
-                                                       const float *dec) {
+                                                       const float *dec, const bool pow2) {
     const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
     const uint32_t e_imask = n0.w;
     const float ex = __uint_as_float((e_imask & 0xffu) << 23);
@@ -171,6 +183,18 @@ __device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_d
         bx = (px - r.ox) * r.ix;
         by = (py - r.oy) * r.iy;
         bz = (pz - r.oz) * r.iz;
+    } else if (pow2) {
+        // The shader divides per node (query.hlsl:237-243).  e is a power of two, and a correctly rounded quotient
+        // scales exactly with powers of two: RN(2^k / d) = 2^k * RN(1 / d) bit for bit, as long as neither side leaves
+        // the normal range - which pow2_exact() below guarantees from the ray (every |d| normal and <= 2^20) and the
+        // scene (every exponent byte 0 or >= 21); overflow to infinity happens to both sides at the same threshold.
+        // Three of the six IEEE divisions of a node step become multiplications by the ray's 1/d.
+        ax = ex * r.ix;
+        ay = ey * r.iy;
+        az = ez * r.iz;
+        bx = (px - r.ox) / r.dx;
+        by = (py - r.oy) / r.dy;
+        bz = (pz - r.oz) / r.dz;
     } else {
         ax = ex / r.dx;
         ay = ey / r.dy;
@@ -261,6 +285,16 @@ __device__ __forceinline__ void finish_ray_dir(Ray &r, float dx, float dy, float
     r.iz = 1.0f / r.dz;
     r.oct_inv4 = (r.dx < 0.0f ? 0u : 0x04040404u) | (r.dy < 0.0f ? 0u : 0x02020202u) |
                  (r.dz < 0.0f ? 0u : 0x01010101u);
+    // bit 31 (masked out wherever oct_inv4 is used): this ray's direction does NOT allow e / d = e * (1/d) exactly
+    const float lo = 1.17549435e-38f, hi = 1048576.0f; // 2^-126 (smallest normal), 2^20; a NaN fails both
+    const bool exact = fabsf(r.dx) >= lo && fabsf(r.dx) <= hi && fabsf(r.dy) >= lo && fabsf(r.dy) <= hi &&
+                       fabsf(r.dz) >= lo && fabsf(r.dz) <= hi;
+    if (!exact) r.oct_inv4 |= 0x80000000u;
+}
+
+// Wave-uniform: may this node step of the literal-division variants multiply by 1/d (node_intersect, pow2)?
+__device__ __forceinline__ bool pow2_exact(const TraceParams &P, const Ray &r, bool act) {
+    return P.exp_exact != 0u && __ballot(act && (r.oct_inv4 >> 31) != 0u) == 0ull;
 }
 
 __device__ __forceinline__ void mat4_mul(const float *m, float v0, float v1, float v2, float v3, float &r0,
@@ -1009,12 +1043,13 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         if constexpr (!PIPE) {
             for (;;) {
                 const bool act = has_ray;
+                const bool pow2 = (NODE & 1) ? false : pow2_exact(P, r, act); // (literal-division variants only)
                 uint2 tri = make_uint2(0u, 0u);
                 trip++;
 #ifdef TRX_DEV_TUNE
                 if (!(P.tune & 0x10000000u)) // (A/B: no priority by ray age)
 #endif
-                if (MODE != kModePrimary && (trip & 7u) == 0u) old_ray_priority();
+                if (!TLAS && MODE != kModePrimary && (trip & 7u) == 0u) old_ray_priority(); // (the two-level AO kernel has no register to spare for it)
                 // Coherent primary rays (BLAS only): when every lane that steps visits the SAME node - 47 % of the wave-level
                 // node steps on the bistro-class frame, 90 % on the kitchen-class one - its 48 quantised plane bytes are
                 // converted once, one byte per lane, parked in LDS as floats and read back by address (node_intersect_dec)
@@ -1040,7 +1075,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                                 const uint4 n0 = np[0], n1 = np[1];
                                 cur.y &= ~(1u << child_bit);
                                 stack_push(cur, (cur.y & 0xff000000u) != 0u);
-                                const uint32_t hitmask = node_intersect_dec<NODE>(r, t, n0, n1, lds_dec);
+                                const uint32_t hitmask = node_intersect_dec<NODE>(r, t, n0, n1, lds_dec, pow2);
                                 cur.x = n1.x;
                                 tri.x = n1.y;
                                 cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -1090,7 +1125,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             }
     #endif
                         }
-                        const uint32_t hitmask = node_intersect<NODE>(r, t, n0, n1, n2, n3, n4);
+                        const uint32_t hitmask = node_intersect<NODE>(r, t, n0, n1, n2, n3, n4, pow2);
                         cur.x = n1.x;
                         tri.x = n1.y;
                         cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -1206,11 +1241,12 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             // order, triangle order and the t every test sees are those of the plain walk.
             for (;;) {
                 const bool act = has_ray;
+                const bool pow2 = (NODE & 1) ? false : pow2_exact(P, r, act); // (literal-division variants only)
                 trip++;
 #ifdef TRX_DEV_TUNE
                 if (!(P.tune & 0x10000000u)) // (A/B: no priority by ray age)
 #endif
-                if (MODE != kModePrimary && (trip & 7u) == 0u) old_ray_priority();
+                if (!TLAS && MODE != kModePrimary && (trip & 7u) == 0u) old_ray_priority(); // (the two-level AO kernel has no register to spare for it)
                 // (1)
                 if (act && !fetched && (cur.y & 0xff000000u)) {
                     const uint32_t hits_imask = cur.y;
@@ -1258,7 +1294,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 TRX_STAMP(k_pop);
                 // (4)
                 if (fetched) {
-                    const uint32_t hitmask = node_intersect<NODE>(r, t, pn0, pn1, pn2, pn3, pn4);
+                    const uint32_t hitmask = node_intersect<NODE>(r, t, pn0, pn1, pn2, pn3, pn4, pow2);
                     cur.x = pn1.x;
                     ptri.x = pn1.y;
                     cur.y = (hitmask & 0xff000000u) | (pn0.w >> 24);
