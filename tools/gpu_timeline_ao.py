@@ -25,4 +25,13 @@ for name in sys.argv[1:]:
         name, n.value, end.max(), np.percentile(end, 10), np.percentile(end, 50), np.percentile(end, 90), end.max(), (end - start).mean(), 100 * (end - start).mean() / end.max()))
     ts = np.linspace(0, end.max(), 11)
     print("   alive at 0..100%%: %s" % [int(((start <= x) & (end > x)).sum()) for x in ts])
+    if r[:, 5].any():  # -DTRX_TAIL_DIAG build: the moment each wave found the queues dry
+        dry, alive, age, trips = (r[:, 5] - t0) / 100.0, r[:, 6], r[:, 7] & 0xffffffff, r[:, 7] >> 32
+        left = end - dry
+        print("   queues dry for a wave at p10 %.0f p50 %.0f p90 %.0f us | rays it still held: mean %.1f | oldest of them %.0f trips (mean) | time to finish them: p10 %.0f p50 %.0f p90 %.0f max %.0f us" % (
+            np.percentile(dry, 10), np.percentile(dry, 50), np.percentile(dry, 90), alive.mean(), age.mean(),
+            np.percentile(left, 10), np.percentile(left, 50), np.percentile(left, 90), left.max()))
+        print("   trips per wave: mean %.0f -> %.2f us per trip over the wave's life; in the tail (after dry) the longest-living waves: %s" % (
+            trips.mean(), ((end - start) / np.maximum(trips, 1)).mean(),
+            ["%.0f us, %d rays, oldest %d" % (left[i], alive[i], age[i]) for i in np.argsort(-left)[:6]]))
     sc.close()

@@ -461,7 +461,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 #ifdef TRX_TAIL_DIAG
     // (diagnostic builds only, tools/gpu_tail.py: what was every wave's LAST tile, and when did it start?)
     unsigned long long diag_t0 = 0ull, diag_chunk = 0ull, diag_tiles = 0ull;
-    uint32_t diag_pl = 0u, diag_cw = 0u;
+    uint32_t diag_pl = 0u, diag_cw = 0u, diag_dry_alive = 0u, diag_dry_age = 0u;
+    unsigned long long diag_dry_t = 0ull;
 #endif
 #ifdef TRX_STAMPS
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
@@ -658,6 +659,15 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     }
                     if (ticket >= q_count) {
                         exhausted = true;
+#ifdef TRX_TAIL_DIAG
+                        diag_dry_t = wall_clock64();                                 // when the wave found every queue dry ...
+                        diag_dry_alive = (uint32_t)__popcll(__ballot(has_ray));      // ... how many rays it still held ...
+                        {   // ... and the age of the oldest, in trips
+                            uint32_t age = has_ray ? trip - steps : 0u;
+                            for (int off = 32; off > 0; off >>= 1) age = max(age, (uint32_t)__shfl_xor((int)age, off));
+                            diag_dry_age = age;
+                        }
+#endif
                         break;
                     }
                     // a ticket taken a tile ahead hides the atomic's round trip (1-2 us) but binds the wave's NEXT tile
@@ -1331,6 +1341,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             P.wave_times[kWaveTimeStride * wave_global + 2] = diag_t0;     // start of the wave's last tile
             P.wave_times[kWaveTimeStride * wave_global + 3] = diag_chunk;  // its position in the frame's order
             P.wave_times[kWaveTimeStride * wave_global + 4] = diag_tiles;  // tiles the wave traced
+            P.wave_times[kWaveTimeStride * wave_global + 5] = diag_dry_t;
+            P.wave_times[kWaveTimeStride * wave_global + 6] = diag_dry_alive;
+            P.wave_times[kWaveTimeStride * wave_global + 7] = ((unsigned long long)trip << 32) | diag_dry_age; // trips of the wave | oldest ray at that moment
 #endif
 #ifdef TRX_STAMPS
             unsigned long long *wt = P.wave_times + kWaveTimeStride * wave_global;
