@@ -343,7 +343,10 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     const uint32_t variant = g_variant.load(std::memory_order_relaxed);
     // tuning overrides (trx_set_kernel_variant): bits 8..15 waves per CU, bits 16..19 waves per workgroup
     uint32_t wpb = (variant >> 16) & 0x7u; // (bit 19: the tile-order feedback does not tune itself off, see below)
-    if (wpb != 1 && wpb != 2 && wpb != 4) wpb = kDefaultWavesPerBlock;
+    // incoherent single-level passes run two waves to a workgroup, so that the second can hand its last rays to the first
+    // when both are draining (kernels.hip, "drain"); an explicit 1 or 4 here switches that off
+    const bool merge_default = (wpb != 1 && wpb != 2 && wpb != 4) && mode != kModePrimary && !s->tlas && !count;
+    if (wpb != 1 && wpb != 2 && wpb != 4) wpb = merge_default ? 2u : kDefaultWavesPerBlock;
     const uint32_t per_cu = (variant >> 8) & 0xffu;
     int grid = per_cu ? (int)(std::min(per_cu, 32u) * (uint32_t)s->cu_count) : s->grid;
     // no more waves than chunks of work: a batch of one ray (trx_traverse1) is a one-wave launch with a
@@ -422,6 +425,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         p.tri_coop_ratio = r == 0u ? 2u : r == 7u ? 0u : r;
     }
     p.waves_per_block = wpb;
+    p.merge = merge_default ? 1u : 0u;
     // Decode-once node test on wave-uniform node steps (kernels.hip, node_intersect_dec): pays where almost every step is
     // uniform - a scene small enough for the L2s, seen by coherent primary rays (kitchen-class frame -4 %, 90 % of its
     // steps uniform) - is neutral on the bistro-class frame (-1 %, 47 %) and costs 1-2 % on the dense and hairball-class

@@ -121,6 +121,7 @@ struct TraceParams {
     uint32_t tune;                   // development switches (TRX_TUNE environment word), 0 in the product
     uint32_t n_tris, n_nodes;        // buffer extents (prefetch addresses are clamped to them)
     uint32_t waves_per_block;        // 1, 2 or 4
+    uint32_t merge;                  // 2 waves per workgroup, incoherent BLAS pass: the second wave may hand its last rays to the first (kernels.hip, drain)
     unsigned long long *wave_times;  // diagnostics: [8*wave] start, [8*wave+1] end (wall_clock64), [+2..7] phase cycles in TRX_STAMPS builds; or null
     // frames per launch (image modes): frame f = local_tile / tiles_per_frame uses views[f] and writes its
     // records at out + f * frame_stride; one launch then balances n_frames x the tiles

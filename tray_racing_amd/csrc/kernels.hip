@@ -488,6 +488,32 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint4 pn0 = make_uint4(0u, 0u, 0u, 0u), pn1 = pn0, pn2 = pn0, pn3 = pn0, pn4 = pn0;
     uint2 ptri = make_uint2(0u, 0u);
     uint32_t overflow = 0; // sticky, set on the rare paths only (stack past its HBM part, step cap)
+    // The drain (incoherent single-level passes, two waves to a workgroup).  Every wave of such a pass finds the queues dry
+    // holding about 45 rays and then spends a full ray lifetime finishing them at falling occupancy (13 % of a
+    // bistro-class AO pass, 64 % of a hairball-class one: profiles/r03_ao_order.log).  Fewer waves draining is the remedy:
+    // once the two waves of a workgroup are both dry and their rays fit one wave, the second wave parks its rays' state
+    // in its own (now idle) LDS region, offers them with one LDS compare-and-swap and leaves; the first wave picks them
+    // up into its idle lanes - stack entries included, they are in the same workgroup's LDS - and goes on.  A ray is
+    // the same ray whichever wave steps it, so the hits are those of the unmerged pass.  No wave ever waits for the other:
+    // control word 0 goes 0 -> n (rays offered) or 0 -> kMergeClosed (the first wave left first), whichever swap lands.
+    constexpr bool kMerge = !TLAS && MODE != kModePrimary && !COUNT;
+    constexpr uint32_t kMergeMax = 48u, kMergeWords = 21u, kMergeClosed = 0xffffffffu;
+    const bool merging = kMerge && P.merge != 0u && blockDim.x == 2u * kWave;
+    bool merge_open = merging; // wave-uniform: this wave has not offered / taken / refused rays yet
+    uint32_t need_take = 0u;   // wave-uniform: rays the first wave found offered as it was about to leave
+    char *const lds_wave0 = reinterpret_cast<char *>(lds_dyn), *const lds_wave1 = lds_wave0 + kLdsBytesPerWave;
+    // control words (in wave 0's decode table, which only coherent primary passes use): [0] offer, [1] free lanes of wave 0
+    uint32_t *const merge_ctl = reinterpret_cast<uint32_t *>(lds_wave0 + (reinterpret_cast<char *>(lds_dec) - lds_wave));
+    // parking area: wave 1's region from its ray copies up to and including its decode table (4 032 B = 48 x 21 words)
+    uint32_t *const merge_box = reinterpret_cast<uint32_t *>(lds_wave1 + kLdsStack * kWave * 8);
+    const uint2 *const merge_stack1 = reinterpret_cast<const uint2 *>(lds_wave1);
+    if (merging) {
+        if (threadIdx.x == 0u) {
+            merge_ctl[0] = 0u;
+            merge_ctl[1] = 0u;
+        }
+        __syncthreads(); // (the only barrier of the kernel: both waves are at their very start)
+    }
     // COUNT only
     uint32_t c_node = 0, c_tri = 0, c_rays = 0, c_hits = 0, c_maxsp = 0, c_over = 0;
     uint32_t c_wnode = 0, c_wtri = 0; // wave-level executions (leader lane only): SIMD-efficiency denominators
@@ -833,8 +859,22 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         }
         TRX_STAMP(k_refill);
         if (__ballot(has_ray) == 0ull) {
-            if (exhausted) break;
-            continue;
+            if (exhausted) {
+                if (kMerge && merge_open && wave_in_block == 0u) {
+                    // leaving: close the door, or find that the second wave has just offered its rays
+                    uint32_t old = 0u;
+                    if (lane == 0u) old = atomicCAS(&merge_ctl[0], 0u, kMergeClosed);
+                    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+                    merge_open = false;
+                    if (old != 0u) {
+                        merge_open = true;
+                        need_take = old;
+                    }
+                }
+                if (!(kMerge && need_take != 0u)) break;
+            } else {
+                continue;
+            }
         }
 
         // ---- traverse ------------------------------------------------------------
@@ -1019,6 +1059,69 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 
 
 
+        // The second wave of a draining workgroup offers its rays (see "The drain" above); true = taken over, this wave is empty.
+        auto merge_offer = [&](uint32_t alive) -> bool {
+            const uint32_t avail = *reinterpret_cast<volatile uint32_t *>(&merge_ctl[1]);
+            if (avail < alive || __ballot(has_ray && sp > (uint32_t)kLdsStack) != 0ull) return false; // (stacks past the LDS part stay)
+            const uint32_t j = lane_rank(__ballot(has_ray));
+            if (has_ray) {
+                uint32_t *m = merge_box + j * kMergeWords;
+                m[0] = __float_as_uint(r.ox); m[1] = __float_as_uint(r.oy); m[2] = __float_as_uint(r.oz);
+                m[3] = __float_as_uint(r.dx); m[4] = __float_as_uint(r.dy); m[5] = __float_as_uint(r.dz);
+                m[6] = __float_as_uint(r.ix); m[7] = __float_as_uint(r.iy); m[8] = __float_as_uint(r.iz);
+                m[9] = __float_as_uint(r.tmin); m[10] = r.oct_inv4;
+                m[11] = __float_as_uint(t); m[12] = prim; m[13] = out_index; m[14] = trip - steps;
+                m[15] = cur.x; m[16] = cur.y; m[17] = sp; m[18] = ptri.x; m[19] = ptri.y; m[20] = lane;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            uint32_t old = 0u;
+            if (lane == 0u) old = atomicCAS(&merge_ctl[0], 0u, alive);
+            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+            merge_open = false; // one offer per wave
+            if (old != 0u) { // the first wave has left: finish them here (the parking area covered this wave's ray copies)
+                if (has_ray) {
+                    lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+                    lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+                }
+                return false;
+            }
+            has_ray = false;
+            return true;
+        };
+        // The first wave takes what the second offered, if anything (n = control word 0).
+        auto merge_take = [&](uint32_t n) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t j = lane_rank(__ballot(!has_ray));
+            if (!has_ray && j < n) {
+                const uint32_t *m = merge_box + j * kMergeWords;
+                r.ox = __uint_as_float(m[0]); r.oy = __uint_as_float(m[1]); r.oz = __uint_as_float(m[2]);
+                r.dx = __uint_as_float(m[3]); r.dy = __uint_as_float(m[4]); r.dz = __uint_as_float(m[5]);
+                r.ix = __uint_as_float(m[6]); r.iy = __uint_as_float(m[7]); r.iz = __uint_as_float(m[8]);
+                r.tmin = __uint_as_float(m[9]); r.oct_inv4 = m[10];
+                t = __uint_as_float(m[11]); prim = m[12]; out_index = m[13]; steps = trip - m[14];
+                cur = make_uint2(m[15], m[16]); sp = m[17]; ptri = make_uint2(m[18], m[19]);
+                const uint32_t from = m[20];
+                for (uint32_t k = 0; k < sp; k++) lds_stack[k * kWave + lane] = merge_stack1[k * kWave + from];
+                lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+                lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+                fetched = false;
+                overflow = 0u;
+                has_ray = true;
+            }
+            merge_open = false;
+        };
+        // End of a trip of a dry wave: the second wave offers once its rays fit the first one's idle lanes; the first
+        // publishes its idle lanes and looks for an offer.
+        auto merge_step = [&](uint32_t alive) {
+            if (wave_in_block == 1u) {
+                if (alive != 0u && alive <= kMergeMax) (void)merge_offer(alive);
+            } else {
+                if (lane == 0u) *reinterpret_cast<volatile uint32_t *>(&merge_ctl[1]) = (uint32_t)kWave - alive;
+                const uint32_t n = *reinterpret_cast<volatile uint32_t *>(&merge_ctl[0]);
+                if (n != 0u) merge_take(n);
+            }
+        };
+
         // Incoherent passes end when their longest rays do (a third of the hairball-class AO pass's wave time is waves
         // waiting for them, and dealing the tiles longest ray first does not move that tail: profiles/r03_ao_order.log, tools/gpu_timeline_ao.py), so
         // a wave that holds an old ray wins the issue arbitration of its SIMD: priority 2 once its oldest ray has run
@@ -1050,6 +1153,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             has_ray = false;
         };
 
+        if (kMerge && need_take != 0u) {
+            merge_take(need_take);
+            need_take = 0u;
+        }
         if constexpr (!PIPE) {
             for (;;) {
                 const bool act = has_ray;
@@ -1240,6 +1347,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 }
                 const uint32_t alive = (uint32_t)__popcll(__ballot(has_ray));
                 TRX_STAMP(k_pop);
+                if (kMerge && merge_open && exhausted) {
+                    merge_step(alive);
+                    if (__ballot(has_ray) == 0ull) break;
+                    continue;
+                }
                 if (alive == 0u || (!exhausted && alive <= keep)) break;
             }
 
@@ -1316,6 +1428,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     }
                 }
                 TRX_STAMP(k_test);
+                if (kMerge && merge_open && exhausted) {
+                    merge_step(alive);
+                    if (__ballot(has_ray) == 0ull) break;
+                    continue;
+                }
                 if (leave) break;
             }
         }
