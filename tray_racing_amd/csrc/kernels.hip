@@ -441,7 +441,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     static_assert(!(PIPE && TLAS), "the pipelined walk is BLAS-only");
     // triangles of a lane requested together in a per-lane triangle round (the two-level walk has fewer registers to spare)
     constexpr int kBatch = TLAS ? kTriBatchTlas : (PIPE ? kTriBatchPipe : kTriBatch);
-    // one stack region per wave of the workgroup; waves never synchronise with each other
+    // one LDS region per wave of the workgroup; waves do not synchronise with each other (incoherent single-level passes:
+    // one barrier at the very start and a wait-free hand-over of rays between the two waves of a workgroup, see "The drain")
     extern __shared__ float4 lds_dyn[];
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave_in_block = threadIdx.x / kWave;
