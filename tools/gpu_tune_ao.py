@@ -34,7 +34,7 @@ def timed(fn, reps=8, warm=3):
 
 for name in names:
     verts, counts = T.gen_scene(name, 0, 1)
-    flat = T.flat_build(verts, counts)
+    flat = T.flat_build(verts, counts, use_tlas=bool(int(os.environ.get("TLAS", "0"))))  # TLAS=1: the two-level kernels
     eye, look, fov = T.scene_camera(name)
     view = T.view_from_camera(eye, look, fov, w, h)
     sc = T.Scene(flat)

@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     static_assert(!(PIPE && TLAS), "the pipelined walk is BLAS-only");
     // triangles of a lane requested together in a per-lane triangle round (the two-level walk has fewer registers to spare)
     constexpr int kBatch = TLAS ? kTriBatchTlas : (PIPE ? kTriBatchPipe : kTriBatch);
-    // one LDS region per wave of the workgroup; waves do not synchronise with each other (incoherent single-level passes:
+    // one LDS region per wave of the workgroup; waves do not synchronise with each other (incoherent passes:
     // one barrier at the very start and a wait-free hand-over of rays between the two waves of a workgroup, see "The drain")
     extern __shared__ float4 lds_dyn[];
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint4 pn0 = make_uint4(0u, 0u, 0u, 0u), pn1 = pn0, pn2 = pn0, pn3 = pn0, pn4 = pn0;
     uint2 ptri = make_uint2(0u, 0u);
     uint32_t overflow = 0; // sticky, set on the rare paths only (stack past its HBM part, step cap)
-    // The drain (incoherent single-level passes, two waves to a workgroup).  Every wave of such a pass finds the queues dry
+    // The drain (incoherent passes - AO, explicit rays - run two waves to a workgroup).  Every wave of such a pass finds the queues dry
     // holding about 45 rays and then spends a full ray lifetime finishing them at falling occupancy (13 % of a
     // bistro-class AO pass, 64 % of a hairball-class one: profiles/r03_ao_order.log).  Fewer waves draining is the remedy:
     // once the two waves of a workgroup are both dry and their rays fit one wave, the second wave parks its rays' state
@@ -497,8 +497,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // up into its idle lanes - stack entries included, they are in the same workgroup's LDS - and goes on.  A ray is
     // the same ray whichever wave steps it, so the hits are those of the unmerged pass.  No wave ever waits for the other:
     // control word 0 goes 0 -> n (rays offered) or 0 -> kMergeClosed (the first wave left first), whichever swap lands.
-    constexpr bool kMerge = !TLAS && MODE != kModePrimary && !COUNT;
-    constexpr uint32_t kMergeMax = 48u, kMergeWords = 21u, kMergeClosed = 0xffffffffu;
+    constexpr bool kMerge = MODE != kModePrimary && !COUNT;
+    // (the two-level walk carries ten words more per ray - the instance being walked and the world-space ray - so fewer fit the parking area)
+    constexpr uint32_t kMergeWords = TLAS ? 31u : 21u, kMergeMax = TLAS ? 32u : 48u, kMergeClosed = 0xffffffffu;
     const bool merging = kMerge && P.merge != 0u && blockDim.x == 2u * kWave;
     bool merge_open = merging; // wave-uniform: this wave has not offered / taken / refused rays yet
     uint32_t need_take = 0u;   // wave-uniform: rays the first wave found offered as it was about to leave
@@ -1073,6 +1074,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 m[9] = __float_as_uint(r.tmin); m[10] = r.oct_inv4;
                 m[11] = __float_as_uint(t); m[12] = prim; m[13] = out_index; m[14] = trip - steps;
                 m[15] = cur.x; m[16] = cur.y; m[17] = sp; m[18] = ptri.x; m[19] = ptri.y; m[20] = lane;
+                if (TLAS) {
+                    m[21] = bvh_off; m[22] = tlas_sp; m[23] = cur_inst; m[24] = hit_inst;
+                    m[25] = __float_as_uint(wox); m[26] = __float_as_uint(woy); m[27] = __float_as_uint(woz);
+                    m[28] = __float_as_uint(wdx); m[29] = __float_as_uint(wdy); m[30] = __float_as_uint(wdz);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             uint32_t old = 0u;
@@ -1101,6 +1107,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 r.tmin = __uint_as_float(m[9]); r.oct_inv4 = m[10];
                 t = __uint_as_float(m[11]); prim = m[12]; out_index = m[13]; steps = trip - m[14];
                 cur = make_uint2(m[15], m[16]); sp = m[17]; ptri = make_uint2(m[18], m[19]);
+                if (TLAS) {
+                    bvh_off = m[21]; tlas_sp = m[22]; cur_inst = m[23]; hit_inst = m[24];
+                    wox = __uint_as_float(m[25]); woy = __uint_as_float(m[26]); woz = __uint_as_float(m[27]);
+                    wdx = __uint_as_float(m[28]); wdy = __uint_as_float(m[29]); wdz = __uint_as_float(m[30]);
+                }
                 const uint32_t from = m[20];
                 for (uint32_t k = 0; k < sp; k++) lds_stack[k * kWave + lane] = merge_stack1[k * kWave + from];
                 lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
