@@ -1178,7 +1178,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 #ifdef TRX_DEV_TUNE
                 if (!(P.tune & 0x10000000u)) // (A/B: no priority by ray age)
 #endif
-                if (!TLAS && MODE != kModePrimary && (trip & 7u) == 0u) old_ray_priority(); // (the two-level AO kernel has no register to spare for it)
+                if (!TLAS && MODE != kModePrimary && (trip & 7u) == 0u) old_ray_priority(); // (measured without effect in the two-level kernels)
                 // Coherent primary rays (BLAS only): when every lane that steps visits the SAME node - 47 % of the wave-level
                 // node steps on the bistro-class frame, 90 % on the kitchen-class one - its 48 quantised plane bytes are
                 // converted once, one byte per lane, parked in LDS as floats and read back by address (node_intersect_dec)
@@ -1380,7 +1380,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 #ifdef TRX_DEV_TUNE
                 if (!(P.tune & 0x10000000u)) // (A/B: no priority by ray age)
 #endif
-                if (!TLAS && MODE != kModePrimary && (trip & 7u) == 0u) old_ray_priority(); // (the two-level AO kernel has no register to spare for it)
+                if (!TLAS && MODE != kModePrimary && (trip & 7u) == 0u) old_ray_priority(); // (measured without effect in the two-level kernels)
                 // (1)
                 if (act && !fetched && (cur.y & 0xff000000u)) {
                     const uint32_t hits_imask = cur.y;
