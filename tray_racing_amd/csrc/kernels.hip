@@ -419,15 +419,32 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// Appends the parked {tile, list} entries to the next frame's tile lists, one lane per entry.
+// Appends the parked {tile, list} entries to the next frame's tile lists.  A wave files all its tiles of a class under one
+// shard, so its entries fall into a few groups (one per class it met); the first lane of a group claims the group's
+// slots with ONE returning atomic, the groups' atomics go out together, and every lane stores its tile at its rank
+// within the group.  (One atomic per ENTRY - round 1 and 2 - was 32 400 a frame on 128 counters, most of them as the
+// waves leave; in a natural-order frame neighbouring tiles share a class and a few counters took them all: 0.08 ms of a
+// bistro-class first frame, 0.11 ms of a kitchen-class one, profiles/r03_filing_cost.log.)
 __device__ __forceinline__ void flush_pending(const TraceParams &P, const uint2 *lds_pend, uint32_t n, uint32_t lane) {
     __builtin_amdgcn_wave_barrier();
-    if (lane < n) {
-        const uint2 e = lds_pend[lane];
-        if (e.y < 16u * kLptShards) { // (a list index can only be out of range if LDS was corrupted: never turn that into a stray global atomic)
-            const uint32_t pos = atomicAdd(&P.lpt_write_counts[e.y], 1u);
-            if (pos < P.lpt_cap) P.lpt_write_lists[(size_t)e.y * P.lpt_cap + pos] = e.x;
-        }
+    uint2 e = make_uint2(0u, 0xffffffffu);
+    if (lane < n) e = lds_pend[lane];
+    const bool valid = e.y < 16u * kLptShards; // (a list index can only be out of range if LDS was corrupted: never turn that into a stray global atomic)
+    // the lanes that share this lane's list: one ballot per class (the shard is the wave's, so the class names the list)
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (uint32_t c = 0; c < 16u; c++) {
+        const unsigned long long m = __ballot(valid && (e.y / kLptShards) == c);
+        if (valid && (e.y / kLptShards) == c) mine = m;
+    }
+    const uint32_t leader = (uint32_t)__ffsll((long long)mine) - 1u; // (mine != 0 for a valid lane: it contains the lane itself)
+    const uint32_t rank = (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+    uint32_t base = 0u;
+    if (valid && lane == leader) base = atomicAdd(&P.lpt_write_counts[e.y], (uint32_t)__popcll(mine));
+    base = (uint32_t)__shfl((int)base, (int)(valid ? leader : lane));
+    if (valid) {
+        const uint32_t pos = base + rank;
+        if (pos < P.lpt_cap) P.lpt_write_lists[(size_t)e.y * P.lpt_cap + pos] = e.x;
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -645,7 +662,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         const uint32_t kk = 2u * msb + (msb ? (wk >> (msb - 1u)) & 1u : 0u);
                         b = kk == 0u ? 0u : min(kk - 1u, 15u);
                     }
-                    const uint32_t list = b * kLptShards + ((wave_global ^ tile_slot) & (kLptShards - 1u));
+                    const uint32_t list = b * kLptShards + (wave_global & (kLptShards - 1u)); // (one shard per wave: see flush_pending)
                     // park the entry in LDS: the appends (returning atomics) are issued together,
                     // one lane each, when the buffer fills or the wave exits, off every tile's path
                     lds_pend[n_pend] = make_uint2(tile_slot, list);
