@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // as the current one is taken, so the atomic's round trip overlaps the traversal.
     //
     // Tile order feedback: a wave that finishes a tile files it in one of 16 cost buckets
-    // (sqrt(2)-wide classes of the tile's wall-clock time) of the NEXT frame's lists; this frame
+    // (sqrt(2)-wide classes of the tile's traversal-loop trips; its wall-clock time until round 3) of the NEXT frame's lists; this frame
     // reads the lists the previous frame wrote, heaviest bucket first, so chunk p is the p-th
     // heaviest tile (longest-processing-time-first) and every queue starts with heavy tiles.
     const uint32_t n_chunks = (P.n_items + 63u) >> 6;
@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     unsigned long long tile_t0 = 0;
     uint32_t tile_trip0 = 0;
     uint32_t cur_tile = 0, my_tile = 0;      // tile of the current chunk (uniform) / of this lane's item
-    // Lists are kept per (cost bucket, shard): kLptShards appenders per bucket, because one atomic
+    // Lists are kept per (cost bucket, shard): kLptShards appenders per bucket (a wave always appends to its own shard), because one atomic
     // word saturates near 90 appends/us.  Entry e = (15 - bucket) * kLptShards + shard is the e-th
     // list of the heaviest-first concatenation; lane l holds the (exclusive) ends of entries l, l+64.
     uint32_t end_a = 0, end_b = 0;
