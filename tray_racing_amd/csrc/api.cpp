@@ -343,9 +343,9 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     const uint32_t variant = g_variant.load(std::memory_order_relaxed);
     // tuning overrides (trx_set_kernel_variant): bits 8..15 waves per CU, bits 16..19 waves per workgroup
     uint32_t wpb = (variant >> 16) & 0x7u; // (bit 19: the tile-order feedback does not tune itself off, see below)
-    // incoherent passes (AO, explicit rays) run two waves to a workgroup, so that the second can hand its last rays to the first
+    // incoherent single-level passes (AO, explicit rays) run two waves to a workgroup, so that the second can hand its last rays to the first
     // when both are draining (kernels.hip, "drain"); an explicit 1 or 4 here switches that off
-    const bool merge_default = (wpb != 1 && wpb != 2 && wpb != 4) && mode != kModePrimary && !count;
+    const bool merge_default = (wpb != 1 && wpb != 2 && wpb != 4) && mode != kModePrimary && !s->tlas && !count;
     if (wpb != 1 && wpb != 2 && wpb != 4) wpb = merge_default ? 2u : kDefaultWavesPerBlock;
     const uint32_t per_cu = (variant >> 8) & 0xffu;
     int grid = per_cu ? (int)(std::min(per_cu, 32u) * (uint32_t)s->cu_count) : s->grid;

@@ -432,10 +432,11 @@ __device__ __forceinline__ void flush_pending(const TraceParams &P, const uint2 
     const bool valid = e.y < 16u * kLptShards; // (a list index can only be out of range if LDS was corrupted: never turn that into a stray global atomic)
     // the lanes that share this lane's list: one ballot per class (the shard is the wave's, so the class names the list)
     unsigned long long mine = 0ull;
-#pragma unroll
-    for (uint32_t c = 0; c < 16u; c++) {
-        const unsigned long long m = __ballot(valid && (e.y / kLptShards) == c);
-        if (valid && (e.y / kLptShards) == c) mine = m;
+    const uint32_t cls = valid ? e.y / kLptShards : 0xffffffffu;
+#pragma nounroll
+    for (uint32_t c = 0; c < 16u; c++) { // (a loop, not sixteen copies: this runs once or twice per wave and must not cost the walk a register)
+        const unsigned long long m = __ballot(cls == c);
+        if (cls == c) mine = m;
     }
     const uint32_t leader = (uint32_t)__ffsll((long long)mine) - 1u; // (mine != 0 for a valid lane: it contains the lane itself)
     const uint32_t rank = (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
@@ -445,6 +446,20 @@ __device__ __forceinline__ void flush_pending(const TraceParams &P, const uint2 
     if (valid) {
         const uint32_t pos = base + rank;
         if (pos < P.lpt_cap) P.lpt_write_lists[(size_t)e.y * P.lpt_cap + pos] = e.x;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The same without the grouping, one atomic per entry: for the flush in the middle of a frame (a wave that has parked
+// kLptPend tiles - 4K frames), where the walk's registers are live and the grouped version would cost it a spill.
+__device__ __forceinline__ void flush_pending_plain(const TraceParams &P, const uint2 *lds_pend, uint32_t n, uint32_t lane) {
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n) {
+        const uint2 e = lds_pend[lane];
+        if (e.y < 16u * kLptShards) {
+            const uint32_t pos = atomicAdd(&P.lpt_write_counts[e.y], 1u);
+            if (pos < P.lpt_cap) P.lpt_write_lists[(size_t)e.y * P.lpt_cap + pos] = e.x;
+        }
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -506,7 +521,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint4 pn0 = make_uint4(0u, 0u, 0u, 0u), pn1 = pn0, pn2 = pn0, pn3 = pn0, pn4 = pn0;
     uint2 ptri = make_uint2(0u, 0u);
     uint32_t overflow = 0; // sticky, set on the rare paths only (stack past its HBM part, step cap)
-    // The drain (incoherent passes - AO, explicit rays - run two waves to a workgroup).  Every wave of such a pass finds the queues dry
+    // The drain (incoherent single-level passes - AO, explicit rays - run two waves to a workgroup).  Every wave of such a pass finds the queues dry
     // holding about 45 rays and then spends a full ray lifetime finishing them at falling occupancy (13 % of a
     // bistro-class AO pass, 64 % of a hairball-class one: profiles/r03_ao_order.log).  Fewer waves draining is the remedy:
     // once the two waves of a workgroup are both dry and their rays fit one wave, the second wave parks its rays' state
@@ -514,8 +529,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // up into its idle lanes - stack entries included, they are in the same workgroup's LDS - and goes on.  A ray is
     // the same ray whichever wave steps it, so the hits are those of the unmerged pass.  No wave ever waits for the other:
     // control word 0 goes 0 -> n (rays offered) or 0 -> kMergeClosed (the first wave left first), whichever swap lands.
-    constexpr bool kMerge = MODE != kModePrimary && !COUNT;
-    // (the two-level walk carries ten words more per ray - the instance being walked and the world-space ray - so fewer fit the parking area)
+    // (Single-level walks only.  The two-level kernels were given the hand-over too - ten words more per ray, 32 rays at most: with it on
+    // they run 2.5-4 % faster than with it off, but the kernel that contains the code is 3 % slower on the 4K two-level AO pass than the
+    // kernel that does not, profiles/r03_drain_merge.log - the code for it stays below, compiled out.)
+    constexpr bool kMerge = !TLAS && MODE != kModePrimary && !COUNT;
     constexpr uint32_t kMergeWords = TLAS ? 31u : 21u, kMergeMax = TLAS ? 32u : 48u, kMergeClosed = 0xffffffffu;
     const bool merging = kMerge && P.merge != 0u && blockDim.x == 2u * kWave;
     bool merge_open = merging; // wave-uniform: this wave has not offered / taken / refused rays yet
@@ -671,7 +688,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             if (lpt_write) {
                 n_pend++;
                 if (n_pend == (uint32_t)kLptPend) {
-                    flush_pending(P, lds_pend, n_pend, lane);
+                    flush_pending_plain(P, lds_pend, n_pend, lane);
                     n_pend = 0;
                 }
             }
