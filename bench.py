@@ -407,12 +407,31 @@ def main():
         # (c) the literal HLSL arithmetic (per-node IEEE divides, tt <= t)
         hmin, hmean = scene.bench_primary(view, w, h, sem=0, warmup=3, frames=20)
         legs["sem_hlsl_ms"] = {"min": round(hmin, 4), "mean": round(hmean, 4)}
-        # (c') every frame a camera cut: the probe pass (one centre ray per tile) + a frame in the order it predicts -
-        #      what the first frame of a view costs since round 3; hipEvents bracket both kernels
+        # (c') every frame runs as the first frame of its image geometry (natural order while its tiles are measured; the
+        #      probe pass that once predicted an order here was measured and removed)
         lib.trx_set_kernel_variant(VARIANT_CUT)
         fmin, fmean = scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20)
         lib.trx_set_kernel_variant(0)
         legs["first_frame_ms"] = {"min": round(fmin, 4), "mean": round(fmean, 4)}
+        # (c") the AO pass over this frame's primary hits (the reference's second ray per pixel, rt_gpu_software.hlsl:105-128):
+        #      one cosine-weighted ray per primary hit, a new noise seed every pass; default stream, hipEvents per launch
+        d_prim = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
+        d_ao = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
+        scene.trace_primary_dev(view, w, h, d_prim.data_ptr(), sem=args.sem)
+        torch.cuda.synchronize()
+        n_ao = int(((d_prim & 0xffffffff) != 0x7f800000).sum().item())   # low word = t bits; +inf = miss
+        ao_ev = []
+        for k in range(3 + 12):
+            a, b = ev(), ev()
+            a.record()
+            scene.trace_ao_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=k, ao_eps=0.01)
+            b.record()
+            ao_ev.append((a, b))
+        torch.cuda.synchronize()
+        at = [a.elapsed_time(b) for a, b in ao_ev][3:]
+        legs["ao_pass_ms"] = {"rays": n_ao, "frames": len(at), "min": round(min(at), 4), "mean": round(sum(at) / len(at), 4),
+                              "mrays_at_mean": round(n_ao / (sum(at) / len(at)) / 1e3, 1)}
+        del d_prim, d_ao
         # (d) frames overlapped on 4 streams (independent frames; the tail of one overlaps the next)
         ps = [torch.cuda.Stream() for _ in range(4)]
         pbuf = [torch.empty(n_rays_total, dtype=torch.int64, device="cuda") for _ in ps]

@@ -83,6 +83,8 @@ def test_cpu_baseline_and_legs(line):
     assert legs["first_frame_ms"]["mean"] > line["kernel_ms_mean"]        # a camera cut: natural order + measuring
     assert legs["moving_camera_ms"]["mean"] < legs["first_frame_ms"]["mean"]
     assert legs["ploc_pipeline"]["nodes_per_ray"] > 0 and legs["dense_scene"]["nodes_per_ray"] > 25
+    # the AO pass over the bench frame's primary hits: one ray per hit, timed per launch
+    assert 0 < legs["ao_pass_ms"]["rays"] <= 1920 * 1080 and legs["ao_pass_ms"]["mean"] >= legs["ao_pass_ms"]["min"] > 0
 
 
 def test_default_arguments_finish_in_minutes():
