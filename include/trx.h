@@ -241,6 +241,14 @@ int trx_view_from_camera(const float eye[3], const float look_at[3], float fov_d
  * `stream` is a hipStream_t (NULL = the null stream).  d_* pointers are device
  * memory on the scene's device.  These calls only enqueue work.
  *
+ * Scheduling state (never results) lives with the stream: a stream keeps a launch slot of
+ * the scene, and an image pass remembers, per image geometry, in which order its 8x8 tiles
+ * are best started (heaviest first, learnt from the previous pass of that geometry on that
+ * stream).  A frame loop that keeps its passes on one stream - as the reference does on its
+ * one queue - gets that for free from the second frame on, camera motion and cuts included;
+ * the first pass of a geometry, and a caller that sprays frames over many streams, run in
+ * natural order (bench.py: 0.52 ms against 0.42 ms).  Hits are identical either way.
+ *
  * trx_trace_primary_dev replaces the timed dispatch of the reference
  * (src/rt_gpu/rt_gpu_software.rs:289-302) restricted to the primary ray of
  * src/rt_gpu/rt_gpu_software.hlsl:69-89: ray-gen in-kernel, closest hit,
