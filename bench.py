@@ -14,7 +14,8 @@ frame of a geometry (tile order not yet learnt: `cold_order_ms`), the literal-HL
 (`sem_hlsl_ms`), frames overlapped on 4 streams (`pipelined_mrays`), a measured HBM copy ceiling, live
 rocprofv3 counter passes of the same workload (child processes) and the CPU port on the host cores.
 
-N > 1 (one process per GPU under torch.distributed.run): the frame's 8x8 tiles are dealt round-robin to the
+N > 1 (one process per GPU; under `python -m torch.distributed.run` as the driver launches it, or plain
+`python bench.py --gpus N`, which starts those ranks itself before it touches the GPU): the frame's 8x8 tiles are dealt round-robin to the
 ranks (tile % N == rank), each rank traces its tiles straight into its block of a gather buffer and ONE
 in-place all-gather (RCCL) per batch of `--gather-batch` frames brings the hit records to every rank, which
 de-interleaves them into row-major frames — all inside the timed region.  Total work is fixed as N grows:
@@ -54,7 +55,7 @@ VALU_CYCLES = 2.0      # a wave64 VALU instruction issues over 2 cycles on a SIM
 # SDWA, and scalar ALU alike) issue at one per 2.63 cycles per SIMD; only v_fma/mul/add_f32, v_and, v_add_u32 reach 1.62
 ISSUE_CYCLES_MEASURED = 2.63
 VARIANT_COLD = 1 << 20  # trx_set_kernel_variant: tile-order feedback off
-VARIANT_CUT = 1 << 7    # ... every frame treated as a camera cut: probe pass + probe-ordered frame (a first frame)
+VARIANT_CUT = 1 << 7    # ... every frame runs as the first frame of its geometry: natural order while the tiles are measured
 # static VALU instruction counts of the two tests in the shipped primary kernel (llvm-objdump of k_trace<0,false,1,...>:
 # the node-test block is 213 vector instructions, one per-lane triangle round - bit select, address, test, commit - 70);
 # roofline.useful_frac prices the COUNTED lane-level tests at these, i.e. what a divergence-free walk would issue
@@ -198,8 +199,34 @@ def pmc_passes(scene_npz, frames=10, timeout_s=150):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def entry_nodes(flat):
+    """The entry-node table of a re-braided TLAS (None for every BLAS-only scene) travels with the flat buffers: a scene
+    restored without it would enter every BLAS at its root (same hits, many more node visits)."""
+    ent = getattr(flat, "instance_entry", None)
+    return {} if ent is None else {"instance_entry": ent}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has not touched the
+    GPU (nothing below `import` level does; libtrx.so is not even loaded yet), so the ranks are FRESH children of
+    `python -m torch.distributed.run` - never an exec of a process that initialised HIP - one per GPU, rendezvous on
+    127.0.0.1.  Their stdout / stderr are ours (rank 0 prints the JSON line); the launcher's return code is ours."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -211,9 +238,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     lib = T.load()
     lib.trx_set_kernel_variant(int(args.kernel_variant, 0))
@@ -526,7 +550,7 @@ def main():
             npz = os.path.join(tempfile.gettempdir(), "trx_bench_scene_%d.npz" % os.getpid())
             np.savez(npz, nodes=flat.nodes, tri_verts=flat.tri_verts, instance_offsets=flat.instance_offsets,
                      tlas_start=np.uint32(flat.tlas_start), view=np.frombuffer(bytes(view), dtype=np.uint8),
-                     width=np.uint32(w), height=np.uint32(h), sem=np.uint32(args.sem))
+                     width=np.uint32(w), height=np.uint32(h), sem=np.uint32(args.sem), **entry_nodes(flat))
             try:
                 pmc, pmc_ms = pmc_passes(npz)
                 pmc_src = "live: rocprofv3 --pmc child passes of this workload" if pmc else "live passes failed (%s)" % pmc_ms
@@ -673,8 +697,8 @@ def main():
                 "frames_per_gather": F,
                 "build_seconds": round(build_s, 2),
                 "tile_order": "learnt from the previous frame on the same stream (static camera, as the reference "
-                              "benches); a first frame (probe pass + probe-ordered frame) in legs.first_frame_ms, feedback off "
-                              "in legs.cold_order_ms",
+                              "benches); a first frame (natural order while the tiles are measured, no learnt order) in "
+                              "legs.first_frame_ms, feedback off in legs.cold_order_ms",
             },
             "kernel_ms_mean": round(kernel_ms, 4),
             "kernel_ms_min": round(min(launch_ms), 4),
@@ -702,7 +726,8 @@ def main():
         np.save(args.dump_frame, frame.detach().cpu().numpy())
         np.savez(args.dump_frame + ".scene.npz", nodes=flat.nodes, tri_verts=flat.tri_verts,
                  instance_offsets=flat.instance_offsets, tlas_start=np.uint32(flat.tlas_start),
-                 view=np.frombuffer(bytes(view), dtype=np.uint8), width=np.uint32(w), height=np.uint32(h))
+                 view=np.frombuffer(bytes(view), dtype=np.uint8), width=np.uint32(w), height=np.uint32(h),
+                 **entry_nodes(flat))
     # CPU baseline: the oracle (a port, not the reference binary) on the host cores, rank 0 at N=1 only; it is
     # the only place this file touches oracle/ (as the thing timed beside the GPU, and as the frame's checker)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.sim_shards == 1:

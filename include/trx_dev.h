@@ -1,0 +1,56 @@
+/* trx_dev.h - development surface of libtrx.so: diagnostics and tuning switches used by tools/, bench.py's legs and
+ * the tests.  NOT part of the drop-in boundary: nothing here replaces an interface of tray_racing, INTEGRATION.md binds
+ * none of it, and a host that only includes trx.h never sees it.  Results of every trace entry point are identical
+ * whatever is set here (tests/test_gpu_parity.py::test_scheduling_variants_and_streams_do_not_change_results). */
+#ifndef TRX_DEV_H
+#define TRX_DEV_H
+
+#include "trx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Diagnostics: start / end wall-clock stamps (100 MHz ticks) of every persistent wave of one
+ * primary frame: out_times[2*i], out_times[2*i+1].  Shows residency and the frame's tail. */
+int trx_debug_wave_timeline(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                            uint32_t semantics, uint64_t *out_times, uint32_t max_waves,
+                            uint32_t *out_waves);
+
+/* Diagnostics: 8 words per wave: start, end (as above), then — only in libraries built with -DTRX_STAMPS,
+ * zero otherwise — shader cycles spent in {refill, node fetch, node test, triangle phase, pop / bookkeeping}
+ * and the number of loop trips. */
+int trx_debug_wave_phases(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                          uint32_t semantics, uint64_t *out_records, uint32_t max_waves,
+                          uint32_t *out_waves);
+/* The same 8-word records for the AO pass of the frame (frame 0, eps 0.01; its primary pass runs first, unrecorded). */
+int trx_debug_wave_timeline_ao(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                               uint32_t semantics, uint64_t *out_records, uint32_t max_waves,
+                               uint32_t *out_waves);
+
+/* Diagnostics (counting kernel): the compulsory footprint of one primary frame — how many distinct nodes were
+ * fetched and distinct triangles tested (80 * nodes + 48 * tris + 8 * rays bytes). */
+int trx_debug_footprint(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                        uint32_t semantics, uint64_t *out_nodes_touched, uint64_t *out_tris_touched);
+
+/* Diagnostics (counting kernel): over the triangle phases of one primary frame, out_hist[0..15] = histogram of the
+ * largest per-lane triangle count of the wave (15 = 15 or more), out_hist[16..31] = histogram of the wave's
+ * (ray, triangle) pair total in units of 8, rounded up. */
+int trx_debug_tri_histogram(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                            uint32_t semantics, uint32_t out_hist[32]);
+
+/* Diagnostics: per 8x8 tile (row-major tile id) the wall-clock cost of the tile in a normal frame
+ * (100 MHz ticks) and its wave-level iteration counts from a counting frame:
+ * (node steps << 16) | triangle rounds.  n_tiles = ceil(w/8) * ceil(h/8). */
+int trx_debug_tile_profile(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
+                           uint32_t semantics, uint32_t *out_cost, uint32_t *out_iters, uint32_t n_tiles);
+
+/* Kernel variant selection (tuning aid; 0 = default).  Returns the previous
+ * value.  Variants compute identical results. */
+uint32_t trx_set_kernel_variant(uint32_t variant);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* TRX_DEV_H */

@@ -11,15 +11,28 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "trx.h")).read()
+def declared_symbols(header="trx.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(trx_[a-z0-9_]+)\s*\(", text)))
 
 
+def test_the_boundary_header_carries_no_development_surface():
+    """include/trx.h is what INTEGRATION.md binds; diagnostics and the tuning word live in include/trx_dev.h."""
+    product, dev = declared_symbols(), declared_symbols("trx_dev.h")
+    assert not [n for n in product if n.startswith("trx_debug_") or n == "trx_set_kernel_variant"]
+    assert dev and all(n.startswith("trx_debug_") or n == "trx_set_kernel_variant" for n in dev)
+    assert not set(product) & set(dev)
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert not [n for n in dev if n in integration]
+    # and it is plain C as well
+    subprocess.run(["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", "-I",
+                    os.path.join(ROOT, "include"), "-"], input=b'#include "trx_dev.h"\nint main(void) { return 0; }\n', check=True)
+
+
 def test_every_declared_symbol_is_exported_and_bound(trx):
     from tray_racing_amd import _lib
-    declared = declared_symbols()
+    declared = sorted(set(declared_symbols()) | set(declared_symbols("trx_dev.h")))
     assert len(declared) >= 35
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (trx_[a-z0-9_]+)", out))

@@ -720,6 +720,36 @@ def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path, world, streams, batch
     assert_hits_equal(D.int64_to_hits(torch.from_numpy(np.load(dump))), want, "%d-rank bench frame" % world)
 
 
+def test_bench_launches_its_own_ranks(trx, orc, tmp_path):
+    """`python bench.py --gpus 2 ...` with NO launcher around it (the way the driver runs the scaling bench): the parent
+    starts the ranks itself as fresh children of torch.distributed.run before it has touched the GPU, relays rank 0's
+    JSON line and the launcher's return code; the frame is the oracle's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "frame.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--tris", "150000",
+           "--width", "256", "--height", "136", "--dist-backend", "gloo", "--dump-frame", dump]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # one JSON line, rank 0's
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["phases_ms_per_frame"]["collective_world_size"] == 2
+    g = np.load(dump + ".scene.npz")
+    osc = orc.Scene(g["nodes"], g["tri_verts"], g["instance_offsets"], int(g["tlas_start"]))
+    want, _ = osc.trace_primary(orc.view_from_bytes(g["view"].tobytes()), int(g["width"]), int(g["height"]), sem=3)
+    from tray_racing_amd import dist as D
+    import torch
+    assert_hits_equal(D.int64_to_hits(torch.from_numpy(np.load(dump))), want, "self-launched 2-rank bench frame")
+    # a rank that fails makes the parent fail: the launcher's return code is relayed
+    bad = subprocess.run(cmd[:-2] + ["--scene", "no_such_scene"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert bad.returncode != 0
+
+
 def test_scheduling_variants_and_streams_do_not_change_results(trx, orc):
     """Work-queue layout, tile-order feedback, issue priorities, the cooperative triangle phase and
     frames in flight on several streams only change WHEN work is done: every combination must

@@ -13,7 +13,7 @@ from tray_racing_amd import _lib as L  # noqa: E402
 z = np.load(sys.argv[1])
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 flat = T.FlatScene(z["nodes"], z["tri_verts"], z["instance_offsets"], int(z["tlas_start"]), np.zeros(0, np.uint32),
-                   np.zeros(1, np.uint32))
+                   np.zeros(1, np.uint32), instance_entry=z["instance_entry"] if "instance_entry" in z.files else None)
 view = L.View.from_buffer_copy(z["view"].tobytes())
 w, h, sem = int(z["width"]), int(z["height"]), int(z["sem"])
 sc = T.Scene(flat)

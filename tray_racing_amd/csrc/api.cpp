@@ -1,4 +1,5 @@
-// api.cpp — implementation of the C-ABI declared in include/trx.h.
+// api.cpp — implementation of the C-ABI declared in include/trx.h (and of the development entry points of
+// include/trx_dev.h).
 //
 // Host side of the HIP backend: scene upload (replaces the buffer creation of
 // src/rt_gpu/rt_gpu_software.rs:83-160), launch + hipEvent timing (replaces
@@ -24,6 +25,7 @@
 #include <vector>
 
 #include "../../include/trx.h"
+#include "../../include/trx_dev.h"
 #include "builder.h"
 #include "cwbvh_format.h"
 #include "kernels.h"
@@ -112,7 +114,7 @@ struct Slot {
         uint32_t capacity = 0;
         uint32_t parity = 0; // set written by the next frame
         uint64_t key = 0;    // (width, height, shard, mode) the lists were measured for; 0 = none
-        ViewDev view{};      // view of the last frame that read or wrote the lists (camera-cut detection)
+        ViewDev view[kMaxBatchFrames]{}; // views of the last launch that read or wrote the lists (camera-cut detection)
     } order[2];
 };
 
@@ -439,6 +441,9 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.single_queue = (variant >> 21) & 1u;
     // tile order feedback (image modes, whole-tile refills only)
     const bool lpt = mode != kModeRays && p.refill_idle == 64u && !((variant >> 20) & 1u);
+    // the drain's parking area covers the second wave's parked tile-list entries (lds_pend): a pass that files tiles
+    // (whole-tile refills with the order feedback on - reachable for AO through trx_set_kernel_variant) does not merge
+    if (lpt) p.merge = 0u;
     const uint32_t n_tiles = (p.n_items + 63u) >> 6;
     uint64_t key = 0;
     if (lpt) {
@@ -477,14 +482,16 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         // Variant bit 7: every frame runs as the first frame of its geometry (bench.py's first-frame leg).
         const bool no_order = ord.key != key || ((variant >> 7) & 1u);
         bool cut = no_order;
-        if (!cut) {
-            const ViewDev &a = ord.view, &b = p.views[0];
+        // (a batched launch is a cut when any of its frames is; the key holds n_frames, so the stored views match in number.
+        // The tuner's timings are per LAUNCH SHAPE: a key change - another n_frames included - resets them.)
+        for (uint32_t f = 0; f < std::max(p.n_frames, 1u) && !cut; f++) {
+            const ViewDev &a = ord.view[f], &b = p.views[f];
             const float ex = a.eye[0] - b.eye[0], ey = a.eye[1] - b.eye[1], ez = a.eye[2] - b.eye[2];
             const float moved2 = ex * ex + ey * ey + ez * ez, lim = 0.01f * s->scene_diag;
             const float turn = a.view_inv[8] * b.view_inv[8] + a.view_inv[9] * b.view_inv[9] + a.view_inv[10] * b.view_inv[10];
             cut = !(moved2 <= lim * lim) || !(turn >= 0.99939f) || std::memcmp(a.proj_inv, b.proj_inv, sizeof(a.proj_inv)) != 0;
         }
-        ord.view = p.views[0];
+        for (uint32_t f = 0; f < std::max(p.n_frames, 1u); f++) ord.view[f] = p.views[f];
         ord.key = key;
         // (variant bit 19: feedback always on, for A/B runs)
         p.fb = (s->dbg_cost || ((variant >> 19) & 1u)) ? nullptr : &slot.ctr->fb[mode == kModeAo ? 1 : 0];

@@ -298,6 +298,11 @@ Stats render_input(const Options &o, const std::string &input) {
     check(trx_scene_create(flat->bvh_bytes, flat->n_nodes, flat->tri_verts, flat->n_tris, TRX_TRI_VERTS_36,
                            flat->n_instances ? flat->instance_offsets : nullptr, flat->n_instances, flat->tlas_start,
                            o.device, &scene), "scene upload");
+    // a re-braided TLAS (trx_set_build_rebraid, on by default) names the node of its BLAS at which each primitive's walk
+    // starts; without the table every primitive would enter its BLAS at the root and a ray crossing k sub-boxes of one
+    // BLAS would walk that BLAS k times (same hits, many more node visits)
+    if (flat->instance_entry_nodes && flat->n_instances)
+        check(trx_scene_set_instance_entry_nodes(scene, flat->instance_entry_nodes, flat->n_instances), "instance entry nodes");
     trx_view view;
     check(trx_view_from_camera(cam.eye, cam.look_at, cam.fov, (float)o.width, (float)o.height, &view), "camera");
 

@@ -753,6 +753,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         const uint32_t list = (15u - (j >> 3)) * kLptShards + (j & 7u);
                         cur_tile = P.lpt_read_lists[(size_t)list * P.lpt_cap + (chunk - start)];
                         cur_tile = __builtin_amdgcn_readfirstlane(cur_tile);
+                        if (cur_tile >= n_chunks) cur_tile = chunk; // (only a corrupted list can name such a tile: never turn it into an out-of-range pixel)
                         // the tiles that set the frame's critical path get issue priority over the
                         // waves they share a SIMD with
                         if (chunk < P.prio_cut[0]) __builtin_amdgcn_s_setprio(3);
