@@ -702,6 +702,8 @@ def main():
             },
             "kernel_ms_mean": round(kernel_ms, 4),
             "kernel_ms_min": round(min(launch_ms), 4),
+            # every timed launch in order, for short runs (the driver's protocol is 20): shows a schedule still settling
+            "kernel_ms_per_step": [round(x, 4) for x in launch_ms] if len(launch_ms) <= 64 else None,
             "timed_region_ms": round(elapsed * 1e3, 3),
             "roofline": roof,
             "roofline_hbm": hbm,

@@ -279,10 +279,12 @@ int trx_trace_primary_batch_dev(trx_scene *scene, const trx_view *views, uint32_
  * cosine-hemisphere direction from hash_noise(px, frame) /
  * hash_noise(px, frame + 1024)) and trace it (closest hit).  Pixels whose
  * primary ray missed get a miss record.  ao_eps: 0.0001 (GPU) / 0.01 (CPU).
- * The direction's sin / cos (sampling.hlsl:33-34 calls the platform's) are evaluated by an explicit polynomial
- * (|error| < 2.5e-7) so that results reproduce bit for bit across machines; against another platform's libm the
- * AO hit's t moves in its last bits on a few percent of the rays (within 1e-5 relative except for grazing hits, worst
- * measured 5.7e-5), its triangle index on fewer than 1 ray in 10,000, hit / miss never. */
+ * The direction's sin / cos (sampling.hlsl:33-34 calls the platform's; on the CPU path Rust's f32::sin / cos are the C
+ * library's sinf / cosf) are evaluated explicitly so that results reproduce bit for bit across machines: the binary64
+ * algorithm the GNU C library (2.28 and later) publishes for sinf / cosf, rounded once to binary32 - identical to glibc's
+ * sinf / cosf for every binary32 in [0, 2 pi], so on a Linux host the AO directions are the reference CPU path's own.
+ * Against a correctly rounded sin / cos (another C library) the AO hit's t moves in its last bits on a fraction of a
+ * per cent of the rays. */
 int trx_trace_ao_dev(trx_scene *scene, const trx_view *view, uint32_t width,
                      uint32_t height, trx_shard shard, uint32_t semantics, uint32_t frame,
                      float ao_eps, const trx_hit *d_primary, trx_hit *d_ao, void *stream);
@@ -293,6 +295,19 @@ int trx_trace_ao_dev(trx_scene *scene, const trx_view *view, uint32_t width,
 int trx_trace_ao_inst_dev(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height, trx_shard shard,
                           uint32_t semantics, uint32_t frame, float ao_eps, const trx_hit *d_primary,
                           const uint32_t *d_primary_inst, trx_hit *d_ao, uint32_t *d_ao_inst, void *stream);
+
+/* n_frames (1..TRX_MAX_BATCH_FRAMES) AO passes over ONE view and ONE primary hit buffer as one launch: pass f uses the
+ * noise seed frame0 + f and writes its records at d_ao + f * frame_stride (d_ao_inst likewise, may be NULL;
+ * d_primary_inst as for trx_trace_ao_inst_dev, NULL without instance transforms).  This is BASELINE.json's "4 spp":
+ * the reference traces one AO ray per hit pixel per frame and varies the seed with the frame counter
+ * (src/rt_cpu/rt_cpu.rs:95-97, src/rt_gpu/rt_gpu_software.rs:285-288), so 4 spp are frames 0..3 - submitted together
+ * they share one launch's start-up and, above all, ONE drain (the end of an incoherent pass, where every wave finishes
+ * its last rays at falling occupancy: two thirds of a hairball-class pass).  The seeds of a tile go to the same XCD.
+ * Results are identical to n_frames separate trx_trace_ao_inst_dev launches. */
+int trx_trace_ao_batch_dev(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height, trx_shard shard,
+                           uint32_t semantics, uint32_t frame0, uint32_t n_frames, float ao_eps,
+                           const trx_hit *d_primary, const uint32_t *d_primary_inst, trx_hit *d_ao, uint32_t *d_ao_inst,
+                           uint64_t frame_stride, void *stream);
 
 /* Batch form of Traversable::traverse (traversable/src/lib.rs:13-28):
  * n explicit rays -> n hits. */

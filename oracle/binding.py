@@ -71,6 +71,7 @@ def load():
         "orc_uhash": (u32, [u32, u32]),
         "orc_hash_noise": (f, [u32, u32, u32]),
         "orc_sincos": (None, [f, P, P]),
+        "orc_sincos_libm_mismatches": (C.c_uint64, [u32, u32, u32]),
         "orc_traverse": (HitC, [SP, P, P, f, f, u32, STP]),
         "orc_trace_primary": (None, [SP, VP, u32, u32, u32, u32, u32, i, P, STP]),
         "orc_trace_ao": (None, [SP, VP, u32, u32, u32, u32, u32, u32, f, i, P, P, STP]),
@@ -105,8 +106,9 @@ def set_simd(on):
 
 
 def set_ao_libm(on):
-    """Measurement aid: AO directions from libm sinf / cosf instead of the explicit polynomial (oracle only)."""
-    load().orc_set_ao_libm(1 if on else 0)
+    """Measurement aid (oracle only): AO directions from libm sinf / cosf (True or 1) or from a correctly rounded sin /
+    cos (2) instead of the explicit evaluation."""
+    load().orc_set_ao_libm(int(on))
 
 
 def _ptr(a):

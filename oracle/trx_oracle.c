@@ -224,37 +224,89 @@ float orc_hash_noise(uint32_t x, uint32_t y, uint32_t frame) {
     return (float)urnd * (1.0f / 4294967296.0f); /* 1/float(0xffffffff): float(0xffffffff) == 2^32 */
 }
 
-/* sin/cos of theta in [0, 2*pi]: the reference calls the platform's sin/cos
- * (sampling.hlsl:33-34), which are not bit-reproducible across libm / GPU.
- * Both this oracle and the kernels use the same explicit evaluation instead:
- * Cody-Waite reduction by pi/2 and the cephes single-precision minimax
- * polynomials on [-pi/4, pi/4] (max error ~1 ulp). */
+/* sin/cos of theta in [0, 2*pi].  The reference calls its platform's sin / cos (sampling.hlsl:33-34; obvhs
+ * test_util::sampling on the CPU path, src/rt_cpu/rt_cpu.rs:5-8,69-73, where Rust's f32::sin / cos are the C library's
+ * sinf / cosf).  A platform call is not reproducible on a GPU, so this oracle and the kernels both evaluate the SAME
+ * explicit binary64 algorithm and round once to binary32 - and the algorithm is the one the GNU C library (2.28 and
+ * later; also bionic and the Arm Optimized Routines it comes from) publishes for sinf / cosf: quadrant n =
+ * round(x * 2/pi) through a scaled integer conversion, r = x - n * pi/2 in binary64, then a degree-7 odd / degree-8 even
+ * polynomial in binary64.  Measured against this container's glibc 2.35: bit-identical sinf and cosf for EVERY binary32
+ * in [0, 2 pi] (orc_sincos_libm_mismatches, tests/test_oracle.py, profiles/r04_sincos_vs_libm.log), so on a Linux host
+ * the AO directions are the reference CPU path's own.  (Until round 3 both sides used a 2-3 ulp binary32 polynomial;
+ * against libm 5-7 % of the AO rays then differed in their last bits of t.  A correctly rounded sin / cos - what a
+ * CORE-MATH based C library returns - differs from this algorithm by one ulp for 1.3 % of the arguments: the exposure
+ * tool reports that column too.) */
 static int g_ao_libm = 0;
-/* Exposure measurement only (tools/semantics_exposure.py): AO directions from this platform's libm sinf / cosf, the
- * way the reference calls its platform's (sampling.hlsl:33-34), instead of the explicit evaluation below.  The
- * product has no such switch; the count of AO rays whose hit changes is what "parity unpinned" costs here. */
+/* Exposure measurement only (tools/semantics_exposure.py): AO directions from this platform's libm sinf / cosf (1), the
+ * way the reference calls its platform's, or from a correctly rounded sin / cos (2: binary64 libm rounded once to
+ * binary32), instead of the explicit evaluation below.  The product has no such switch. */
 void orc_set_ao_libm(int on) { g_ao_libm = on; }
 
+static const double SC_HPI_INV = 0x1.45F306DC9C883p+23; /* 2/pi * 2^24 */
+static const double SC_HPI = 0x1.921FB54442D18p0;       /* pi/2 */
+static const double SC_C0 = 0x1p0, SC_C1 = -0x1.ffffffd0c621cp-2, SC_C2 = 0x1.55553e1068f19p-5,
+                    SC_C3 = -0x1.6c087e89a359dp-10, SC_C4 = 0x1.99343027bf8c3p-16;
+static const double SC_S1 = -0x1.555545995a603p-3, SC_S2 = 0x1.1107605230bc4p-7, SC_S3 = -0x1.994eb3774cf24p-13;
+
 void orc_sincos(float theta, float *s, float *c) {
-    if (g_ao_libm) {
+    if (g_ao_libm == 1) {
         *s = sinf(theta);
         *c = cosf(theta);
         return;
     }
-    float kf = floorf(theta * 0.636619772f + 0.5f); /* round(theta * 2/pi) */
-    int k = (int)kf;
-    float r = theta - kf * 1.5703125f;              /* pi/2 split: hi */
-    r = r - kf * 4.837512969970703125e-4f;          /* mid */
-    r = r - kf * 7.54978995489188216e-8f;           /* lo */
-    float z = r * r;
-    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
-    switch (k & 3) {
+    if (g_ao_libm == 2) {
+        *s = (float)sin((double)theta);
+        *c = (float)cos((double)theta);
+        return;
+    }
+    const uint32_t top = (f2u(theta) >> 20) & 0x7ffu; /* sign cleared, exponent and three mantissa bits */
+    double x = (double)theta;
+    int n = 0;
+    if (top >= 0x3f4u) { /* |theta| >= 0.75: reduce by multiples of pi/2 (theta <= 2 pi here, far below the 120 the method allows) */
+        const double q = x * SC_HPI_INV;
+        n = ((int32_t)q + 0x800000) >> 24;
+        x = x - (double)n * SC_HPI;
+    }
+    const double x2 = x * x;
+    /* sine polynomial */
+    const double x3 = x * x2;
+    const double s1 = SC_S2 + x2 * SC_S3;
+    const double x7 = x3 * x2;
+    const double sa = x + x3 * SC_S1;
+    float sp = (float)(sa + x7 * s1);
+    /* cosine polynomial */
+    const double x4 = x2 * x2;
+    const double c2 = SC_C3 + x2 * SC_C4;
+    const double c1 = SC_C0 + x2 * SC_C1;
+    const double x6 = x4 * x2;
+    const double ca = c1 + x4 * SC_C2;
+    float cp = (float)(ca + x6 * c2);
+    if (top < 0x398u) { /* |theta| < 2^-12 */
+        sp = theta;
+        cp = 1.0f;
+    }
+    switch (n & 3) {
     case 0: *s = sp; *c = cp; break;
     case 1: *s = cp; *c = -sp; break;
     case 2: *s = -sp; *c = -cp; break;
     default: *s = -cp; *c = sp; break;
     }
+}
+
+/* Every binary32 whose bits lie in [lo_bits, hi_bits], `stride` apart: how many have orc_sincos's sine or cosine differ
+ * from this platform's sinf / cosf (bit compare).  0 over [0, 2 pi] on glibc >= 2.28. */
+uint64_t orc_sincos_libm_mismatches(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride) {
+    uint64_t bad = 0;
+    if (stride == 0) stride = 1;
+    const int64_t n = ((int64_t)hi_bits - (int64_t)lo_bits) / stride + 1;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        const float th = u2f(lo_bits + (uint32_t)i * stride);
+        float s, c;
+        orc_sincos(th, &s, &c);
+        bad += (f2u(s) != f2u(sinf(th))) || (f2u(c) != f2u(cosf(th)));
+    }
+    return bad;
 }
 
 /* AO ray of src/rt_cpu/rt_cpu.rs:61-76 / src/rt_gpu/rt_gpu_software.hlsl:105-121.

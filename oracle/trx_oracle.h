@@ -102,7 +102,9 @@ int orc_ao_ray(const orc_scene *s, const orc_view *view, uint32_t w, uint32_t h,
 uint32_t orc_uhash(uint32_t a, uint32_t b);
 float orc_hash_noise(uint32_t x, uint32_t y, uint32_t frame);
 void orc_sincos(float theta, float *s, float *c);
-void orc_set_ao_libm(int on); /* measurement aid: libm sinf / cosf in the AO direction */
+void orc_set_ao_libm(int on); /* measurement aid: 1 = libm sinf / cosf, 2 = correctly rounded sin / cos in the AO direction */
+/* binary32 values with bits lo..hi (step `stride`) whose orc_sincos differs from this platform's sinf / cosf */
+uint64_t orc_sincos_libm_mismatches(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride);
 /* Node test over the eight children at once in AVX2 registers instead of the scalar loop: the same IEEE operations
  * per child, so every result is bit-identical (tests/test_oracle.py asserts it on the goldens and on whole frames);
  * it is what bench.py's cpu_baseline leg times, because the reference's CPU node test (obvhs) is SIMD as well.

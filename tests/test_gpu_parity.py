@@ -203,6 +203,48 @@ def test_shards_and_layouts(trx, orc):
     sc.close()
 
 
+@pytest.mark.parametrize("name,tris,tlas,w,h", [("kitchen", 20000, False, 100, 52), ("cornell", 0, False, 33, 47),
+                                               ("san_miguel", 60000, True, 120, 72), ("bistro", 400000, False, 256, 144)])
+def test_ao_batch_is_n_separate_ao_passes(trx, orc, name, tris, tlas, w, h):
+    """trx_trace_ao_batch_dev (BASELINE.json configs[3]'s "4 spp" = AO frames with seeds frame0 .. frame0 + n - 1 over
+    one view and one primary hit buffer, as ONE launch): every frame of the batch equals the oracle's AO pass with that
+    seed, bit for bit; n = 2, 3, 4, 8, image sizes whose tile count is not a multiple of eight (the queues are padded),
+    a two-level scene, and a compact tile shard."""
+    import torch
+    from tray_racing_amd import dist as D
+    flat, view, osc, ov = make_scene(trx, orc, name, tris, w, h, tlas=tlas)
+    sc = trx.Scene(flat)
+    op, _ = osc.trace_primary(ov, w, h, sem=3)
+    d_prim = torch.empty(w * h, dtype=torch.int64, device="cuda")
+    sc.trace_primary_dev(view, w, h, d_prim.data_ptr(), sem=3)
+    for n, frame0 in ((2, 0), (3, 7), (4, 0), (8, 1021)):
+        stride = w * h + 5                                           # frames need not be packed
+        d_ao = torch.full((n * stride,), -1, dtype=torch.int64, device="cuda")
+        sc.trace_ao_batch_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), stride, n, sem=3, frame0=frame0, ao_eps=0.01)
+        torch.cuda.synchronize()
+        sc.check()
+        for f in range(n):
+            want, _ = osc.trace_ao(ov, w, h, op, sem=3, frame=frame0 + f, ao_eps=0.01)
+            assert_hits_equal(D.int64_to_hits(d_ao[f * stride: f * stride + w * h]), want, "%s ao batch of %d, frame %d" % (name, n, f))
+            assert bool((d_ao[f * stride + w * h: (f + 1) * stride] == -1).all())    # nothing written between frames
+    # a compact tile shard: rank 1 of 3 traces its tiles of the primary frame and of a 4-frame AO batch
+    world, r = 3, 1
+    fg = D.FrameGather(w, h, r, world, "cuda")
+    rec = D.max_shard_tiles(w, h, world) * 64
+    lp = fg.new_local()
+    sc.trace_primary_dev(view, w, h, lp.data_ptr(), sem=3, shard=(r, world, 1))
+    la = torch.full((4 * rec,), -1, dtype=torch.int64, device="cuda")
+    sc.trace_ao_batch_dev(view, w, h, lp.data_ptr(), la.data_ptr(), rec, 4, sem=3, frame0=2, ao_eps=0.0001, shard=(r, world, 1))
+    one = torch.full((rec,), -1, dtype=torch.int64, device="cuda")
+    for f in range(4):
+        one.fill_(-1)
+        sc.trace_ao_dev(view, w, h, lp.data_ptr(), one.data_ptr(), sem=3, frame=2 + f, ao_eps=0.0001, shard=(r, world, 1))
+        torch.cuda.synchronize()
+        assert bool((la[f * rec:(f + 1) * rec] == one).all()), "shard layout, frame %d" % f
+    sc.check()
+    sc.close()
+
+
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (9, 8), (64, 1), (33, 47)])
 def test_image_sizes_not_multiple_of_8(trx, orc, w, h):
     flat, view, osc, ov = make_scene(trx, orc, "cornell", 0, w, h)
@@ -506,11 +548,24 @@ def test_full_size_hairball_4spp_whole_frames(trx, orc):
     ov = orc.view_from_bytes(view)
     op, ost = osc.trace_primary(ov, w, h, sem=3)
     assert ost.n_hits > 0.25 * w * h
+    # the four AO frames as ONE launch (trx_trace_ao_batch_dev: they share one drain), and frame 0 once more through
+    # the two-pass entry point the reference's frame loop maps to
+    import torch
+    from tray_racing_amd import dist as D
+    d_prim = torch.empty(w * h, dtype=torch.int64, device="cuda")
+    d_ao = torch.full((4 * w * h,), -1, dtype=torch.int64, device="cuda")
+    sc.trace_primary_dev(view, w, h, d_prim.data_ptr(), sem=3)
+    sc.trace_ao_batch_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), w * h, 4, sem=3, frame0=0, ao_eps=0.01)
+    torch.cuda.synchronize()
+    sc.check()
+    assert_hits_equal(D.int64_to_hits(d_prim), op, "hairball primary")
     for frame in range(4):
-        gp, gao, _ = sc.trace_primary_ao(view, w, h, sem=3, frame=frame, ao_eps=0.01)
-        assert_hits_equal(gp, op, "hairball primary, frame %d" % frame)
         oao, _ = osc.trace_ao(ov, w, h, op, sem=3, frame=frame, ao_eps=0.01)
-        assert_hits_equal(gao, oao, "hairball ao frame %d" % frame)
+        assert_hits_equal(D.int64_to_hits(d_ao[frame * w * h:(frame + 1) * w * h]), oao, "hairball ao frame %d (batch)" % frame)
+        if frame == 0:
+            gp, gao, _ = sc.trace_primary_ao(view, w, h, sem=3, frame=0, ao_eps=0.01)
+            assert_hits_equal(gp, op, "hairball primary (two-pass entry point)")
+            assert_hits_equal(gao, oao, "hairball ao frame 0 (two-pass entry point)")
     sc.close()
 
 
@@ -836,12 +891,12 @@ def test_camera_cuts_and_schedule_modes_never_change_the_hits(trx, orc):
         lib.trx_set_kernel_variant(1 << 7)
         for k in range(3):
             assert_hits_equal(sc.trace_primary(view, w, h, sem=3)[0], want[0], "every frame a cut, frame %d" % k)
-        # the feedback tunes itself: 24 frames with it, 4 without, then the faster mode holds - whichever mode a frame
-        # runs in, and across the switches, the hits are the oracle's
+        # the feedback tunes itself: 64 frames with it, 4 without, 4 with mid-tile refills, then the fastest mode holds -
+        # whichever mode a frame runs in, and across the switches, the hits are the oracle's
         lib.trx_set_kernel_variant(0)
-        for k in range(40):
+        for k in range(84):
             got = sc.trace_primary(view, w, h, sem=3)[0]
-            if k % 3 == 0 or 20 <= k < 34:
+            if k % 5 == 0 or 58 <= k < 78:
                 assert_hits_equal(got, want[0], "self-tuning feedback, frame %d" % k)
     finally:
         lib.trx_set_kernel_variant(0)

@@ -2,7 +2,8 @@
 (1) the TRX_SEM_CPU preset (NODE_RCP | TIE_FIRST) being a recollection of obvhs, while the only in-tree normative text
 is the HLSL (TRX_SEM_HLSL): rays of each BASELINE frame whose (t, prim) differ between the two;
 (2) the AO directions using an explicit sin / cos where the reference calls its platform's: AO rays whose hit differs
-when this platform's libm sinf / cosf is used instead.
+when this platform's libm sinf / cosf is used instead (since round 4 the explicit evaluation is glibc's own binary64
+algorithm, so on a glibc host this column is 0), and when a correctly rounded sin / cos is (another C library).
 Oracle only (CPU), full BASELINE sizes by default.  usage: python tools/semantics_exposure.py [--scale 4] [--json out]"""
 import argparse
 import json
@@ -42,16 +43,22 @@ def measure(scene, w, h, tlas, tris=0):
     rel = float(np.max(np.abs(p_cpu["t"][both] - p_hlsl["t"][both]) / p_hlsl["t"][both])) if both.any() else 0.0
     a_cpu, ast = osc.trace_ao(view, w, h, p_cpu, sem=O.SEM_CPU, frame=0, ao_eps=0.01)
     a_hlsl, _ = osc.trace_ao(view, w, h, p_cpu, sem=O.SEM_HLSL, frame=0, ao_eps=0.01)
-    O.set_ao_libm(True)
-    try:
-        a_libm, _ = osc.trace_ao(view, w, h, p_cpu, sem=O.SEM_CPU, frame=0, ao_eps=0.01)
-    finally:
-        O.set_ao_libm(False)
-    dl = differ(a_cpu, a_libm)
-    hit_flip = np.isfinite(a_cpu["t"]) != np.isfinite(a_libm["t"])
-    prim_change = dl & (a_cpu["prim"] != a_libm["prim"])
-    same_tri = dl & ~prim_change & np.isfinite(a_cpu["t"]) & np.isfinite(a_libm["t"])
-    rel_l = float(np.max(np.abs(a_cpu["t"][same_tri] - a_libm["t"][same_tri]) / a_cpu["t"][same_tri])) if same_tri.any() else 0.0
+    def against(mode):
+        """AO frame with the AO directions from another sin / cos: (rays differing, ... another triangle, hit <-> miss,
+        max rel. dt on the same triangle)."""
+        O.set_ao_libm(mode)
+        try:
+            other, _ = osc.trace_ao(view, w, h, p_cpu, sem=O.SEM_CPU, frame=0, ao_eps=0.01)
+        finally:
+            O.set_ao_libm(0)
+        dl = differ(a_cpu, other)
+        flip = np.isfinite(a_cpu["t"]) != np.isfinite(other["t"])
+        pc = dl & (a_cpu["prim"] != other["prim"])
+        same = dl & ~pc & np.isfinite(a_cpu["t"]) & np.isfinite(other["t"])
+        rel_s = float(np.max(np.abs(a_cpu["t"][same] - other["t"][same]) / a_cpu["t"][same])) if same.any() else 0.0
+        return int(dl.sum()), int(pc.sum()), int(flip.sum()), rel_s
+    libm = against(1)   # this platform's sinf / cosf (glibc: the explicit evaluation IS its algorithm -> 0 expected)
+    cr = against(2)     # a correctly rounded sin / cos (what a CORE-MATH based C library returns)
     return {
         "tris": int(flat.n_tris), "primary_rays": int(w * h), "primary_hits": int(st.n_hits),
         "primary_differ_hlsl_vs_cpu": int(d.sum()),
@@ -59,10 +66,14 @@ def measure(scene, w, h, tlas, tris=0):
         "primary_max_rel_dt": rel,
         "ao_rays": int(ast.n_rays),
         "ao_differ_hlsl_vs_cpu": int(differ(a_cpu, a_hlsl).sum()),
-        "ao_differ_libm_vs_explicit_sincos": int(dl.sum()),
-        "ao_libm_prim_changes": int(prim_change.sum()),
-        "ao_libm_max_rel_dt_same_triangle": rel_l,
-        "ao_libm_hit_miss_flips": int(hit_flip.sum()),
+        "ao_differ_libm_vs_explicit_sincos": libm[0],
+        "ao_libm_prim_changes": libm[1],
+        "ao_libm_max_rel_dt_same_triangle": libm[3],
+        "ao_libm_hit_miss_flips": libm[2],
+        "ao_differ_correctly_rounded_vs_explicit_sincos": cr[0],
+        "ao_cr_prim_changes": cr[1],
+        "ao_cr_max_rel_dt_same_triangle": cr[3],
+        "ao_cr_hit_miss_flips": cr[2],
     }
 
 
@@ -81,10 +92,13 @@ def main():
         r = measure(scene, w // args.scale, h // args.scale, tlas, tris)
         out[label] = r
         print("%-40s primary %8d rays: %4d differ HLSL vs CPU preset (%d of them prim-only ties, max rel dt %.1e) | AO %8d rays: %4d differ "
-              "HLSL vs CPU, %5d differ libm vs explicit sin/cos (%d other triangle, %d hit<->miss, max rel dt on the same triangle %.1e)" % (
+              "HLSL vs CPU; vs this platform's libm sinf / cosf %d differ (%d other triangle, %d hit<->miss, max rel dt %.1e); vs a "
+              "correctly rounded sin / cos %d differ (%d other triangle, %d hit<->miss, max rel dt on the same triangle %.1e)" % (
                   label, r["primary_rays"], r["primary_differ_hlsl_vs_cpu"], r["primary_differ_prim_only_ties"],
                   r["primary_max_rel_dt"], r["ao_rays"], r["ao_differ_hlsl_vs_cpu"], r["ao_differ_libm_vs_explicit_sincos"],
-                  r["ao_libm_prim_changes"], r["ao_libm_hit_miss_flips"], r["ao_libm_max_rel_dt_same_triangle"]), flush=True)
+                  r["ao_libm_prim_changes"], r["ao_libm_hit_miss_flips"], r["ao_libm_max_rel_dt_same_triangle"],
+                  r["ao_differ_correctly_rounded_vs_explicit_sincos"], r["ao_cr_prim_changes"], r["ao_cr_hit_miss_flips"],
+                  r["ao_cr_max_rel_dt_same_triangle"]), flush=True)
     if args.json:
         json.dump(out, open(args.json, "w"), indent=1)
 

@@ -407,7 +407,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     // profiles/r03_refill_sweep.log: 12 / 16 / 20 idle lanes = 0.880 / 0.886 / 0.884 ms bistro-class, 0.864 / 0.860 / 0.851
     // hairball-class, 1.382 / 1.369 / 1.383 dense, 0.402 / 0.383 / 0.389 kitchen-class)
     p.refill_idle = refill ? std::min(refill, 64u) : (mode == kModePrimary ? 64u : 16u);
-    if (p.n_frames > 1) p.refill_idle = 64u; // the kernel takes the frame of a wave from its (whole) tile
+    if (p.n_frames > 1 && mode == kModePrimary) p.refill_idle = 64u; // the kernel takes the frame of a wave from its (whole) tile
     p.variant = variant;
 #ifdef TRX_DEV_TUNE
     {   // development builds only (make KFLAGS=-DTRX_DEV_TUNE): experiment switches of kernels.hip, some of which
@@ -440,7 +440,8 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.wave_times = s->d_wave_times;
     p.single_queue = (variant >> 21) & 1u;
     // tile order feedback (image modes, whole-tile refills only)
-    const bool lpt = mode != kModeRays && p.refill_idle == 64u && !((variant >> 20) & 1u);
+    // (an AO batch deals its tiles seed by seed within a queue: it has no tile order to learn)
+    const bool lpt = mode != kModeRays && p.refill_idle == 64u && !((variant >> 20) & 1u) && !(mode == kModeAo && p.n_frames > 1);
     // the drain's parking area covers the second wave's parked tile-list entries (lds_pend): a pass that files tiles
     // (whole-tile refills with the order feedback on - reachable for AO through trx_set_kernel_variant) does not merge
     if (lpt) p.merge = 0u;
@@ -1002,6 +1003,41 @@ int trx_trace_ao_inst_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32
 int trx_trace_ao_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,
                      uint32_t frame, float ao_eps, const trx_hit *d_primary, trx_hit *d_ao, void *stream) {
     return trx_trace_ao_inst_dev(s, view, w, h, shard, sem, frame, ao_eps, d_primary, nullptr, d_ao, nullptr, stream);
+}
+
+int trx_trace_ao_batch_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,
+                           uint32_t frame0, uint32_t n_frames, float ao_eps, const trx_hit *d_primary,
+                           const uint32_t *d_primary_inst, trx_hit *d_ao, uint32_t *d_ao_inst, uint64_t frame_stride,
+                           void *stream) {
+    if (!s || !d_primary || !d_ao) return fail(TRX_ERR_INVALID, "null argument");
+    if (n_frames == 0 || n_frames > (uint32_t)kMaxBatchFrames)
+        return fail(TRX_ERR_INVALID, "n_frames %u outside 1..%d", n_frames, kMaxBatchFrames);
+    if (n_frames == 1)
+        return trx_trace_ao_inst_dev(s, view, w, h, shard, sem, frame0, ao_eps, d_primary, d_primary_inst, d_ao, d_ao_inst, stream);
+    TraceParams p;
+    std::memset(&p, 0, sizeof(p));
+    int rc = image_params(p, view, w, h, shard);
+    if (rc) return rc;
+    const uint64_t frame_records = p.compact ? (uint64_t)p.tiles_per_frame * 64 : (uint64_t)w * h;
+    if (frame_stride < frame_records)
+        return fail(TRX_ERR_INVALID, "frame_stride %llu < %llu records of one frame", (unsigned long long)frame_stride,
+                    (unsigned long long)frame_records);
+    // every queue gets the same number of tickets: the tile count is padded to a multiple of eight (the kernel skips
+    // the padding), and the seeds of a tile are consecutive tickets of one queue
+    const uint64_t tiles8 = ((uint64_t)p.tiles_per_frame + 7u) & ~7ull;
+    if (tiles8 * 64 * n_frames > 0x7fffffffull || frame_stride * (n_frames - 1) + frame_records > 0xffffffffull)
+        return fail(TRX_ERR_INVALID, "batch of %u frames too large", n_frames);
+    if (p.n_items == 0) return TRX_OK;
+    p.n_frames = n_frames;
+    p.frame_stride = (uint32_t)frame_stride;
+    p.n_items = (uint32_t)(tiles8 * 64 * n_frames);
+    p.primary = d_primary;
+    p.primary_inst = d_primary_inst;
+    p.out = d_ao;
+    p.out_inst = d_ao_inst;
+    p.frame = frame0;
+    p.ao_eps = ao_eps;
+    return enqueue(s, p, kModeAo, sem, false, (hipStream_t)stream, nullptr);
 }
 
 static int trace_rays_impl(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, trx_hit *d_hits,

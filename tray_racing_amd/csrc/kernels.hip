@@ -342,18 +342,37 @@ __device__ __forceinline__ float hash_noise(uint32_t x, uint32_t y, uint32_t fra
     return (float)uhash(x, (y << 11) + frame) * (1.0f / 4294967296.0f);
 }
 
-// Explicit sin/cos (same evaluation as the oracle's; platform sin/cos are not
-// bit-reproducible): Cody-Waite reduction by pi/2 + cephes minimax polynomials.
+// Explicit sin / cos of theta in [0, 2 pi], operation for operation what the test suite's CPU restatement evaluates:
+// the binary64 algorithm the GNU C library publishes for sinf / cosf - quadrant through a scaled integer
+// conversion, r = x - n * pi/2, a degree-7 odd and a degree-8 even polynomial - rounded once to binary32.  On a Linux
+// host that IS the reference CPU path's sin / cos (Rust's f32::sin / cos are libm's; checked bit for bit against glibc
+// for every binary32 in [0, 2 pi]).  Once per AO ray; binary64 vector arithmetic runs at full rate on this part.
 __device__ __forceinline__ void sincos_det(float theta, float &s, float &c) {
-    const float kf = floorf(theta * 0.636619772f + 0.5f);
-    const int k = (int)kf;
-    float r = theta - kf * 1.5703125f;
-    r = r - kf * 4.837512969970703125e-4f;
-    r = r - kf * 7.54978995489188216e-8f;
-    const float z = r * r;
-    const float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-    const float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
-    switch (k & 3) {
+    const uint32_t top = (__float_as_uint(theta) >> 20) & 0x7ffu;
+    double x = (double)theta;
+    int n = 0;
+    if (top >= 0x3f4u) { // |theta| >= 0.75
+        const double q = x * 0x1.45F306DC9C883p+23; // 2/pi * 2^24
+        n = ((int)q + 0x800000) >> 24;
+        x = x - (double)n * 0x1.921FB54442D18p0;
+    }
+    const double x2 = x * x;
+    const double x3 = x * x2;
+    const double s1 = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13;
+    const double x7 = x3 * x2;
+    const double sa = x + x3 * -0x1.555545995a603p-3;
+    float sp = (float)(sa + x7 * s1);
+    const double x4 = x2 * x2;
+    const double c2 = -0x1.6c087e89a359dp-10 + x2 * 0x1.99343027bf8c3p-16;
+    const double c1 = 0x1p0 + x2 * -0x1.ffffffd0c621cp-2;
+    const double x6 = x4 * x2;
+    const double ca = c1 + x4 * 0x1.55553e1068f19p-5;
+    float cp = (float)(ca + x6 * c2);
+    if (top < 0x398u) { // |theta| < 2^-12
+        sp = theta;
+        cp = 1.0f;
+    }
+    switch (n & 3) {
     case 0: s = sp; c = cp; break;
     case 1: s = cp; c = -sp; break;
     case 2: s = -sp; c = -cp; break;
@@ -578,6 +597,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     unsigned long long tile_t0 = 0;
     uint32_t tile_trip0 = 0;
     uint32_t cur_tile = 0, my_tile = 0;      // tile of the current chunk (uniform) / of this lane's item
+    uint32_t cur_vf = 0, my_vf = 0;          // AO batches: frame (noise seed) of the current chunk (uniform) / of this lane's item
     // Lists are kept per (cost bucket, shard): kLptShards appenders per bucket (a wave always appends to its own shard), because one atomic
     // word saturates near 90 appends/us.  Entry e = (15 - bucket) * kLptShards + shard is the e-th
     // list of the heaviest-first concatenation; lane l holds the (exclusive) ends of entries l, l+64.
@@ -743,6 +763,19 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     chunk_next = chunk << 6;
                     chunk_left = min(64u, P.n_items - chunk_next);
                     cur_tile = chunk;
+                    if (MODE == kModeAo && P.n_frames > 1u) {
+                        // AO batch (one view, one primary hit buffer, n_frames noise seeds - configs[3]'s "4 spp"): the
+                        // seeds of a tile are consecutive tickets of ONE queue, so the same XCD walks the same origins
+                        // through the same upper nodes n_frames times over; a tile id past the image is the padding of
+                        // the last group of eight tiles (every queue has the same number of tickets)
+                        const uint32_t tq = ticket / P.n_frames;
+                        cur_vf = ticket - tq * P.n_frames;
+                        cur_tile = P.single_queue ? tq : tq * 8u + my_q;
+                        if (cur_tile >= P.tiles_per_frame) {
+                            chunk_left = 0u;
+                            continue;
+                        }
+                    }
                     if (ordered) {
                         // chunk -> bucket (heaviest first) -> tile
                         uint32_t j = (uint32_t)__popcll(__ballot(chunk >= end_a));
@@ -781,6 +814,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 if (rank >= given && rank < given + take) {
                     item = chunk_next + (rank - given);
                     my_tile = cur_tile;
+                    if (MODE == kModeAo) my_vf = cur_vf;
                 }
                 chunk_next += take;
                 chunk_left -= take;
@@ -799,8 +833,15 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     ok = true;
                 } else {
                     // whole-tile refills only when frames are batched, so the frame is wave-uniform
-                    uint32_t local_tile = my_tile, frame_base = 0u, vf = 0u;
-                    if (P.n_frames > 1u) {
+                    uint32_t local_tile = my_tile, frame_base = 0u, vf = 0u, seed = P.frame;
+                    if (MODE == kModeAo) {
+                        // an AO batch shares its view and its primary hits; the lanes of a wave may hold different seeds
+                        // (mid-tile refills stay on), so nothing here is wave-uniform
+                        if (P.n_frames > 1u) {
+                            frame_base = my_vf * P.frame_stride;
+                            seed += my_vf;
+                        }
+                    } else if (P.n_frames > 1u) {
                         vf = __builtin_amdgcn_readfirstlane(my_tile / P.tiles_per_frame);
                         local_tile = my_tile - vf * P.tiles_per_frame;
                         frame_base = vf * P.frame_stride;
@@ -817,14 +858,14 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             r.ox = view.eye[0]; r.oy = view.eye[1]; r.oz = view.eye[2];
                             ok = true;
                         } else {
-                            const trx_hit ph = P.primary[out_index];
+                            const trx_hit ph = P.primary[out_index - frame_base];
                             if (ph.t < TRX_F32_MAX && ph.prim != TRX_INVALID) {
                                 // normal of the hit triangle, flipped toward the viewer
                                 const float4 *tp = P.tris + (size_t)ph.prim * 3;
                                 float nx = tp[0].w, ny = tp[1].w, nz = tp[2].w; // cross(e1, e2)
                                 if (TLAS && P.inst_xform) {
                                     // object-space normal -> world: transpose of world-to-object
-                                    const uint32_t pi = P.primary_inst[out_index];
+                                    const uint32_t pi = P.primary_inst[out_index - frame_base];
                                     if (pi != TRX_INVALID) {
                                         const float4 *m = P.inst_xform + (size_t)pi * 3;
                                         const float4 r0 = m[0], r1 = m[1], r2 = m[2];
@@ -842,8 +883,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                                 r.ox = (view.eye[0] + dx * ph.t) - dx * P.ao_eps;
                                 r.oy = (view.eye[1] + dy * ph.t) - dy * P.ao_eps;
                                 r.oz = (view.eye[2] + dz * ph.t) - dz * P.ao_eps;
-                                const float u1 = hash_noise(px, py, P.frame);
-                                const float u2 = hash_noise(px, py, P.frame + 1024u);
+                                const float u1 = hash_noise(px, py, seed);
+                                const float u2 = hash_noise(px, py, seed + 1024u);
                                 const float rr = sqrtf(u1);
                                 const float theta = u2 * 6.28318530717958647692f;
                                 float sn, cs;
@@ -1529,7 +1570,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 // (the first three relearn the order and do not count), kFbProbe frames in natural order, kFbProbe with
                 // mid-tile refills; the ordered mode stays unless another is 3 % faster; the winner holds for kFbHold frames,
                 // then everything is measured again.  Frame time = last wave out minus first wave in, best of a phase.
-                constexpr unsigned int kFbOn = 24u, kFbProbe = 4u, kFbHold = 1024u;
+                // (kFbOn was 24 until round 4: a bench protocol of 5 warm-up + 20 timed frames then had its last timed
+                // frames run as natural-order probes, 20 % slower each; a slot now runs ordered for its first 64 frames)
+                constexpr unsigned int kFbOn = 64u, kFbProbe = 4u, kFbHold = 1024u;
                 FbState &c = *P.fb;
                 if (P.new_view) c.mode = c.frames = c.phase = c.t[0] = c.t[1] = c.t[2] = 0u; // a new view measures afresh
                 const unsigned int dur = (unsigned int)min(wall_clock64() - c.t0, 0xffffffffull);
