@@ -115,6 +115,11 @@ def parse():
                     help="N > 1: frames completed by one all-gather; 0 = 8 (a 1080p frame is only 2 MB per rank at N = 8)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="frames submitted per kernel launch (1..8); 0 = 1 on one GPU, the gather batch beyond")
+    ap.add_argument("--wake-frames", type=int, default=64,
+                    help="untimed frames of the same workload BEFORE the warm-up steps: the GPU idles while the host builds the "
+                         "scene and its clocks take about 20 ms of load to come back up (profiles/r04_clock_ramp.log: the same "
+                         "kernel runs 5-7 %% slower for its first ~40 frames after an idle second, whatever the tile order); 0 = "
+                         "none, the warm-up steps then run on a GPU at idle clocks")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (child processes)")
@@ -379,12 +384,16 @@ def main():
         torch.cuda.synchronize()
 
     if world > 1:  # gather indices for every batch size the loops below will meet, built outside the timed region
-        fgs[0].prepare(min(F, args.steps), args.steps % F, min(F, max(args.warmup, 1)), args.warmup % F)
+        fgs[0].prepare(min(F, args.steps), args.steps % F, min(F, max(args.warmup, 1)), args.warmup % F,
+                       min(F, max(args.wake_frames, 1)), args.wake_frames % F)
     # set-up, like the scene upload: every stream's launch slot sees the frame geometry once (its first frame
     # runs in natural tile order and measures the tiles: reported separately as cold_order_ms)
     sync_all()
     run_frames(n_streams * (1 if world == 1 else F), [])
     sync_all()
+    if args.wake_frames > 0:   # bring the GPU out of its idle clocks (see --wake-frames); reported in config.wake_frames
+        run_frames(args.wake_frames, [])
+        sync_all()
     run_frames(args.warmup, [])
     sync_all()
     t0 = time.perf_counter()
@@ -695,9 +704,11 @@ def main():
                 "frames_in_flight": n_streams,   # kernels in flight inside the timed region (one per stream)
                 "frames_per_launch": L_launch,
                 "frames_per_gather": F,
+                # untimed frames ahead of the `warmup` steps that take the GPU out of its idle clocks (--wake-frames 0: none)
+                "wake_frames": args.wake_frames,
                 "build_seconds": round(build_s, 2),
-                "tile_order": "learnt from the previous frame on the same stream (static camera, as the reference "
-                              "benches); a first frame (natural order while the tiles are measured, no learnt order) in "
+                "tile_order": "filed by the first frame of the view on the stream, then replayed unchanged (static camera, as "
+                              "the reference benches); a first frame (natural order while the tiles are measured) in "
                               "legs.first_frame_ms, feedback off in legs.cold_order_ms",
             },
             "kernel_ms_mean": round(kernel_ms, 4),

@@ -296,6 +296,14 @@ int trx_trace_ao_inst_dev(trx_scene *scene, const trx_view *view, uint32_t width
                           uint32_t semantics, uint32_t frame, float ao_eps, const trx_hit *d_primary,
                           const uint32_t *d_primary_inst, trx_hit *d_ao, uint32_t *d_ao_inst, void *stream);
 
+/* The reference's whole pixel program as ONE launch (src/rt_gpu/rt_gpu_software.hlsl:47-144 is one dispatch: primary
+ * ray, normal of the hit triangle, AO ray): d_primary / d_ao receive exactly what trx_trace_primary_inst_dev followed by
+ * trx_trace_ao_inst_dev write (d_primary_inst / d_ao_inst may be NULL).  A lane whose primary ray ends in a hit becomes
+ * that pixel's AO ray in place, so neither pass has a tail of its own and the primary hits never travel through memory. */
+int trx_trace_frame_dev(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height, trx_shard shard,
+                        uint32_t semantics, uint32_t frame, float ao_eps, trx_hit *d_primary, uint32_t *d_primary_inst,
+                        trx_hit *d_ao, uint32_t *d_ao_inst, void *stream);
+
 /* n_frames (1..TRX_MAX_BATCH_FRAMES) AO passes over ONE view and ONE primary hit buffer as one launch: pass f uses the
  * noise seed frame0 + f and writes its records at d_ao + f * frame_stride (d_ao_inst likewise, may be NULL;
  * d_primary_inst as for trx_trace_ao_inst_dev, NULL without instance transforms).  This is BASELINE.json's "4 spp":

@@ -33,7 +33,8 @@ class SceneC(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_rays", C.c_uint64), ("n_node", C.c_uint64), ("n_tri", C.c_uint64), ("n_hits", C.c_uint64),
-                ("max_stack", C.c_uint32), ("overflow", C.c_uint32), ("seconds", C.c_double), ("threads", C.c_int)]
+                ("max_stack", C.c_uint32), ("overflow", C.c_uint32), ("seconds", C.c_double), ("threads", C.c_int),
+                ("n_tlas_node", C.c_uint64), ("n_inst_enter", C.c_uint64)]
 
 
 class HitC(C.Structure):

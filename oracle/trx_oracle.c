@@ -586,7 +586,7 @@ static inline __attribute__((always_inline)) orc_hit traverse_body(const orc_sce
     u2 cur = {0, 0x80000000u};
     float t = fminf(tmax, F32_MAX);
     uint32_t prim = INVALID;
-    uint64_t n_node = 0, n_tri = 0;
+    uint64_t n_node = 0, n_tri = 0, n_tlas_node = 0, n_inst_enter = 0;
 
 #define PUSH(g)                                   \
     do {                                          \
@@ -609,6 +609,7 @@ static inline __attribute__((always_inline)) orc_hit traverse_body(const orc_sce
             uint32_t child_node_index = child_index_base + relative_index;
             const uint32_t *node = s->nodes + 20 * (uint64_t)(bvh_offset + child_node_index);
             n_node++;
+            n_tlas_node += tlas && tlas_stack_size == INVALID;
 #ifdef ORC_HAVE_AVX2
             uint32_t hitmask = simd ? node_intersect_avx2(o, d, inv_d, oct_inv4, t, node, sem)
                                     : node_intersect_scalar(o, d, inv_d, oct_inv4, t, node, sem);
@@ -635,6 +636,7 @@ static inline __attribute__((always_inline)) orc_hit traverse_body(const orc_sce
                 if (tri.y != 0) PUSH(tri);
                 if (cur.y & 0xff000000u) PUSH(cur);
                 tlas_stack_size = sp;
+                n_inst_enter++;
                 bvh_offset = s->instance_offsets[global];
                 cur_inst = global;
                 if (s->instance_w2o) {
@@ -694,6 +696,8 @@ static inline __attribute__((always_inline)) orc_hit traverse_body(const orc_sce
         st->n_rays++;
         st->n_node += n_node;
         st->n_tri += n_tri;
+        st->n_tlas_node += n_tlas_node;
+        st->n_inst_enter += n_inst_enter;
         st->n_hits += prim != INVALID;
         if (max_sp > st->max_stack) st->max_stack = max_sp;
         st->overflow += (uint32_t)overflow;
@@ -727,6 +731,8 @@ static void stats_merge(orc_stats *dst, const orc_stats *src) {
     dst->n_rays += src->n_rays;
     dst->n_node += src->n_node;
     dst->n_tri += src->n_tri;
+    dst->n_tlas_node += src->n_tlas_node;
+    dst->n_inst_enter += src->n_inst_enter;
     dst->n_hits += src->n_hits;
     if (src->max_stack > dst->max_stack) dst->max_stack = src->max_stack;
     dst->overflow += src->overflow;

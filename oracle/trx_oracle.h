@@ -79,6 +79,8 @@ typedef struct orc_stats {
     uint32_t max_stack, overflow;
     double seconds; /* wall-clock of the frame loop */
     int threads;
+    /* two-level scenes: node visits spent in the TLAS (n_node counts both levels) and BLAS (sub)trees entered */
+    uint64_t n_tlas_node, n_inst_enter;
 } orc_stats;
 
 /* triangle format conversion to {v0,e1,e2} */

@@ -105,6 +105,11 @@ def save(name, flat, view, w, h, extra, asset=None, use_tlas=False):
 
 
 def main():
+    # TLAS fixtures are in the REFERENCE's layout - one TLAS primitive per whole BLAS (src/cwbvh.rs:108-137), no entry-node
+    # table, which buffers from the reference's host never carry; this library's re-braided TLAS has its own tests
+    # (tests/test_rebraid.py and the full-size two-level frame of the GPU suite)
+    from tray_racing_amd import _lib
+    _lib.check(_lib.load().trx_set_build_rebraid(0.0))
     # 1. Cornell-class box (5 objects), camera of assets/scenes/cornell_box.ron
     verts, counts = T.gen_scene("cornell", 0, 1)
     eye, look, fov = T.scene_camera("cornell")

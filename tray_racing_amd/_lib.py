@@ -104,6 +104,7 @@ SIGNATURES = {
     "trx_trace_primary_batch_dev": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, Shard, _u32, _P, _u64, _P]),
     "trx_trace_ao_dev": (_i, [_P, C.POINTER(View), _u32, _u32, Shard, _u32, _u32, _f, _P, _P, _P]),
     "trx_trace_ao_inst_dev": (_i, [_P, C.POINTER(View), _u32, _u32, Shard, _u32, _u32, _f, _P, _P, _P, _P, _P]),
+    "trx_trace_frame_dev": (_i, [_P, C.POINTER(View), _u32, _u32, Shard, _u32, _u32, _f, _P, _P, _P, _P, _P]),
     "trx_trace_ao_batch_dev": (_i, [_P, C.POINTER(View), _u32, _u32, Shard, _u32, _u32, _u32, _f, _P, _P, _P, _P, _u64, _P]),
     "trx_trace_rays_dev": (_i, [_P, _P, _u64, _u32, _P, _P]),
     "trx_trace_rays_inst_dev": (_i, [_P, _P, _u64, _u32, _P, _P, _P]),

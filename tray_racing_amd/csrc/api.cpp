@@ -112,7 +112,7 @@ struct Slot {
     struct Order {
         uint32_t *lists = nullptr; // two sets of {16 counts, 16 lists}
         uint32_t capacity = 0;
-        uint32_t parity = 0; // set written by the next frame
+        bool have_views = false; // view[] holds the views of a previous launch
         uint64_t key = 0;    // (width, height, shard, mode) the lists were measured for; 0 = none
         ViewDev view[kMaxBatchFrames]{}; // views of the last launch that read or wrote the lists (camera-cut detection)
     } order[2];
@@ -343,13 +343,13 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     Slot &slot = s->slots[pick];
     const bool same_stream = slot.used && slot.last_stream == stream;
     const uint32_t variant = g_variant.load(std::memory_order_relaxed);
-    // tuning overrides (trx_set_kernel_variant): bits 8..15 waves per CU, bits 16..19 waves per workgroup
+    // tuning overrides (trx_set_kernel_variant): bits 8..12 waves per CU, bits 16..19 waves per workgroup
     uint32_t wpb = (variant >> 16) & 0x7u; // (bit 19: the tile-order feedback does not tune itself off, see below)
     // incoherent single-level passes (AO, explicit rays) run two waves to a workgroup, so that the second can hand its last rays to the first
     // when both are draining (kernels.hip, "drain"); an explicit 1 or 4 here switches that off
-    const bool merge_default = (wpb != 1 && wpb != 2 && wpb != 4) && mode != kModePrimary && !s->tlas && !count;
+    const bool merge_default = (wpb != 1 && wpb != 2 && wpb != 4) && mode != kModePrimary && mode != kModeFused && !s->tlas && !count;
     if (wpb != 1 && wpb != 2 && wpb != 4) wpb = merge_default ? 2u : kDefaultWavesPerBlock;
-    const uint32_t per_cu = (variant >> 8) & 0xffu;
+    const uint32_t per_cu = (variant >> 8) & 0x1fu;
     int grid = per_cu ? (int)(std::min(per_cu, 32u) * (uint32_t)s->cu_count) : s->grid;
     // no more waves than chunks of work: a batch of one ray (trx_traverse1) is a one-wave launch with a
     // one-wave spill area
@@ -407,6 +407,12 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     // profiles/r03_refill_sweep.log: 12 / 16 / 20 idle lanes = 0.880 / 0.886 / 0.884 ms bistro-class, 0.864 / 0.860 / 0.851
     // hairball-class, 1.382 / 1.369 / 1.383 dense, 0.402 / 0.383 / 0.389 kitchen-class)
     p.refill_idle = refill ? std::min(refill, 64u) : (mode == kModePrimary ? 64u : 16u);
+    // fused frames, queues dry: lanes whose primary ray has hit wait for this many of their kind before the wave runs
+    // the AO ray set-up for them (tuning: variant bits 14..15)
+    {
+        static const uint32_t pend[4] = {8u, 1u, 16u, 32u};
+        p.pend_min = pend[(variant >> 14) & 3u];
+    }
     if (p.n_frames > 1 && mode == kModePrimary) p.refill_idle = 64u; // the kernel takes the frame of a wave from its (whole) tile
     p.variant = variant;
 #ifdef TRX_DEV_TUNE
@@ -441,7 +447,8 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.single_queue = (variant >> 21) & 1u;
     // tile order feedback (image modes, whole-tile refills only)
     // (an AO batch deals its tiles seed by seed within a queue: it has no tile order to learn)
-    const bool lpt = mode != kModeRays && p.refill_idle == 64u && !((variant >> 20) & 1u) && !(mode == kModeAo && p.n_frames > 1);
+    const bool lpt = mode != kModeRays && mode != kModeFused && p.refill_idle == 64u && !((variant >> 20) & 1u) &&
+                     !(mode == kModeAo && p.n_frames > 1);
     // the drain's parking area covers the second wave's parked tile-list entries (lds_pend): a pass that files tiles
     // (whole-tile refills with the order feedback on - reachable for AO through trx_set_kernel_variant) does not merge
     if (lpt) p.merge = 0u;
@@ -453,6 +460,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         const uint32_t n_lists = 16 * kLptShards;
         const uint32_t list_cap = n_tiles / 2 + 64; // a list holds ~1/8 of one bucket; overflow only drops the order
         const size_t set_words = n_lists + (size_t)n_lists * list_cap;
+        if (2 * set_words > 0xffffffffull) return fail(TRX_ERR_INVALID, "image too large for the tile-order lists");
         Slot::Order &ord = slot.order[mode == kModeAo ? 1 : 0];
         bool fresh = false;
         if (ord.capacity != n_tiles) {
@@ -492,7 +500,6 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
             const float turn = a.view_inv[8] * b.view_inv[8] + a.view_inv[9] * b.view_inv[9] + a.view_inv[10] * b.view_inv[10];
             cut = !(moved2 <= lim * lim) || !(turn >= 0.99939f) || std::memcmp(a.proj_inv, b.proj_inv, sizeof(a.proj_inv)) != 0;
         }
-        for (uint32_t f = 0; f < std::max(p.n_frames, 1u); f++) ord.view[f] = p.views[f];
         ord.key = key;
         // (variant bit 19: feedback always on, for A/B runs)
         p.fb = (s->dbg_cost || ((variant >> 19) & 1u)) ? nullptr : &slot.ctr->fb[mode == kModeAo ? 1 : 0];
@@ -501,17 +508,26 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
 #ifdef TRX_DEV_TUNE
         if (p.tune & 0x8000000u) p.no_order = cut ? 1u : 0u; // (A/B: the round-3 first version, natural order after a cut)
 #endif
-        if (fresh) { // new lists start empty (from then on every frame's exit wave leaves the set it read empty)
+        // A frame whose views are bit for bit those of the previous launch of this kind on the slot replays a complete
+        // order as it stands (the kernel decides: it alone knows whether the set it reads is complete) - the order filed
+        // by the first frame of a view, frozen, is the fastest one measured and costs no filing (kernels.hip); any other
+        // frame (a moving camera, the first frame of a geometry) files a new order while it runs, as before.
+        bool same_view = !no_order && ord.have_views;
+        for (uint32_t f = 0; f < std::max(p.n_frames, 1u) && same_view; f++)
+            same_view = std::memcmp(&ord.view[f], &p.views[f], sizeof(ViewDev)) == 0;
+        for (uint32_t f = 0; f < std::max(p.n_frames, 1u); f++) ord.view[f] = p.views[f];
+        ord.have_views = true;
+        unsigned int *sel = &slot.ctr->lpt_sel[mode == kModeAo ? 1 : 0];
+        if (fresh) { // new lists start empty; from then on a frame that files an order empties the set it read
             HIP_TRY(hipMemsetAsync(set[0], 0, n_lists * sizeof(uint32_t), stream));
             HIP_TRY(hipMemsetAsync(set[1], 0, n_lists * sizeof(uint32_t), stream));
-            ord.parity = 0;
+            HIP_TRY(hipMemsetAsync(sel, 0, sizeof(unsigned int), stream));
         }
-        p.lpt_read_counts = set[ord.parity ^ 1];
-        p.lpt_read_lists = set[ord.parity ^ 1] + n_lists;
-        p.lpt_write_counts = set[ord.parity];
-        p.lpt_write_lists = set[ord.parity] + n_lists;
+        p.lpt_sets = ord.lists;
+        p.lpt_sel = sel;
+        p.lpt_set_words = (uint32_t)set_words;
         p.lpt_cap = list_cap;
-        ord.parity ^= 1;
+        p.same_view = same_view ? 1u : 0u;
         // priority classes over the heaviest-first order (tuning: variant bits 22..24 pick the cuts)
         // measured on bistro-class 1080p: {32,8,2} 0.566 ms, {64,16,4} 0.572, {128,32,8} 0.585, none 0.630
         static const uint32_t cuts[8][3] = {{32, 8, 2}, {0, 0, 0}, {256, 64, 16}, {64, 16, 4}, {512, 128, 32},
@@ -530,7 +546,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     // The pipelined walk (next node's fetch issued under the triangle phase) pays where a node fetch leaves the L2s:
     // incoherent passes over scenes larger than the eight L2s together (measured: hairball-class AO -4..-6 %, dense
     // bistro-class -3 %, a 3 MB kitchen-class scene +4 %; coherent primary rays +-1 %: DESIGN.md section 4).
-    bool pipe = mode != kModePrimary && !s->tlas && s->n_nodes * TRX_NODE_BYTES + s->n_tris * sizeof(TriDev) > (32ull << 20);
+    bool pipe = mode != kModePrimary && mode != kModeFused && !s->tlas && s->n_nodes * TRX_NODE_BYTES + s->n_tris * sizeof(TriDev) > (32ull << 20);
 #ifdef TRX_DEV_TUNE
     if (p.tune & 0x1000u) pipe = true;
     if (p.tune & 0x10000u) pipe = false;
@@ -1003,6 +1019,35 @@ int trx_trace_ao_inst_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32
 int trx_trace_ao_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,
                      uint32_t frame, float ao_eps, const trx_hit *d_primary, trx_hit *d_ao, void *stream) {
     return trx_trace_ao_inst_dev(s, view, w, h, shard, sem, frame, ao_eps, d_primary, nullptr, d_ao, nullptr, stream);
+}
+
+int trx_trace_frame_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,
+                        uint32_t frame, float ao_eps, trx_hit *d_primary, uint32_t *d_primary_inst, trx_hit *d_ao,
+                        uint32_t *d_ao_inst, void *stream) {
+    if (!s || !d_primary || !d_ao) return fail(TRX_ERR_INVALID, "null argument");
+    if (s->tlas || ((g_variant.load(std::memory_order_relaxed) >> 13) & 1u)) {
+        // two-level scenes: the two-level walk has no registers to spare for the in-place hand-over (the kernel that
+        // contains it spills), so their frame stays two launches on the caller's stream - same records.  (Variant bit 13:
+        // every frame this way, for A/B runs.)
+        if (s->d_inst_xform && !d_primary_inst)
+            return fail(TRX_ERR_INVALID, "this scene has instance transforms: the frame needs d_primary_inst (the AO pass takes "
+                                         "the hit normal into world space with the primary pass's instance ids)");
+        int rc2 = trx_trace_primary_inst_dev(s, view, w, h, shard, sem, d_primary, d_primary_inst, stream);
+        if (rc2) return rc2;
+        return trx_trace_ao_inst_dev(s, view, w, h, shard, sem, frame, ao_eps, d_primary, d_primary_inst, d_ao, d_ao_inst, stream);
+    }
+    TraceParams p;
+    std::memset(&p, 0, sizeof(p));
+    int rc = image_params(p, view, w, h, shard);
+    if (rc) return rc;
+    p.out = d_primary;
+    p.out_inst = d_primary_inst;
+    p.out_ao = d_ao;
+    p.out_ao_inst = d_ao_inst;
+    p.frame = frame;
+    p.ao_eps = ao_eps;
+    if (p.n_items == 0) return TRX_OK;
+    return enqueue(s, p, kModeFused, sem, false, (hipStream_t)stream, nullptr);
 }
 
 int trx_trace_ao_batch_dev(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, trx_shard shard, uint32_t sem,

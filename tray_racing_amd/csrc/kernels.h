@@ -37,7 +37,9 @@ constexpr int kLdsBytesPerWave = TRX_LDS_STACK * kWave * 8 + kWave * 32 + kWave 
 constexpr int kWaveTimeStride = 8; // diagnostics record per wave: start, end, then (TRX_STAMPS builds) phase cycles
 constexpr uint32_t kMaxSteps = 1u << 22; // per-ray iteration cap: every wave reaches an exit
 
-enum TraceMode : int { kModePrimary = 0, kModeAo = 1, kModeRays = 2 };
+// kModeFused: the reference's whole pixel program in one launch (rt_gpu_software.hlsl:47-144): a lane whose primary
+// ray ends in a hit becomes that pixel's AO ray in place
+enum TraceMode : int { kModePrimary = 0, kModeAo = 1, kModeRays = 2, kModeFused = 3 };
 
 constexpr int kMaxBatchFrames = 8;
 
@@ -77,6 +79,7 @@ struct SlotCounters {
     unsigned int hist_max[16], hist_total[16];
     // self-tuning of the frame schedule, one state per pass kind (0 = primary, 1 = AO: a frame loop runs both on one stream)
     FbState fb[2];
+    unsigned int lpt_sel[2]; // which of a kind's two tile-list sets holds the order to read (TraceParams::lpt_sel)
 };
 
 struct TraceParams {
@@ -87,6 +90,9 @@ struct TraceParams {
     const trx_ray *rays;
     const trx_hit *primary;
     trx_hit *out;
+    trx_hit *out_ao;        // kModeFused: the AO pass's records (out = the primary pass's)
+    uint32_t *out_ao_inst;  // ... and their instance ids (TLAS scenes), or null
+    uint32_t pend_min;      // kModeFused, queues dry: convert finished primary rays to AO rays once this many lanes wait
     // instance transforms (TLAS scenes; all null = the reference's identity behaviour): world-to-object rows
     // {m0 m1 m2 t} x 3 per TLAS primitive; the instance each hit was found in, per record like `out`; the
     // primary pass's instance ids (AO mode: to take the hit triangle's normal into world space)
@@ -102,11 +108,15 @@ struct TraceParams {
     uint32_t compact; // TRX_LAYOUT_SHARD: hit buffers indexed by local_tile*64 + pixel-in-tile
     uint32_t single_queue;  // tuning: one global queue instead of one per XCD
     // tile order feedback: 16 x kLptShards list counts + lists (lpt_cap entries each) read / written this frame
-    uint32_t *lpt_read_counts;
-    const uint32_t *lpt_read_lists;
-    uint32_t *lpt_write_counts;
-    uint32_t *lpt_write_lists;
+    // Two list sets of lpt_set_words words each ({16 x kLptShards counts}{16 x kLptShards lists of lpt_cap tile ids}) at
+    // lpt_sets (null: no feedback); *lpt_sel (0 / 1, device side: the exit wave of a learning frame flips it) names the
+    // set this frame reads, the other one is empty and takes what a learning frame files.
+    uint32_t *lpt_sets;
+    unsigned int *lpt_sel;
+    uint32_t lpt_set_words;
     uint32_t lpt_cap;
+    uint32_t same_view;     // the views of this launch are those of the previous launch of this kind on the slot: a complete
+                            // order is replayed as it is - nothing is timed or filed (a FROZEN order, kernels.hip)
     uint32_t *cost;         // diagnostics: per-tile cost (wall-clock ticks), or null
     uint32_t prio_cut[3];   // chunks below these (heaviest-first) indices run at s_setprio 3 / 2 / 1
     uint8_t *touch_nodes, *touch_tris; // diagnostics (COUNT kernels): byte set per node fetched / triangle tested, or null

@@ -444,7 +444,7 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 // within the group.  (One atomic per ENTRY - round 1 and 2 - was 32 400 a frame on 128 counters, most of them as the
 // waves leave; in a natural-order frame neighbouring tiles share a class and a few counters took them all: 0.08 ms of a
 // bistro-class first frame, 0.11 ms of a kitchen-class one, profiles/r03_filing_cost.log.)
-__device__ __forceinline__ void flush_pending(const TraceParams &P, const uint2 *lds_pend, uint32_t n, uint32_t lane) {
+__device__ __forceinline__ void flush_pending(const TraceParams &P, uint32_t *wr_set, const uint2 *lds_pend, uint32_t n, uint32_t lane) {
     __builtin_amdgcn_wave_barrier();
     uint2 e = make_uint2(0u, 0xffffffffu);
     if (lane < n) e = lds_pend[lane];
@@ -460,24 +460,24 @@ __device__ __forceinline__ void flush_pending(const TraceParams &P, const uint2 
     const uint32_t leader = (uint32_t)__ffsll((long long)mine) - 1u; // (mine != 0 for a valid lane: it contains the lane itself)
     const uint32_t rank = (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
     uint32_t base = 0u;
-    if (valid && lane == leader) base = atomicAdd(&P.lpt_write_counts[e.y], (uint32_t)__popcll(mine));
+    if (valid && lane == leader) base = atomicAdd(&wr_set[e.y], (uint32_t)__popcll(mine));
     base = (uint32_t)__shfl((int)base, (int)(valid ? leader : lane));
     if (valid) {
         const uint32_t pos = base + rank;
-        if (pos < P.lpt_cap) P.lpt_write_lists[(size_t)e.y * P.lpt_cap + pos] = e.x;
+        if (pos < P.lpt_cap) wr_set[16u * kLptShards + (size_t)e.y * P.lpt_cap + pos] = e.x;
     }
     __builtin_amdgcn_wave_barrier();
 }
 
 // The same without the grouping, one atomic per entry: for the flush in the middle of a frame (a wave that has parked
 // kLptPend tiles - 4K frames), where the walk's registers are live and the grouped version would cost it a spill.
-__device__ __forceinline__ void flush_pending_plain(const TraceParams &P, const uint2 *lds_pend, uint32_t n, uint32_t lane) {
+__device__ __forceinline__ void flush_pending_plain(const TraceParams &P, uint32_t *wr_set, const uint2 *lds_pend, uint32_t n, uint32_t lane) {
     __builtin_amdgcn_wave_barrier();
     if (lane < n) {
         const uint2 e = lds_pend[lane];
         if (e.y < 16u * kLptShards) {
-            const uint32_t pos = atomicAdd(&P.lpt_write_counts[e.y], 1u);
-            if (pos < P.lpt_cap) P.lpt_write_lists[(size_t)e.y * P.lpt_cap + pos] = e.x;
+            const uint32_t pos = atomicAdd(&wr_set[e.y], 1u);
+            if (pos < P.lpt_cap) wr_set[16u * kLptShards + (size_t)e.y * P.lpt_cap + pos] = e.x;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -540,6 +540,12 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint4 pn0 = make_uint4(0u, 0u, 0u, 0u), pn1 = pn0, pn2 = pn0, pn3 = pn0, pn4 = pn0;
     uint2 ptri = make_uint2(0u, 0u);
     uint32_t overflow = 0; // sticky, set on the rare paths only (stack past its HBM part, step cap)
+    // kModeFused (the reference's one-dispatch frame, rt_gpu_software.hlsl:47-144): a lane whose primary ray has ended in
+    // a hit keeps t / prim / out_index and waits (`pend`) until the wave next refills; it is then turned into that pixel's
+    // AO ray in place (`is_ao`), together with every other waiting lane and with the lanes that take new pixels - one
+    // pass through the ray set-up code for all of them, not one per finished ray
+    constexpr bool kFused = MODE == kModeFused;
+    bool pend = false, is_ao = false;
     // The drain (incoherent single-level passes - AO, explicit rays - run two waves to a workgroup).  Every wave of such a pass finds the queues dry
     // holding about 45 rays and then spends a full ray lifetime finishing them at falling occupancy (13 % of a
     // bistro-class AO pass, 64 % of a hairball-class one: profiles/r03_ao_order.log).  Fewer waves draining is the remedy:
@@ -551,7 +557,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // (Single-level walks only.  The two-level kernels were given the hand-over too - ten words more per ray, 32 rays at most: with it on
     // they run 2.5-4 % faster than with it off, but the kernel that contains the code is 3 % slower on the 4K two-level AO pass than the
     // kernel that does not, profiles/r03_drain_merge.log - the code for it stays below, compiled out.)
-    constexpr bool kMerge = !TLAS && MODE != kModePrimary && !COUNT;
+    constexpr bool kMerge = !TLAS && MODE != kModePrimary && MODE != kModeFused && !COUNT;
     constexpr uint32_t kMergeWords = TLAS ? 31u : 21u, kMergeMax = TLAS ? 32u : 48u, kMergeClosed = 0xffffffffu;
     const bool merging = kMerge && P.merge != 0u && blockDim.x == 2u * kWave;
     bool merge_open = merging; // wave-uniform: this wave has not offered / taken / refused rays yet
@@ -612,10 +618,20 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     constexpr uint32_t kFbRefill = 16u;
     const uint32_t refill_idle = (fb_mode == 2u && P.n_frames == 1u) ? kFbRefill : P.refill_idle;
     if (P.fb && wave_global == 0u && lane == 0u) P.fb->t0 = wall_clock64(); // (about when the frame's first waves start)
-    const bool lpt_write = P.lpt_write_counts != nullptr && !fb_off;
-    if (P.lpt_read_counts && !fb_off && !P.no_order) {
-        end_a = P.lpt_read_counts[(15u - (lane >> 3)) * kLptShards + (lane & 7u)];
-        end_b = P.lpt_read_counts[(15u - ((lane + 64u) >> 3)) * kLptShards + (lane & 7u)];
+    // The order lives in one of two list sets; the word *lpt_sel (flipped by the exit wave of a frame that filed a new
+    // order) says which one is read.  The other set is empty and takes what this frame files - unless the frame finds a
+    // COMPLETE order and its views are the previous frame's (same_view): then the order is frozen - replayed as it is, no
+    // tile is timed, nothing is filed, the set stays.  Measured (profiles/r04_order_dynamics.log): an order that keeps
+    // being rewritten from each frame's completion order wanders - the shards deal a class out to eight lists and
+    // concatenate them again, a permutation with short cycles: frame times settle over 10-30 frames or alternate between
+    // two values 5 % apart - while the order filed by the very FIRST frame of a view, frozen, runs 1 % faster than the
+    // settled one from its second frame on (bistro-class frame 0.420 against 0.425 ms; the filing machinery is off too).
+    const uint32_t lpt_rd = (P.lpt_sets != nullptr && __builtin_amdgcn_readfirstlane((int)*P.lpt_sel) != 0) ? P.lpt_set_words : 0u;
+    uint32_t *const rd_set = P.lpt_sets + lpt_rd, *const wr_set = P.lpt_sets + (P.lpt_set_words - lpt_rd);
+    const uint32_t *const rd_lists = rd_set + 16u * kLptShards;
+    if (P.lpt_sets && !fb_off && !P.no_order) {
+        end_a = rd_set[(15u - (lane >> 3)) * kLptShards + (lane & 7u)];
+        end_b = rd_set[(15u - ((lane + 64u) >> 3)) * kLptShards + (lane & 7u)];
         // a list that overflowed its capacity dropped entries: fall back to the natural order
         const bool intact = __ballot(end_a > P.lpt_cap || end_b > P.lpt_cap) == 0ull;
         for (int off = 1; off < 64; off <<= 1) {
@@ -628,6 +644,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         end_b += (uint32_t)__builtin_amdgcn_readlane((int)end_a, 63);
         ordered = intact && (uint32_t)__builtin_amdgcn_readlane((int)end_b, 63) == n_chunks; // complete lists
     }
+    bool frozen = ordered && P.same_view != 0u;
+#ifdef TRX_DEV_TUNE
+    if (P.tune & 0x400u) frozen = false; // (A/B: the order is rewritten by every frame, as until round 3)
+#endif
+    const bool lpt_write = P.lpt_sets != nullptr && !fb_off && !frozen;
 
     // Chunks below this index of the heaviest-first order take their successor's ticket LATE (when the wave is idle), the
     // rest a tile ahead (hides the atomic's 1-2 us round trip, which only matters next to a tile of a few us).  Round 2
@@ -699,7 +720,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         const uint32_t kk = 2u * msb + (msb ? (wk >> (msb - 1u)) & 1u : 0u);
                         b = kk == 0u ? 0u : min(kk - 1u, 15u);
                     }
-                    const uint32_t list = b * kLptShards + (wave_global & (kLptShards - 1u)); // (one shard per wave: see flush_pending)
+                    uint32_t list = b * kLptShards + (wave_global & (kLptShards - 1u)); // (one shard per wave: see flush_pending)
+#ifdef TRX_DEV_TUNE
+                    if (P.tune & 0x200u) list = b * kLptShards; // (experiment: one list per class)
+#endif
                     // park the entry in LDS: the appends (returning atomics) are issued together,
                     // one lane each, when the buffer fills or the wave exits, off every tile's path
                     lds_pend[n_pend] = make_uint2(tile_slot, list);
@@ -708,7 +732,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             if (lpt_write) {
                 n_pend++;
                 if (n_pend == (uint32_t)kLptPend) {
-                    flush_pending_plain(P, lds_pend, n_pend, lane);
+                    flush_pending_plain(P, wr_set, lds_pend, n_pend, lane);
                     n_pend = 0;
                 }
             }
@@ -723,10 +747,14 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             }
             tile_slot = TRX_INVALID;
         }
-        if (!exhausted && n_idle >= refill_idle) {
-            const uint32_t rank = lane_rank(idle);
+        // (fused frames: lanes waiting to become AO rays are idle but take no new pixel)
+        const unsigned long long freem = kFused ? (idle & ~__ballot(pend)) : idle;
+        const uint32_t n_free = kFused ? (uint32_t)__popcll(freem) : n_idle;
+        const bool take = !exhausted && n_idle >= refill_idle;
+        if (take || (kFused && freem != idle)) {
+            const uint32_t rank = lane_rank(freem);
             uint32_t given = 0, item = TRX_INVALID;
-            while (given < n_idle) {
+            while (take && given < n_free) {
                 if (chunk_left == 0u) {
                     // take the prefetched ticket; walk to the next queue when this one is dry
                     if (!have_pending && lane == 0) pending = atomicAdd(&P.ctr->heads[my_q].taken, 1u);
@@ -784,7 +812,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                                                : j <= 64u ? (uint32_t)__builtin_amdgcn_readlane((int)end_a, (int)(j - 1u))
                                                           : (uint32_t)__builtin_amdgcn_readlane((int)end_b, (int)(j - 65u));
                         const uint32_t list = (15u - (j >> 3)) * kLptShards + (j & 7u);
-                        cur_tile = P.lpt_read_lists[(size_t)list * P.lpt_cap + (chunk - start)];
+                        cur_tile = rd_lists[(size_t)list * P.lpt_cap + (chunk - start)];
                         cur_tile = __builtin_amdgcn_readfirstlane(cur_tile);
                         if (cur_tile >= n_chunks) cur_tile = chunk; // (only a corrupted list can name such a tile: never turn it into an out-of-range pixel)
                         // the tiles that set the frame's critical path get issue priority over the
@@ -810,17 +838,19 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         s_wtri = c_wtri;
                     }
                 }
-                const uint32_t take = min(n_idle - given, chunk_left);
-                if (rank >= given && rank < given + take) {
+                const uint32_t n_take = min(n_free - given, chunk_left);
+                if (rank >= given && rank < given + n_take) {
                     item = chunk_next + (rank - given);
                     my_tile = cur_tile;
                     if (MODE == kModeAo) my_vf = cur_vf;
                 }
-                chunk_next += take;
-                chunk_left -= take;
-                given += take;
+                chunk_next += n_take;
+                chunk_left -= n_take;
+                given += n_take;
             }
-            if (!has_ray && item != TRX_INVALID) {
+            const bool conv = kFused && pend; // this lane's primary ray hit something: it becomes the pixel's AO ray
+            if (kFused && pend) item = TRX_INVALID; // (a waiting lane has no rank among the free ones)
+            if (!has_ray && (item != TRX_INVALID || conv)) {
                 bool ok = false;
                 float dx = 0.0f, dy = 0.0f, dz = 0.0f;
                 if (MODE == kModeRays) {
@@ -847,25 +877,46 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         frame_base = vf * P.frame_stride;
                     }
                     const ViewDev &view = P.views[vf];
-                    const uint32_t tile = local_tile * P.shard_count + P.shard_index;
-                    const uint32_t k = item & 63u;
-                    const uint32_t px = (tile % P.tiles_x) * 8u + (k & 7u);
-                    const uint32_t py = (tile / P.tiles_x) * 8u + (k >> 3);
+                    uint32_t px, py;
+                    if (conv) {
+                        // the pixel this lane's primary ray belonged to, back from its record index
+                        if (P.compact) {
+                            const uint32_t tile = (out_index >> 6) * P.shard_count + P.shard_index, k = out_index & 63u;
+                            px = (tile % P.tiles_x) * 8u + (k & 7u);
+                            py = (tile / P.tiles_x) * 8u + (k >> 3);
+                        } else {
+                            py = out_index / P.width;
+                            px = out_index - py * P.width;
+                        }
+                    } else {
+                        const uint32_t tile = local_tile * P.shard_count + P.shard_index;
+                        const uint32_t k = item & 63u;
+                        px = (tile % P.tiles_x) * 8u + (k & 7u);
+                        py = (tile / P.tiles_x) * 8u + (k >> 3);
+                        if (px < P.width && py < P.height) out_index = frame_base + (P.compact ? local_tile * 64u + k : py * P.width + px);
+                    }
                     if (px < P.width && py < P.height) {
-                        out_index = frame_base + (P.compact ? local_tile * 64u + k : py * P.width + px);
                         primary_dir(view, P.width, P.height, px, py, dx, dy, dz);
-                        if (MODE == kModePrimary) {
+                        if (MODE == kModePrimary || (kFused && !conv)) {
                             r.ox = view.eye[0]; r.oy = view.eye[1]; r.oz = view.eye[2];
+                            if (kFused) is_ao = false;
                             ok = true;
                         } else {
-                            const trx_hit ph = P.primary[out_index - frame_base];
+                            trx_hit ph;
+                            if (kFused) { // the primary hit is still in this lane's registers
+                                ph.t = t;
+                                ph.prim = prim;
+                                is_ao = true;
+                            } else {
+                                ph = P.primary[out_index - frame_base];
+                            }
                             if (ph.t < TRX_F32_MAX && ph.prim != TRX_INVALID) {
                                 // normal of the hit triangle, flipped toward the viewer
                                 const float4 *tp = P.tris + (size_t)ph.prim * 3;
                                 float nx = tp[0].w, ny = tp[1].w, nz = tp[2].w; // cross(e1, e2)
                                 if (TLAS && P.inst_xform) {
                                     // object-space normal -> world: transpose of world-to-object
-                                    const uint32_t pi = P.primary_inst[out_index - frame_base];
+                                    const uint32_t pi = kFused ? hit_inst : P.primary_inst[out_index - frame_base];
                                     if (pi != TRX_INVALID) {
                                         const float4 *m = P.inst_xform + (size_t)pi * 3;
                                         const float4 r0 = m[0], r1 = m[1], r2 = m[2];
@@ -901,7 +952,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                                 const float dinv = 1.0f / sqrtf(dot3(dx, dy, dz, dx, dy, dz));
                                 dx *= dinv; dy *= dinv; dz *= dinv;
                                 ok = true;
-                            } else {
+                            } else if (!kFused) { // (a fused frame writes its AO misses where the primary ray ends)
                                 trx_hit miss;
                                 miss.t = __builtin_inff();
                                 miss.prim = TRX_INVALID;
@@ -915,6 +966,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         }
                     }
                 }
+                if (kFused) pend = false;
                 if (ok) {
                     finish_ray_dir(r, dx, dy, dz);
                     lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
@@ -1231,7 +1283,24 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 trx_hit h;
                 h.t = prim != TRX_INVALID ? t : __builtin_inff();
                 h.prim = prim;
-                P.out[out_index] = h;
+                const uint32_t hi = prim != TRX_INVALID ? hit_inst : TRX_INVALID;
+                if (kFused && is_ao) {
+                    P.out_ao[out_index] = h;
+                    if (TLAS && P.out_ao_inst) P.out_ao_inst[out_index] = hi;
+                } else {
+                    P.out[out_index] = h;
+                    if (TLAS && P.out_inst) P.out_inst[out_index] = hi;
+                    if (kFused) {
+                        // the reference's pixel program goes on with the AO ray when the primary ray hit
+                        // (rt_gpu_software.hlsl:105); a miss ends the pixel: its AO record is a miss as well
+                        if (prim != TRX_INVALID) {
+                            pend = true;
+                        } else {
+                            P.out_ao[out_index] = h;
+                            if (TLAS && P.out_ao_inst) P.out_ao_inst[out_index] = TRX_INVALID;
+                        }
+                    }
+                }
             }
             if (COUNT) {
                 c_rays++;
@@ -1411,27 +1480,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     // any-hit query (intersects_bl_bvh, query.hlsl:440-445): the first accepted triangle settles it.
                     // Until a hit is accepted the walk is the closest-hit walk, so hit / no hit is the same answer.
                     if (MODE == kModeRays && P.any_hit != 0u && prim != TRX_INVALID) done = true;
-                    if (done && MODE == kModeRays && P.any_hit != 0u) {
-                        reinterpret_cast<uint8_t *>(P.out)[out_index] = prim != TRX_INVALID ? 1u : 0u;
-                        if (COUNT) {
-                            c_rays++;
-                            c_hits += prim != TRX_INVALID;
-                        }
-                        c_over += overflow;
-                        has_ray = false;
-                    } else if (done) {
-                        trx_hit h;
-                        h.t = prim != TRX_INVALID ? t : __builtin_inff();
-                        h.prim = prim;
-                        P.out[out_index] = h;
-                        if (TLAS && P.out_inst) P.out_inst[out_index] = prim != TRX_INVALID ? hit_inst : TRX_INVALID;
-                        if (COUNT) {
-                            c_rays++;
-                            c_hits += prim != TRX_INVALID;
-                        }
-                        c_over += overflow;
-                        has_ray = false;
-                    }
+                    if (done) finish_lane();
                 }
                 const uint32_t alive = (uint32_t)__popcll(__ballot(has_ray));
                 TRX_STAMP(k_pop);
@@ -1441,6 +1490,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     continue;
                 }
                 if (alive == 0u || (!exhausted && alive <= keep)) break;
+                // fused frame, queues dry: waiting lanes are turned into AO rays once enough of them have gathered
+                if (kFused && exhausted && (uint32_t)__popcll(__ballot(pend)) >= P.pend_min) break;
             }
 
         } else {
@@ -1522,12 +1573,13 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     continue;
                 }
                 if (leave) break;
+                if (kFused && exhausted && (uint32_t)__popcll(__ballot(pend)) >= P.pend_min) break;
             }
         }
     }
 
     // ---- epilogue: flags, counters, queue reset ---------------------------------------
-    if (lpt_write && n_pend) flush_pending(P, lds_pend, n_pend, lane);
+    if (lpt_write && n_pend) flush_pending(P, wr_set, lds_pend, n_pend, lane);
     if (c_over) atomicAdd(&P.ctr->overflow, c_over);
     if (COUNT) {
         atomicAdd(&P.ctr->n_rays, (unsigned long long)c_rays);
@@ -1559,8 +1611,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         if (ticket == gridDim.x * (blockDim.x / kWave) - 1u) {
             for (int q = 0; q < 8; q++) atomicExch(&P.ctr->heads[q].taken, 0u);
             // the lists this frame consumed become the next frame's (empty) write lists
-            if (P.lpt_read_counts)
-                for (uint32_t b = 0; b < 16u * kLptShards; b++) atomicExch(&P.lpt_read_counts[b], 0u);
+            // a frame that filed a new order: the set it read is emptied (it takes the next new order) and the selector flips
+            if (lpt_write) {
+                for (uint32_t b = 0; b < 16u * kLptShards; b++) atomicExch(&rd_set[b], 0u);
+                atomicExch(P.lpt_sel, lpt_rd ? 0u : 1u);
+            }
             if (P.fb) {
                 // Which schedule suits this slot's frames?  The tile-order feedback costs about 2 us a tile (timing, the list
                 // look-up behind the queue atomic, the appends) and repays that many times over where a few tiles set the
@@ -1638,6 +1693,11 @@ hipError_t launch_node(const TraceParams &p, int node, int grid, hipStream_t str
 
 template <int MODE>
 hipError_t launch_mode(const TraceParams &p, bool tlas, int node, bool count, bool pipe, int grid, hipStream_t stream) {
+    // (the one-launch frame exists for single-level scenes: the two-level walk has no registers to spare for the in-place
+    // hand-over - it spills - so trx_trace_frame_dev runs a two-level frame as two launches, api.cpp)
+    if constexpr (MODE == kModeFused) {
+        if (tlas) return hipErrorInvalidValue;
+    } else
     if (tlas) { // the two-level walk is not pipelined
         if (count) return launch_node<MODE, true, false, true>(p, node, grid, stream);
         return launch_node<MODE, true, false, false>(p, node, grid, stream);
@@ -1687,6 +1747,7 @@ hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem,
     case kModePrimary: return launch_mode<kModePrimary>(p, tlas, node, count, pipe, grid, stream);
     case kModeAo: return launch_mode<kModeAo>(p, tlas, node, count, pipe, grid, stream);
     case kModeRays: return launch_mode<kModeRays>(p, tlas, node, count, pipe, grid, stream);
+    case kModeFused: return launch_mode<kModeFused>(p, tlas, node, count, pipe, grid, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -367,6 +367,13 @@ class Scene:
         L.check(self._lib.trx_trace_ao_dev(self._h, C.byref(view), width, height, L.Shard(*shard), sem, frame, ao_eps,
                                            C.c_void_p(d_primary), C.c_void_p(d_ao), C.c_void_p(stream)))
 
+    def trace_frame_dev(self, view, width, height, d_primary, d_ao, sem=L.SEM_HLSL, frame=0, ao_eps=0.01, shard=(0, 1),
+                        stream=0, d_primary_inst=0, d_ao_inst=0):
+        """Primary + AO of one frame in ONE launch (the reference's single dispatch)."""
+        L.check(self._lib.trx_trace_frame_dev(self._h, C.byref(view), width, height, L.Shard(*shard), sem, frame, ao_eps,
+                                              C.c_void_p(d_primary), C.c_void_p(d_primary_inst), C.c_void_p(d_ao),
+                                              C.c_void_p(d_ao_inst), C.c_void_p(stream)))
+
     def trace_ao_batch_dev(self, view, width, height, d_primary, d_ao, frame_stride, n_frames, sem=L.SEM_HLSL, frame0=0,
                            ao_eps=0.01, shard=(0, 1), stream=0, d_primary_inst=0, d_ao_inst=0):
         """n_frames AO passes (seeds frame0 ..) over one view and one primary hit buffer in ONE launch."""
