@@ -934,12 +934,13 @@ def test_camera_cuts_and_schedule_modes_never_change_the_hits(trx, orc):
         lib.trx_set_kernel_variant(1 << 7)
         for k in range(3):
             assert_hits_equal(sc.trace_primary(view, w, h, sem=3)[0], want[0], "every frame a cut, frame %d" % k)
-        # the feedback tunes itself: 64 frames with it, 4 without, 4 with mid-tile refills, then the fastest mode holds -
-        # whichever mode a frame runs in, and across the switches, the hits are the oracle's
+        # the feedback tunes itself: 128 frames with it (the order of the first one replayed unchanged while the view is),
+        # 4 without, 4 with mid-tile refills, then the fastest mode holds - whichever mode a frame runs in, and across the
+        # switches, the hits are the oracle's
         lib.trx_set_kernel_variant(0)
-        for k in range(84):
+        for k in range(150):
             got = sc.trace_primary(view, w, h, sem=3)[0]
-            if k % 5 == 0 or 58 <= k < 78:
+            if k % 7 == 0 or 120 <= k < 142:
                 assert_hits_equal(got, want[0], "self-tuning feedback, frame %d" % k)
     finally:
         lib.trx_set_kernel_variant(0)

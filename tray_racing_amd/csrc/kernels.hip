@@ -1626,8 +1626,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 // mid-tile refills; the ordered mode stays unless another is 3 % faster; the winner holds for kFbHold frames,
                 // then everything is measured again.  Frame time = last wave out minus first wave in, best of a phase.
                 // (kFbOn was 24 until round 4: a bench protocol of 5 warm-up + 20 timed frames then had its last timed
-                // frames run as natural-order probes, 20 % slower each; a slot now runs ordered for its first 64 frames)
-                constexpr unsigned int kFbOn = 64u, kFbProbe = 4u, kFbHold = 1024u;
+                // frames run as natural-order probes, 20-40 % slower each; a slot now runs ordered for its first 128 frames)
+                constexpr unsigned int kFbOn = 128u, kFbProbe = 4u, kFbHold = 1024u;
                 FbState &c = *P.fb;
                 if (P.new_view) c.mode = c.frames = c.phase = c.t[0] = c.t[1] = c.t[2] = 0u; // a new view measures afresh
                 const unsigned int dur = (unsigned int)min(wall_clock64() - c.t0, 0xffffffffull);
