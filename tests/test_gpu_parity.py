@@ -59,6 +59,35 @@ def test_golden_images(trx, name):
     sc.close()
 
 
+@pytest.mark.parametrize("name,tris", [("hairball", 60000), ("bistro", 150000), ("cornell", 0)])
+def test_thin_waves_a_handful_of_rays_eight_lanes_each(trx, orc, name, tris):
+    """A dry wave that is down to eight rays or fewer gives every ray eight lanes (one child of the node each, a leaf's
+    triangles eight at a time: kernels.hip, thin_walk).  Batches of 1 ... 100 rays run (almost) wholly that way - a
+    64-ray wave goes thin once 56 rays are through - and must equal the oracle bit for bit under all eight semantics,
+    closest hit and any hit, with zero direction components, ranged rays and exact ties in the mix; the switch off
+    (variant bit 28) must give the same records."""
+    flat, _view, osc, _ov = make_scene(trx, orc, name, tris, 64, 64)
+    sc = trx.Scene(flat)
+    lib = trx.load()
+    try:
+        for n in (1, 2, 3, 7, 8, 9, 13, 64, 65, 100):
+            rays = random_rays(trx, flat, n, 1000 + n, zero_dirs=True)
+            for sem in ALL_SEMS:
+                want, _ = osc.trace_rays(rays, sem=sem)
+                got, _ = sc.trace_rays(rays, sem=sem)
+                assert_hits_equal(got, want, "%s %d rays sem %d" % (name, n, sem))
+                if sem in (0, 3):
+                    occ, _ = sc.trace_occluded(rays, sem=sem)
+                    assert (occ.astype(bool) == np.isfinite(want["t"])).all()
+                    lib.trx_set_kernel_variant(1 << 28)
+                    off, _ = sc.trace_rays(rays, sem=sem)
+                    lib.trx_set_kernel_variant(0)
+                    assert_hits_equal(off, want, "%s %d rays sem %d, thin waves off" % (name, n, sem))
+    finally:
+        lib.trx_set_kernel_variant(0)
+        sc.close()
+
+
 def test_golden_ties_and_zero_directions(trx):
     g = np.load(os.path.join(GOLDEN, "ties_rays.npz"))
     sc = trx.Scene(GoldenFlat(trx, g).flat)
@@ -862,9 +891,10 @@ def test_scheduling_variants_and_streams_do_not_change_results(trx, orc):
     sc = trx.Scene(flat)
     lib = trx.load()
     NO_LPT, ONE_Q = 1 << 20, 1 << 21
-    never_compact, compact3 = 15 << 25, 3 << 25
+    never_compact, compact3 = 7 << 25, 3 << 25
     try:
-        for variant in (0, NO_LPT, ONE_Q, NO_LPT | ONE_Q, never_compact, compact3, (1 << 22), 4 << 16, 12 << 8):
+        NO_THIN = 1 << 28   # dry waves never switch to eight lanes per ray
+        for variant in (0, NO_LPT, ONE_Q, NO_LPT | ONE_Q, never_compact, compact3, (1 << 22), 4 << 16, 12 << 8, NO_THIN, NO_THIN | (1 << 16)):
             lib.trx_set_kernel_variant(variant)
             for rep in range(6):  # > kSlots launches: every slot gets to read its own feedback
                 got, ao, _ = sc.trace_primary_ao(view, w, h, sem=3, frame=4, ao_eps=0.01)

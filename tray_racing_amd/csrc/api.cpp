@@ -424,10 +424,11 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
 #endif
     p.n_tris = (uint32_t)s->n_tris;
     p.n_nodes = (uint32_t)s->n_nodes;
-    {   // tuning: variant bits 25..28 = compaction threshold (0 = default, 15 = never)
-        const uint32_t c = (variant >> 25) & 0xfu;
+    {   // tuning: variant bits 25..27 = compaction threshold (0 = default, 7 = never); bit 28 = no thin waves (A/B runs)
+        const uint32_t c = (variant >> 25) & 0x7u;
+        p.no_thin = (variant >> 28) & 1u;
         // a lane's first kTriBatch triangles go in one per-lane round: the scans are only worth computing beyond that
-        p.tri_compact_min = c == 0u ? (uint32_t)(s->tlas ? kTriBatchTlas : kTriBatch) + 1u : c == 15u ? 0xffffffffu : c;
+        p.tri_compact_min = c == 0u ? (uint32_t)(s->tlas ? kTriBatchTlas : kTriBatch) + 1u : c == 7u ? 0xffffffffu : c;
         // tuning: variant bits 29..31 = per-lane rounds one cooperative round is worth (0 = default 2; 7 = always cooperative)
         const uint32_t r = (variant >> 29) & 0x7u;
         p.tri_coop_ratio = r == 0u ? 2u : r == 7u ? 0u : r;

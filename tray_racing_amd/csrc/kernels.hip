@@ -236,6 +236,66 @@ __device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_d
     return hit_mask;
 }
 
+// One CHILD of a node (thin waves: eight lanes share a ray, one child each).  The same IEEE operations on the same
+// operands as the per-child body of node_intersect: this lane's contribution to the hit mask, child_bits << bit_index
+// where the ray enters the child's box.  q = the child's six plane bytes {x near, x far, y near, y far, z near, z far}
+// (near = the max plane where the direction is negative), meta = its child_meta byte.
+template <int NODE>
+__device__ __forceinline__ uint32_t node_child_intersect(const Ray &r, float max_distance, const uint4 n0, uint32_t meta,
+                                                         const uint32_t q[6], const bool pow2) {
+    const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
+    const uint32_t e_imask = n0.w;
+    const float ex = __uint_as_float((e_imask & 0xffu) << 23);
+    const float ey = __uint_as_float(((e_imask >> 8) & 0xffu) << 23);
+    const float ez = __uint_as_float(((e_imask >> 16) & 0xffu) << 23);
+    float ax, ay, az, bx, by, bz;
+    if (NODE & 1) {
+        ax = ex * r.ix;
+        ay = ey * r.iy;
+        az = ez * r.iz;
+        bx = (px - r.ox) * r.ix;
+        by = (py - r.oy) * r.iy;
+        bz = (pz - r.oz) * r.iz;
+    } else if (pow2) { // (see node_intersect)
+        ax = ex * r.ix;
+        ay = ey * r.iy;
+        az = ez * r.iz;
+        bx = (px - r.ox) / r.dx;
+        by = (py - r.oy) / r.dy;
+        bz = (pz - r.oz) / r.dz;
+    } else {
+        ax = ex / r.dx;
+        ay = ey / r.dy;
+        az = ez / r.dz;
+        bx = (px - r.ox) / r.dx;
+        by = (py - r.oy) / r.dy;
+        bz = (pz - r.oz) / r.dz;
+    }
+    const f32x2 tx = plane2<NODE>(f32x2{(float)q[0], (float)q[1]}, ax, bx);
+    const f32x2 ty = plane2<NODE>(f32x2{(float)q[2], (float)q[3]}, ay, by);
+    const f32x2 tz = plane2<NODE>(f32x2{(float)q[4], (float)q[5]}, az, bz);
+    const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0001f);
+    const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), max_distance);
+    const uint32_t is_inner = (meta & (meta << 1)) & 0x10u;
+    const uint32_t bit_index = (meta ^ (is_inner ? (r.oct_inv4 & 0xffu) : 0u)) & 0x1fu;
+    const uint32_t child_bits = (meta >> 5) & 0x07u;
+    return tmin <= tmax ? child_bits << bit_index : 0u;
+}
+
+// Groups of eight lanes (thin waves): the value of a group's first lane in all eight, and the OR of all eight in the
+// first - both on the DPP network (VALU only).  Every lane of the wave must be active.
+__device__ __forceinline__ uint32_t group8_first(uint32_t v) {
+    const uint32_t q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xf, 0xf, false);  // quad_perm [0,0,0,0]
+    const uint32_t h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q, 0x114, 0xf, 0xf, false); // row_shr:4
+    return (__lane_id() & 4u) ? h : q;
+}
+__device__ __forceinline__ uint32_t group8_or_to_first(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); // row_shl:1 (0 past the row's end)
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xf, 0xf, true); // row_shl:2
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, true); // row_shl:4
+    return v; // (complete in the first lane of every group of eight; the others hold partial ORs)
+}
+
 // TriDev = {v0, e1 = v0 - v1, e2 = v2 - v0} as three float4; ng = cross(e1, e2) (query.hlsl:93) rides in the
 // w lanes, evaluated at upload exactly as written there.
 template <bool EARLY = false>
@@ -447,6 +507,8 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 __device__ __forceinline__ void flush_pending(const TraceParams &P, uint32_t *wr_set, const uint2 *lds_pend, uint32_t n, uint32_t lane) {
     __builtin_amdgcn_wave_barrier();
     uint2 e = make_uint2(0u, 0xffffffffu);
+    // (the address is formed HERE: left alone the compiler forms it at kernel start and carries - or spills - it to the epilogue)
+    asm volatile("" : "+v"(lane));
     if (lane < n) e = lds_pend[lane];
     const bool valid = e.y < 16u * kLptShards; // (a list index can only be out of range if LDS was corrupted: never turn that into a stray global atomic)
     // the lanes that share this lane's list: one ballot per class (the shard is the wave's, so the class names the list)
@@ -497,7 +559,12 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     extern __shared__ float4 lds_dyn[];
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave_in_block = threadIdx.x / kWave;
-    const uint32_t wave_global = blockIdx.x * (blockDim.x / kWave) + wave_in_block;
+    // (a macro-like lambda, recomputed at each of its few uses - start-up, a tile filed, the epilogue - rather than a value
+    // carried through the walk: the two-level AO kernel sits at the register budget)
+    auto wave_id = [&]() -> uint32_t {
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave));
+    };
+#define wave_global (wave_id())
     char *const lds_wave = reinterpret_cast<char *>(lds_dyn) + wave_in_block * kLdsBytesPerWave;
     uint2 *const lds_stack = reinterpret_cast<uint2 *>(lds_wave);                          // [kLdsStack][64]
     float4 *const lds_ray = reinterpret_cast<float4 *>(lds_wave + kLdsStack * kWave * 8);  // [64][2]: o,tmin | d
@@ -507,7 +574,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint32_t *const lds_head = lds_pref + kWave;                                           // [64] run starts of a window
     uint2 *const lds_pend = reinterpret_cast<uint2 *>(lds_head + kWave);                   // [kLptPend] {tile, list} to append
     float *const lds_dec = reinterpret_cast<float *>(lds_pend + kLptPend);                 // [6][8] decoded child planes of a wave-uniform node step
-    uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave) + lane;
+    // (wave-uniform base, so that it lives in scalar registers: the HBM part of a stack is touched on rare paths only)
+    uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave);
     const bool tie_first = P.tie_first != 0;
     if (P.wave_times && lane == 0) P.wave_times[kWaveTimeStride * wave_global] = wall_clock64();
 #ifdef TRX_TAIL_DIAG
@@ -557,6 +625,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // (Single-level walks only.  The two-level kernels were given the hand-over too - ten words more per ray, 32 rays at most: with it on
     // they run 2.5-4 % faster than with it off, but the kernel that contains the code is 3 % slower on the 4K two-level AO pass than the
     // kernel that does not, profiles/r03_drain_merge.log - the code for it stays below, compiled out.)
+    // Thin waves (incoherent single-level passes, queues dry, at most kThinMax rays left): eight lanes to a ray, see thin_walk.
+    constexpr bool kThin = !TLAS && MODE != kModePrimary && !COUNT;
+    constexpr uint32_t kThinMax = 8u;
+    bool go_thin = false; // wave-uniform
     constexpr bool kMerge = !TLAS && MODE != kModePrimary && MODE != kModeFused && !COUNT;
     constexpr uint32_t kMergeWords = TLAS ? 31u : 21u, kMergeMax = TLAS ? 32u : 48u, kMergeClosed = 0xffffffffu;
     const bool merging = kMerge && P.merge != 0u && blockDim.x == 2u * kWave;
@@ -680,6 +752,239 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 #endif
     const uint32_t tail_cut = n_chunks > tail_tiles ? n_chunks - tail_tiles : 0u;
     bool exhausted = false; // wave-uniform
+    // (defined out here, ahead of the loop, because the thin walk also runs after it: see the end of the loop)
+    // Stack push / pop.  Fast path: every lane's top is inside the LDS part, so the write needs no
+    // predication at all (an entry above a lane's top is free to clobber) and the whole push is one
+    // ds_write_b64 plus a conditional increment; lanes past the LDS part (rare: depth > kLdsStack) take the
+    // general path behind a wave-uniform branch.
+    auto stack_push = [&](uint2 e, bool cond) {
+        if (__builtin_expect(__ballot(sp >= (uint32_t)kLdsStack) != 0ull, 0)) {
+            if (cond) {
+                if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = e;
+                else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave + lane] = e;
+                else overflow = 1u;
+            }
+        } else {
+            lds_stack[sp * kWave + lane] = e;
+        }
+        sp += cond ? 1u : 0u;
+        if (COUNT) c_maxsp = max(c_maxsp, sp);
+    };
+    auto stack_pop = [&]() -> uint2 { // callers guarantee sp != 0
+        sp--;
+        if (__builtin_expect(__ballot(sp >= (uint32_t)kLdsStack) != 0ull, 0)) {
+            if (sp < (uint32_t)kLdsStack) return lds_stack[sp * kWave + lane];
+            if (sp < (uint32_t)(kLdsStack + kSpillStack)) return spill[(sp - kLdsStack) * kWave + lane];
+            return make_uint2(0u, 0u);
+        }
+        return lds_stack[sp * kWave + lane];
+    };
+
+    // Finished ray: the hit record (or the any-hit flag) leaves the lane.
+    auto finish_lane = [&]() {
+        if (MODE == kModeRays && P.any_hit != 0u) {
+            reinterpret_cast<uint8_t *>(P.out)[out_index] = prim != TRX_INVALID ? 1u : 0u;
+        } else {
+            trx_hit h;
+            h.t = prim != TRX_INVALID ? t : __builtin_inff();
+            h.prim = prim;
+            const uint32_t hi = prim != TRX_INVALID ? hit_inst : TRX_INVALID;
+            if (kFused && is_ao) {
+                P.out_ao[out_index] = h;
+                if (TLAS && P.out_ao_inst) P.out_ao_inst[out_index] = hi;
+            } else {
+                P.out[out_index] = h;
+                if (TLAS && P.out_inst) P.out_inst[out_index] = hi;
+                if (kFused) {
+                    // the reference's pixel program goes on with the AO ray when the primary ray hit
+                    // (rt_gpu_software.hlsl:105); a miss ends the pixel: its AO record is a miss as well
+                    if (prim != TRX_INVALID) {
+                        pend = true;
+                    } else {
+                        P.out_ao[out_index] = h;
+                        if (TLAS && P.out_ao_inst) P.out_ao_inst[out_index] = TRX_INVALID;
+                    }
+                }
+            }
+        }
+        if (COUNT) {
+            c_rays++;
+            c_hits += prim != TRX_INVALID;
+        }
+        c_over += overflow;
+        has_ray = false;
+    };
+
+    // Thin waves.  An incoherent pass ends when its longest rays do (two thirds of a hairball-class AO pass is its
+    // drain), and at the end those rays sit one or two to a wave: the wave then issues alone on its SIMD, one
+    // instruction every four to five cycles whatever the instruction is, so a ray's trip costs its INSTRUCTION COUNT -
+    // 213 vector instructions for the node test of one lane while 63 lanes idle.  Once a dry wave is down to kThinMax
+    // rays they are moved to lanes 0, 8, 16 ... and every ray gets eight lanes: lane j of a group tests child j of the
+    // node (its six plane bytes, loaded by address; the same IEEE operations as the per-lane test: node_child_intersect),
+    // the eight contributions are ORed on the DPP network, and a leaf's triangles are tested eight at a time and folded
+    // into the ray's 64-bit {t, sequence} key with the same LDS atomic min as the cooperative rounds - node order,
+    // triangle order, tie rule and every t are those of the one-lane walk (tested bit for bit).  A trip is about a
+    // third of the instructions.  The walk is the plain one, rotated like the pipelined one: triangles of the node
+    // tested last, then the next node.
+    // (wave-uniform) may this wave go thin now?  Queues dry, a handful of rays, every stack inside its LDS part, no
+    // hand-over with the other wave of the workgroup pending, no lane of a fused frame waiting to become an AO ray.
+    auto thin_now = [&](uint32_t alive) -> bool {
+        return exhausted && alive != 0u && alive <= kThinMax && P.no_thin == 0u && !(kMerge && merge_open) &&
+               __ballot(has_ray && sp > (uint32_t)kLdsStack) == 0ull && !(kFused && __ballot(pend) != 0ull);
+    };
+    auto thin_walk = [&]() {
+        const uint32_t sub = lane & 7u, first = lane & ~7u;
+        {   // ---- move ray k (in lane order) to lane 8 k, stack column and all; give its seven helpers the ray
+            const unsigned long long act = __ballot(has_ray);
+            unsigned long long m = act;
+            for (uint32_t i = 0; i < (lane >> 3); i++) m &= m - 1ull; // (at most seven rounds; the group's rank picks its ray)
+            const bool filled = m != 0ull;
+            const int src = filled ? __ffsll((long long)m) - 1 : (int)lane;
+            const bool owner = filled && sub == 0u;
+            r.ox = __shfl(r.ox, src); r.oy = __shfl(r.oy, src); r.oz = __shfl(r.oz, src);
+            r.dx = __shfl(r.dx, src); r.dy = __shfl(r.dy, src); r.dz = __shfl(r.dz, src);
+            r.ix = __shfl(r.ix, src); r.iy = __shfl(r.iy, src); r.iz = __shfl(r.iz, src);
+            r.tmin = __shfl(r.tmin, src);
+            r.oct_inv4 = (uint32_t)__shfl((int)r.oct_inv4, src);
+            t = __shfl(t, src);
+            prim = (uint32_t)__shfl((int)prim, src);
+            out_index = (uint32_t)__shfl((int)out_index, src);
+            const uint32_t age = (uint32_t)__shfl((int)(trip - steps), src);
+            steps = trip - age;
+            cur.x = (uint32_t)__shfl((int)cur.x, src); cur.y = (uint32_t)__shfl((int)cur.y, src);
+            ptri.x = (uint32_t)__shfl((int)ptri.x, src); ptri.y = (uint32_t)__shfl((int)ptri.y, src);
+            overflow = (uint32_t)__shfl((int)overflow, src);
+            if (kFused) is_ao = __shfl(is_ao ? 1 : 0, src) != 0;
+            const uint32_t sp_src = (uint32_t)__shfl((int)sp, src);
+            uint32_t sp_max = owner ? sp_src : 0u;
+            for (int off = 32; off > 0; off >>= 1) sp_max = max(sp_max, (uint32_t)__shfl_xor((int)sp_max, off));
+            for (uint32_t k = 0; k < sp_max; k++) { // (entries beyond a ray's own top are copied too: harmless)
+                const uint2 e = lds_stack[k * kWave + (uint32_t)src];
+                __builtin_amdgcn_wave_barrier();
+                if (owner) lds_stack[k * kWave + lane] = e;
+                __builtin_amdgcn_wave_barrier();
+            }
+            sp = owner ? sp_src : 0u;
+            has_ray = owner;
+            if (!owner) {
+                ptri = make_uint2(0u, 0u);
+                cur = make_uint2(0u, 0u);
+                r.oct_inv4 &= 0x7fffffffu | (filled ? 0x80000000u : 0u); // (a group without a ray must not veto the exact-reciprocal shortcut)
+            }
+            if (owner) {
+                lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+                lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+            }
+            fetched = false;
+            __builtin_amdgcn_s_setprio(3);
+        }
+        unsigned long long *const lds_key = reinterpret_cast<unsigned long long *>(lds_res);
+        for (;;) {
+            trip++;
+            // ---- triangles of the node tested in the previous trip, eight at a time
+            const uint32_t gx = group8_first(ptri.x), gy = group8_first(ptri.y);
+            const uint32_t cnt = (uint32_t)__popc(gy);
+            if (__ballot(cnt != 0u) != 0ull) {
+                const uint32_t init_lo = tie_first ? 0u : 0xffu;
+                if (sub == 0u) lds_res[lane] = make_uint2(init_lo, ordered_bits(t + 0.0f));
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t j = sub; __ballot(j < cnt) != 0ull; j += 8u) {
+                    if (j < cnt) {
+                        const uint32_t local = select_from_top(gy, j);
+                        const float4 *tp = P.tris + (size_t)(gx + local) * 3;
+                        float4 a = tp[0], b = tp[1], c4 = tp[2];
+                        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c4.x), "+v"(c4.y), "+v"(c4.z), "+v"(c4.w));
+                        float tt = TRX_F32_MAX; // the tie test against the ray's t is the atomic min (see the cooperative rounds)
+                        if (intersect_tri(r, a, b, c4, tt, false)) {
+                            const uint32_t neg_zero = __float_as_uint(tt) == 0x80000000u ? 1u : 0u;
+                            const uint32_t lo = ((tie_first ? 31u - local : local) << 1) | neg_zero;
+                            atomicMin(&lds_key[first], ((unsigned long long)ordered_bits(tt + 0.0f) << 32) | lo);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (sub == 0u && cnt != 0u) {
+                    const uint2 won = lds_res[lane];
+                    if (won.x != init_lo) {
+                        const uint32_t local = tie_first ? 31u - (won.x >> 1) : (won.x >> 1);
+                        t = (won.x & 1u) ? -0.0f : __uint_as_float(unordered_bits(won.y));
+                        prim = ptri.x + local;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            ptri = make_uint2(0u, 0u);
+            // ---- the end of a ray: nothing left to visit and its last triangles are in
+            if (has_ray) {
+                bool done = (cur.y & 0xff000000u) == 0u;
+                if (MODE == kModeRays && P.any_hit != 0u && prim != TRX_INVALID) done = true;
+                if (__builtin_expect((trip & 1023u) == 0u, 0)) { // step cap: every wave reaches an exit
+                    if (trip - steps > kMaxSteps) {
+                        overflow = 1u;
+                        done = true;
+                    }
+                }
+                if (done) finish_lane();
+            }
+            // (every ray left holds a node group and no pending triangles: the state the other walks expect.  A fused
+            // frame leaves when a primary ray has hit: its AO ray is set up at the refill point.)
+            if (__ballot(has_ray) == 0ull || (kFused && __ballot(pend) != 0ull)) break;
+            // ---- the ray's next node
+            uint32_t node_index = 0u;
+            const bool stepping = has_ray;
+            if (stepping) {
+                const uint32_t hits_imask = cur.y;
+                const uint32_t child_bit = 31u - (uint32_t)__builtin_clz(hits_imask);
+                cur.y &= ~(1u << child_bit);
+                const uint32_t slot = (child_bit - 24u) ^ (r.oct_inv4 & 0xffu);
+                node_index = cur.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
+                stack_push(cur, (cur.y & 0xff000000u) != 0u);
+            }
+            // ---- node test, one child per lane
+            const unsigned long long step_mask = __ballot(stepping);
+            const bool gstep = ((step_mask >> first) & 1ull) != 0ull;
+            const uint32_t gnode = group8_first(node_index);
+            const float gt = __uint_as_float(group8_first(__float_as_uint(t)));
+            const bool pow2 = (NODE & 1) ? false : pow2_exact(P, r, gstep);
+            uint32_t contrib = 0u;
+            uint4 n0 = make_uint4(0u, 0u, 0u, 0u), n1 = n0;
+            if (gstep) {
+                const uint4 *np = P.nodes + (size_t)gnode * 5;
+                const uint8_t *nb = reinterpret_cast<const uint8_t *>(np) + sub;
+                n0 = np[0];
+                n1 = np[1];
+                // plane bytes by address: min planes at +32 / +48 / +64, max planes eight bytes on; near = max where d < 0
+                const uint32_t xn = r.dx < 0.0f ? 8u : 0u, yn = r.dy < 0.0f ? 8u : 0u, zn = r.dz < 0.0f ? 8u : 0u;
+                uint32_t q[6];
+                q[0] = nb[32u + xn]; q[1] = nb[32u + (xn ^ 8u)];
+                q[2] = nb[48u + yn]; q[3] = nb[48u + (yn ^ 8u)];
+                q[4] = nb[64u + zn]; q[5] = nb[64u + (zn ^ 8u)];
+                const uint32_t meta = ((sub < 4u ? n1.z : n1.w) >> (8u * (sub & 3u))) & 0xffu;
+                contrib = node_child_intersect<NODE>(r, gt, n0, meta, q, pow2);
+            }
+            const uint32_t hitmask = group8_or_to_first(contrib);
+            if (stepping) {
+                cur.x = n1.x;
+                ptri.x = n1.y;
+                cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                ptri.y = hitmask & 0x00ffffffu;
+                if ((cur.y & 0xff000000u) == 0u && sp != 0u) {
+                    cur = stack_pop();
+                    if (__builtin_expect(overflow != 0u, 0)) cur = make_uint2(0u, 0u); // past the last entry: finish
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (PIPE) { // (no node was in flight all the while: tell the register allocator so, it cannot see through `fetched`)
+            const float4 u0 = unspecified4(), u1 = unspecified4(), u2 = unspecified4(), u3 = unspecified4(), u4 = unspecified4();
+            pn0 = make_uint4(__float_as_uint(u0.x), __float_as_uint(u0.y), __float_as_uint(u0.z), __float_as_uint(u0.w));
+            pn1 = make_uint4(__float_as_uint(u1.x), __float_as_uint(u1.y), __float_as_uint(u1.z), __float_as_uint(u1.w));
+            pn2 = make_uint4(__float_as_uint(u2.x), __float_as_uint(u2.y), __float_as_uint(u2.z), __float_as_uint(u2.w));
+            pn3 = make_uint4(__float_as_uint(u3.x), __float_as_uint(u3.y), __float_as_uint(u3.z), __float_as_uint(u3.w));
+            pn4 = make_uint4(__float_as_uint(u4.x), __float_as_uint(u4.y), __float_as_uint(u4.z), __float_as_uint(u4.w));
+        }
+    };
+
     for (;;) {
         TRX_STAMP(k_pop);
         // ---- refill idle lanes from the queues --------------------------------------------
@@ -1011,33 +1316,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         // The loop is wave-uniform (every lane iterates, work is predicated on `act`), so that the
         // triangle phase can use all 64 lanes whichever lanes own the triangles.
         const uint32_t keep = kWave - refill_idle; // leave when this few lanes remain
-        // Stack push / pop.  Fast path: every lane's top is inside the LDS part, so the write needs no
-        // predication at all (an entry above a lane's top is free to clobber) and the whole push is one
-        // ds_write_b64 plus a conditional increment; lanes past the LDS part (rare: depth > kLdsStack) take the
-        // general path behind a wave-uniform branch.
-        auto stack_push = [&](uint2 e, bool cond) {
-            if (__builtin_expect(__ballot(sp >= (uint32_t)kLdsStack) != 0ull, 0)) {
-                if (cond) {
-                    if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = e;
-                    else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave] = e;
-                    else overflow = 1u;
-                }
-            } else {
-                lds_stack[sp * kWave + lane] = e;
-            }
-            sp += cond ? 1u : 0u;
-            if (COUNT) c_maxsp = max(c_maxsp, sp);
-        };
-        auto stack_pop = [&]() -> uint2 { // callers guarantee sp != 0
-            sp--;
-            if (__builtin_expect(__ballot(sp >= (uint32_t)kLdsStack) != 0ull, 0)) {
-                if (sp < (uint32_t)kLdsStack) return lds_stack[sp * kWave + lane];
-                if (sp < (uint32_t)(kLdsStack + kSpillStack)) return spill[(sp - kLdsStack) * kWave];
-                return make_uint2(0u, 0u);
-            }
-            return lds_stack[sp * kWave + lane];
-        };
-
         // ---- triangle phase ---------------------------------------------------------
             // Each lane owns cnt triangle tests (the hit leaves of its node, highest bit first).
             // Few per lane: every owner tests its own, one round per triangle.  Otherwise the
@@ -1254,11 +1532,23 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         // publishes its idle lanes and looks for an offer.
         auto merge_step = [&](uint32_t alive) {
             if (wave_in_block == 1u) {
-                if (alive != 0u && alive <= kMergeMax) (void)merge_offer(alive);
+                // (a wave that is down to a handful of rays finishes them itself, eight lanes to a ray - thin_walk - rather
+                // than hand them to a wave that steps them one lane each)
+                if (kThin && alive <= kThinMax && !P.no_thin) merge_open = false;
+                else if (alive != 0u && alive <= kMergeMax) (void)merge_offer(alive);
             } else {
                 if (lane == 0u) *reinterpret_cast<volatile uint32_t *>(&merge_ctl[1]) = (uint32_t)kWave - alive;
                 const uint32_t n = *reinterpret_cast<volatile uint32_t *>(&merge_ctl[0]);
-                if (n != 0u) merge_take(n);
+                if (n != 0u) {
+                    merge_take(n);
+                } else if (kThin && alive <= kThinMax && !P.no_thin) {
+                    // ... and the first wave, down to a handful, closes the door - unless an offer has just landed
+                    uint32_t old = 0u;
+                    if (lane == 0u) old = atomicCAS(&merge_ctl[0], 0u, kMergeClosed);
+                    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+                    if (old == 0u) merge_open = false;
+                    else merge_take(old);
+                }
             }
         };
 
@@ -1273,41 +1563,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             if (__ballot(age >= 2u * kOldRay) != 0ull) __builtin_amdgcn_s_setprio(3);
             else if (__ballot(age >= kOldRay) != 0ull) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(0);
-        };
-
-        // Finished ray: the hit record (or the any-hit flag) leaves the lane.
-        auto finish_lane = [&]() {
-            if (MODE == kModeRays && P.any_hit != 0u) {
-                reinterpret_cast<uint8_t *>(P.out)[out_index] = prim != TRX_INVALID ? 1u : 0u;
-            } else {
-                trx_hit h;
-                h.t = prim != TRX_INVALID ? t : __builtin_inff();
-                h.prim = prim;
-                const uint32_t hi = prim != TRX_INVALID ? hit_inst : TRX_INVALID;
-                if (kFused && is_ao) {
-                    P.out_ao[out_index] = h;
-                    if (TLAS && P.out_ao_inst) P.out_ao_inst[out_index] = hi;
-                } else {
-                    P.out[out_index] = h;
-                    if (TLAS && P.out_inst) P.out_inst[out_index] = hi;
-                    if (kFused) {
-                        // the reference's pixel program goes on with the AO ray when the primary ray hit
-                        // (rt_gpu_software.hlsl:105); a miss ends the pixel: its AO record is a miss as well
-                        if (prim != TRX_INVALID) {
-                            pend = true;
-                        } else {
-                            P.out_ao[out_index] = h;
-                            if (TLAS && P.out_ao_inst) P.out_ao_inst[out_index] = TRX_INVALID;
-                        }
-                    }
-                }
-            }
-            if (COUNT) {
-                c_rays++;
-                c_hits += prim != TRX_INVALID;
-            }
-            c_over += overflow;
-            has_ray = false;
         };
 
         if (kMerge && need_take != 0u) {
@@ -1492,6 +1747,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 if (alive == 0u || (!exhausted && alive <= keep)) break;
                 // fused frame, queues dry: waiting lanes are turned into AO rays once enough of them have gathered
                 if (kFused && exhausted && (uint32_t)__popcll(__ballot(pend)) >= P.pend_min) break;
+                if (kThin && thin_now(alive)) {
+                    go_thin = true;
+                    break;
+                }
             }
 
         } else {
@@ -1574,9 +1833,21 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 }
                 if (leave) break;
                 if (kFused && exhausted && (uint32_t)__popcll(__ballot(pend)) >= P.pend_min) break;
+                if (kThin && thin_now(alive)) {
+                    go_thin = true;
+                    break;
+                }
             }
         }
+        if (kThin && go_thin) {
+            // (nothing comes back from the thin walk of a dry wave - except a fused frame's lane that waits to become an AO
+            // ray - so it runs AFTER the loop, where the registers the loop carries are dead)
+            if (!kFused) break;
+            go_thin = false;
+            thin_walk(); // returns with no ray left, or with a lane waiting to become an AO ray
+        }
     }
+    if (kThin && !kFused && go_thin) thin_walk(); // returns with no ray left
 
     // ---- epilogue: flags, counters, queue reset ---------------------------------------
     if (lpt_write && n_pend) flush_pending(P, wr_set, lds_pend, n_pend, lane);
@@ -1672,6 +1943,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 }
 
 
+#undef wave_global
+
 template <int MODE, bool TLAS, int NODE, bool PIPE, bool COUNT>
 hipError_t launch_one(const TraceParams &p, int grid, hipStream_t stream) {
     // grid = total waves; p.waves_per_block waves share a workgroup (and nothing else)
@@ -1702,7 +1975,9 @@ hipError_t launch_mode(const TraceParams &p, bool tlas, int node, bool count, bo
         if (count) return launch_node<MODE, true, false, true>(p, node, grid, stream);
         return launch_node<MODE, true, false, false>(p, node, grid, stream);
     }
-    if constexpr (MODE != kModePrimary) { // coherent primary rays do not gain from the pipelined walk
+    // (coherent primary rays do not gain from the pipelined walk; the one-launch frame with it and
+    // the thin-wave code spills)
+    if constexpr (MODE != kModePrimary && MODE != kModeFused) {
         if (pipe) {
             if (count) return launch_node<MODE, false, true, true>(p, node, grid, stream);
             return launch_node<MODE, false, true, false>(p, node, grid, stream);
