@@ -879,11 +879,60 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             __builtin_amdgcn_s_setprio(3);
         }
         unsigned long long *const lds_key = reinterpret_cast<unsigned long long *>(lds_res);
+        // The trip is rotated like the pipelined walk's, and one step further: (1) the ray's next node is chosen and its
+        // bytes are requested, (2) the triangles of the node tested in the PREVIOUS trip are tested - the first eight
+        // records were requested at the end of that trip - (3) a ray with no node left is finished, (4) the requested node
+        // is tested with the t those triangles left, (5) the first eight triangle records of the new leaf hits are
+        // requested.  A thin wave's time is its rays' dependent round trips to memory: two per trip run in parallel now.
+        uint4 n0 = make_uint4(0u, 0u, 0u, 0u), n1 = n0;
+        uint32_t q0 = 0u, q1 = 0u, q2 = 0u, q3 = 0u, q4 = 0u, q5 = 0u;
+        float4 ta = unspecified4(), tb = unspecified4(), tc = unspecified4();
+        uint32_t gx = 0u, gy = 0u, cnt = 0u;
+        // (the one-launch frame comes back from here into its loop, whose registers stay live meanwhile: it does without
+        // the early triangle request, twelve registers carried from trip to trip)
+        constexpr bool kPre = !kFused;
+        auto request_triangles = [&]() { // (5): the group's pending triangle group, and this lane's record of its first eight
+            gx = group8_first(ptri.x);
+            gy = group8_first(ptri.y);
+            cnt = (uint32_t)__popc(gy);
+            if (kPre && sub < cnt) {
+                const float4 *tp = P.tris + (size_t)(gx + select_from_top(gy, sub)) * 3;
+                ta = tp[0];
+                tb = tp[1];
+                tc = tp[2];
+                asm volatile("" : "+v"(ta.x), "+v"(ta.y), "+v"(ta.z), "+v"(ta.w), "+v"(tb.x), "+v"(tb.y), "+v"(tb.z), "+v"(tb.w), "+v"(tc.x), "+v"(tc.y), "+v"(tc.z), "+v"(tc.w));
+            }
+        };
+        request_triangles(); // (a wave that comes from the pipelined walk brings pending triangle groups)
+        bool leaving = false; // wave-uniform (fused frames): a primary ray has hit, what is in flight is finished, then out
         for (;;) {
             trip++;
-            // ---- triangles of the node tested in the previous trip, eight at a time
-            const uint32_t gx = group8_first(ptri.x), gy = group8_first(ptri.y);
-            const uint32_t cnt = (uint32_t)__popc(gy);
+            // ---- (1) the next node of every ray that holds a node group; its bytes are requested
+            const bool had_group = has_ray && (cur.y & 0xff000000u) != 0u;
+            const bool stepping = had_group && !leaving;
+            uint32_t node_index = 0u;
+            if (stepping) {
+                const uint32_t hits_imask = cur.y;
+                const uint32_t child_bit = 31u - (uint32_t)__builtin_clz(hits_imask);
+                cur.y &= ~(1u << child_bit);
+                const uint32_t slot = (child_bit - 24u) ^ (r.oct_inv4 & 0xffu);
+                node_index = cur.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
+                stack_push(cur, (cur.y & 0xff000000u) != 0u);
+            }
+            const bool gstep = ((__ballot(stepping) >> first) & 1ull) != 0ull;
+            if (gstep) {
+                const uint4 *np = P.nodes + (size_t)group8_first(node_index) * 5;
+                const uint8_t *nb = reinterpret_cast<const uint8_t *>(np) + sub;
+                n0 = np[0];
+                n1 = np[1];
+                // plane bytes by address: min planes at +32 / +48 / +64, max planes eight bytes on; near = max where d < 0
+                const uint32_t xn = r.dx < 0.0f ? 8u : 0u, yn = r.dy < 0.0f ? 8u : 0u, zn = r.dz < 0.0f ? 8u : 0u;
+                q0 = nb[32u + xn]; q1 = nb[32u + (xn ^ 8u)];
+                q2 = nb[48u + yn]; q3 = nb[48u + (yn ^ 8u)];
+                q4 = nb[64u + zn]; q5 = nb[64u + (zn ^ 8u)];
+                asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z), "+v"(n1.w), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5));
+            }
+            // ---- (2) triangles of the node tested in the previous trip, eight at a time; the first eight are here already
             if (__ballot(cnt != 0u) != 0ull) {
                 const uint32_t init_lo = tie_first ? 0u : 0xffu;
                 if (sub == 0u) lds_res[lane] = make_uint2(init_lo, ordered_bits(t + 0.0f));
@@ -891,11 +940,15 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 for (uint32_t j = sub; __ballot(j < cnt) != 0ull; j += 8u) {
                     if (j < cnt) {
                         const uint32_t local = select_from_top(gy, j);
-                        const float4 *tp = P.tris + (size_t)(gx + local) * 3;
-                        float4 a = tp[0], b = tp[1], c4 = tp[2];
-                        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c4.x), "+v"(c4.y), "+v"(c4.z), "+v"(c4.w));
+                        if (!kPre || j >= 8u) {
+                            const float4 *tp = P.tris + (size_t)(gx + local) * 3;
+                            ta = tp[0];
+                            tb = tp[1];
+                            tc = tp[2];
+                            asm volatile("" : "+v"(ta.x), "+v"(ta.y), "+v"(ta.z), "+v"(ta.w), "+v"(tb.x), "+v"(tb.y), "+v"(tb.z), "+v"(tb.w), "+v"(tc.x), "+v"(tc.y), "+v"(tc.z), "+v"(tc.w));
+                        }
                         float tt = TRX_F32_MAX; // the tie test against the ray's t is the atomic min (see the cooperative rounds)
-                        if (intersect_tri(r, a, b, c4, tt, false)) {
+                        if (intersect_tri(r, ta, tb, tc, tt, false)) {
                             const uint32_t neg_zero = __float_as_uint(tt) == 0x80000000u ? 1u : 0u;
                             const uint32_t lo = ((tie_first ? 31u - local : local) << 1) | neg_zero;
                             atomicMin(&lds_key[first], ((unsigned long long)ordered_bits(tt + 0.0f) << 32) | lo);
@@ -914,10 +967,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 __builtin_amdgcn_wave_barrier();
             }
             ptri = make_uint2(0u, 0u);
-            // ---- the end of a ray: nothing left to visit and its last triangles are in
+            // ---- (3) the end of a ray: it had no node left to visit and its last triangles are in
             if (has_ray) {
-                bool done = (cur.y & 0xff000000u) == 0u;
-                if (MODE == kModeRays && P.any_hit != 0u && prim != TRX_INVALID) done = true;
+                bool done = !had_group;
+                if (MODE == kModeRays && P.any_hit != 0u && prim != TRX_INVALID) done = true; // (a node in flight is simply not looked at)
                 if (__builtin_expect((trip & 1023u) == 0u, 0)) { // step cap: every wave reaches an exit
                     if (trip - steps > kMaxSteps) {
                         overflow = 1u;
@@ -926,44 +979,24 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 }
                 if (done) finish_lane();
             }
-            // (every ray left holds a node group and no pending triangles: the state the other walks expect.  A fused
-            // frame leaves when a primary ray has hit: its AO ray is set up at the refill point.)
-            if (__ballot(has_ray) == 0ull || (kFused && __ballot(pend) != 0ull)) break;
-            // ---- the ray's next node
-            uint32_t node_index = 0u;
-            const bool stepping = has_ray;
-            if (stepping) {
-                const uint32_t hits_imask = cur.y;
-                const uint32_t child_bit = 31u - (uint32_t)__builtin_clz(hits_imask);
-                cur.y &= ~(1u << child_bit);
-                const uint32_t slot = (child_bit - 24u) ^ (r.oct_inv4 & 0xffu);
-                node_index = cur.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
-                stack_push(cur, (cur.y & 0xff000000u) != 0u);
-            }
-            // ---- node test, one child per lane
-            const unsigned long long step_mask = __ballot(stepping);
-            const bool gstep = ((step_mask >> first) & 1ull) != 0ull;
-            const uint32_t gnode = group8_first(node_index);
+            if (__ballot(has_ray) == 0ull) break;
+            // (fused frames: a primary ray has hit and waits to become an AO ray at the refill point.  What is in flight is
+            // finished first - this trip's node tests, then, in one more trip that chooses no node, their triangles - so
+            // that every ray left holds a node group and nothing pending: the state the other walks expect.)
+            if (leaving) break;
+            if (kFused && __ballot(pend) != 0ull) leaving = true;
+            // ---- (4) node test, one child per lane, for the rays still there
+            const bool galive = ((__ballot(has_ray) >> first) & 1ull) != 0ull;
             const float gt = __uint_as_float(group8_first(__float_as_uint(t)));
-            const bool pow2 = (NODE & 1) ? false : pow2_exact(P, r, gstep);
+            const bool pow2 = (NODE & 1) ? false : pow2_exact(P, r, gstep && galive);
             uint32_t contrib = 0u;
-            uint4 n0 = make_uint4(0u, 0u, 0u, 0u), n1 = n0;
-            if (gstep) {
-                const uint4 *np = P.nodes + (size_t)gnode * 5;
-                const uint8_t *nb = reinterpret_cast<const uint8_t *>(np) + sub;
-                n0 = np[0];
-                n1 = np[1];
-                // plane bytes by address: min planes at +32 / +48 / +64, max planes eight bytes on; near = max where d < 0
-                const uint32_t xn = r.dx < 0.0f ? 8u : 0u, yn = r.dy < 0.0f ? 8u : 0u, zn = r.dz < 0.0f ? 8u : 0u;
-                uint32_t q[6];
-                q[0] = nb[32u + xn]; q[1] = nb[32u + (xn ^ 8u)];
-                q[2] = nb[48u + yn]; q[3] = nb[48u + (yn ^ 8u)];
-                q[4] = nb[64u + zn]; q[5] = nb[64u + (zn ^ 8u)];
+            if (gstep && galive) {
                 const uint32_t meta = ((sub < 4u ? n1.z : n1.w) >> (8u * (sub & 3u))) & 0xffu;
+                const uint32_t q[6] = {q0, q1, q2, q3, q4, q5};
                 contrib = node_child_intersect<NODE>(r, gt, n0, meta, q, pow2);
             }
             const uint32_t hitmask = group8_or_to_first(contrib);
-            if (stepping) {
+            if (stepping && has_ray) {
                 cur.x = n1.x;
                 ptri.x = n1.y;
                 cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -973,6 +1006,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     if (__builtin_expect(overflow != 0u, 0)) cur = make_uint2(0u, 0u); // past the last entry: finish
                 }
             }
+            // ---- (5)
+            request_triangles();
         }
         __builtin_amdgcn_s_setprio(0);
         if (PIPE) { // (no node was in flight all the while: tell the register allocator so, it cannot see through `fetched`)
