@@ -40,6 +40,23 @@ for name in sys.argv[1:] or ["hairball", "bistro", "kitchen"]:
         "frame, one launch": lambda i: sc.trace_frame_dev(view, w, h, prim.data_ptr(), ao.data_ptr(), sem=3, frame=i % 4, ao_eps=0.01),
         "2 M random rays": lambda i: sc.trace_rays_dev(d_rays.data_ptr(), rays.size, d_hits.data_ptr(), sem=3),
     }
+    sweep = [int(x) for x in os.environ.get("THIN_SWEEP", "").split(",") if x]   # development build: TRX_THIN_MAX values
+    if sweep:
+        for label, fn in passes.items():
+            ts = {v: [] for v in sweep}
+            for i in range(3 + len(sweep) * 6):
+                v = sweep[i % len(sweep)]
+                os.environ["TRX_THIN_MAX"] = str(v)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn(i)
+                b.record()
+                torch.cuda.synchronize()
+                if i >= 3:
+                    ts[v].append(a.elapsed_time(b))
+            print("%-9s %-20s %s" % (name, label, " | ".join("thin_max %2d: %.3f min %.3f mean" % (v, min(ts[v]), sum(ts[v]) / len(ts[v])) for v in sweep)), flush=True)
+        sc.close()
+        continue
     for label, fn in passes.items():
         ts = {0: [], NO_THIN: []}
         for i in range(3 + 2 * 8):

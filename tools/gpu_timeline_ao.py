@@ -34,4 +34,16 @@ for name in sys.argv[1:]:
         print("   trips per wave: mean %.0f -> %.2f us per trip over the wave's life; in the tail (after dry) the longest-living waves: %s" % (
             trips.mean(), ((end - start) / np.maximum(trips, 1)).mean(),
             ["%.0f us, %d rays, oldest %d" % (left[i], alive[i], age[i]) for i in np.argsort(-left)[:6]]))
+        if r[:, 2].any():  # thin waves (round 4): when a wave gave its last rays eight lanes each
+            thin = r[:, 2] != 0
+            tt, rays_t, trips_t = (r[thin, 2] - t0) / 100.0, r[thin, 3], r[thin, 4]
+            dur = end[thin] - tt
+            thin_trips = np.maximum(trips[thin] - trips_t, 1)
+            print("   thin: %d of %d waves | entered at p10 %.0f p50 %.0f p90 %.0f us with %.1f rays (mean) after %.0f trips | thin phase lasts "
+                  "p50 %.0f p90 %.0f max %.0f us = %.0f trips (mean), %.2f us per trip (normal phase of the same waves: %.2f us per trip)" % (
+                      thin.sum(), len(thin), np.percentile(tt, 10), np.percentile(tt, 50), np.percentile(tt, 90), rays_t.mean(), trips_t.mean(),
+                      np.percentile(dur, 50), np.percentile(dur, 90), dur.max(), thin_trips.mean(), (dur / thin_trips).mean(),
+                      ((tt - start[thin]) / np.maximum(trips_t, 1)).mean()))
+            longest = np.argsort(-dur)[:6]
+            print("   longest thin phases: %s" % ["%.0f us, %d trips, entered with %d rays" % (dur[i], thin_trips[i], rays_t[i]) for i in longest])
     sc.close()

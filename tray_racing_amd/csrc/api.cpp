@@ -426,7 +426,13 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.n_nodes = (uint32_t)s->n_nodes;
     {   // tuning: variant bits 25..27 = compaction threshold (0 = default, 7 = never); bit 28 = no thin waves (A/B runs)
         const uint32_t c = (variant >> 25) & 0x7u;
-        p.no_thin = (variant >> 28) & 1u;
+        p.thin_max = ((variant >> 28) & 1u) ? 0u : 32u;
+#ifdef TRX_DEV_TUNE
+        {   // (development builds: TRX_THIN_MAX = 0 / 8 / 16 / 32)
+            const char *tm = getenv("TRX_THIN_MAX");
+            if (tm) p.thin_max = (uint32_t)strtoul(tm, nullptr, 0);
+        }
+#endif
         // a lane's first kTriBatch triangles go in one per-lane round: the scans are only worth computing beyond that
         p.tri_compact_min = c == 0u ? (uint32_t)(s->tlas ? kTriBatchTlas : kTriBatch) + 1u : c == 7u ? 0xffffffffu : c;
         // tuning: variant bits 29..31 = per-lane rounds one cooperative round is worth (0 = default 2; 7 = always cooperative)

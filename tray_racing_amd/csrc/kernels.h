@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "../../include/trx.h"
 
@@ -92,7 +93,7 @@ struct TraceParams {
     trx_hit *out;
     trx_hit *out_ao;        // kModeFused: the AO pass's records (out = the primary pass's)
     uint32_t *out_ao_inst;  // ... and their instance ids (TLAS scenes), or null
-    uint32_t no_thin;       // tuning / A-B: dry waves never switch to eight lanes per ray (kernels.hip, thin_walk)
+    uint32_t thin_max;      // a dry wave with this many rays or fewer gives every ray several lanes (kernels.hip, thin_walk); 0 = never
     uint32_t pend_min;      // kModeFused, queues dry: convert finished primary rays to AO rays once this many lanes wait
     // instance transforms (TLAS scenes; all null = the reference's identity behaviour): world-to-object rows
     // {m0 m1 m2 t} x 3 per TLAS primitive; the instance each hit was found in, per record like `out`; the

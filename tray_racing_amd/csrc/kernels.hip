@@ -29,6 +29,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef TRX_THIN_LEVELS
+#define TRX_THIN_LEVELS 3 // lanes-per-ray steps of the thin walk: 1 = eight only, 2 = four and eight, 3 = two, four and eight
+#endif
+
 // TRX_STAMPS (diagnostic builds only): per-wave cycle accounting of the loop's phases.  Every stamp
 // drains the memory counters first, so a phase owns the latency of what it issued.
 #ifdef TRX_STAMPS
@@ -236,13 +240,14 @@ __device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_d
     return hit_mask;
 }
 
-// One CHILD of a node (thin waves: eight lanes share a ray, one child each).  The same IEEE operations on the same
+// C consecutive CHILDREN of a node (thin waves: L = 8 / C lanes share a ray).  The same IEEE operations on the same
 // operands as the per-child body of node_intersect: this lane's contribution to the hit mask, child_bits << bit_index
-// where the ray enters the child's box.  q = the child's six plane bytes {x near, x far, y near, y far, z near, z far}
-// (near = the max plane where the direction is negative), meta = its child_meta byte.
-template <int NODE>
-__device__ __forceinline__ uint32_t node_child_intersect(const Ray &r, float max_distance, const uint4 n0, uint32_t meta,
-                                                         const uint32_t q[6], const bool pow2) {
+// for every child of its share whose box the ray enters.  q = the six plane words of the share, C bytes each, in the
+// order {x near, x far, y near, y far, z near, z far} (near = the max plane where the direction is negative); meta = its
+// C child_meta bytes.
+template <int NODE, int C>
+__device__ __forceinline__ uint32_t node_children_intersect(const Ray &r, float max_distance, const uint4 n0, uint32_t meta,
+                                                            const uint32_t q[6], const bool pow2) {
     const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
     const uint32_t e_imask = n0.w;
     const float ex = __uint_as_float((e_imask & 0xffu) << 23);
@@ -271,29 +276,47 @@ __device__ __forceinline__ uint32_t node_child_intersect(const Ray &r, float max
         by = (py - r.oy) / r.dy;
         bz = (pz - r.oz) / r.dz;
     }
-    const f32x2 tx = plane2<NODE>(f32x2{(float)q[0], (float)q[1]}, ax, bx);
-    const f32x2 ty = plane2<NODE>(f32x2{(float)q[2], (float)q[3]}, ay, by);
-    const f32x2 tz = plane2<NODE>(f32x2{(float)q[4], (float)q[5]}, az, bz);
-    const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0001f);
-    const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), max_distance);
-    const uint32_t is_inner = (meta & (meta << 1)) & 0x10u;
-    const uint32_t bit_index = (meta ^ (is_inner ? (r.oct_inv4 & 0xffu) : 0u)) & 0x1fu;
-    const uint32_t child_bits = (meta >> 5) & 0x07u;
-    return tmin <= tmax ? child_bits << bit_index : 0u;
+    const uint32_t is_inner4 = (meta & (meta << 1)) & 0x10101010u;
+    const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+    const uint32_t bit_index4 = (meta ^ (r.oct_inv4 & inner_mask4)) & 0x1f1f1f1fu;
+    const uint32_t child_bits4 = (meta >> 5) & 0x07070707u;
+    uint32_t hit_mask = 0u;
+#pragma unroll
+    for (int j = 0; j < C; j++) {
+        const f32x2 tx = plane2<NODE>(f32x2{ubyte(q[0], j), ubyte(q[1], j)}, ax, bx);
+        const f32x2 ty = plane2<NODE>(f32x2{ubyte(q[2], j), ubyte(q[3], j)}, ay, by);
+        const f32x2 tz = plane2<NODE>(f32x2{ubyte(q[4], j), ubyte(q[5], j)}, az, bz);
+        const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0001f);
+        const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), max_distance);
+        if (tmin <= tmax) hit_mask |= ((child_bits4 >> (8 * j)) & 0xffu) << ((bit_index4 >> (8 * j)) & 0xffu);
+    }
+    return hit_mask;
 }
 
-// Groups of eight lanes (thin waves): the value of a group's first lane in all eight, and the OR of all eight in the
-// first - both on the DPP network (VALU only).  Every lane of the wave must be active.
-__device__ __forceinline__ uint32_t group8_first(uint32_t v) {
+// C bytes (1, 2 or 4) of a node at a byte address aligned to C: one load instruction.
+template <int C>
+__device__ __forceinline__ uint32_t load_bytes(const uint8_t *p) {
+    if (C == 1) return *p;
+    if (C == 2) return *reinterpret_cast<const uint16_t *>(p);
+    return *reinterpret_cast<const uint32_t *>(p);
+}
+
+// Groups of L = 2, 4 or 8 lanes (thin waves): the value of a group's first lane in all of them, and the OR of all of
+// them in the first - both on the DPP network (VALU only).  Every lane of the wave must be active.
+template <int L>
+__device__ __forceinline__ uint32_t group_first(uint32_t v) {
+    if (L == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xa0, 0xf, 0xf, false); // quad_perm [0,0,2,2]
     const uint32_t q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xf, 0xf, false);  // quad_perm [0,0,0,0]
+    if (L == 4) return q;
     const uint32_t h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q, 0x114, 0xf, 0xf, false); // row_shr:4
     return (__lane_id() & 4u) ? h : q;
 }
-__device__ __forceinline__ uint32_t group8_or_to_first(uint32_t v) {
+template <int L>
+__device__ __forceinline__ uint32_t group_or_to_first(uint32_t v) {
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); // row_shl:1 (0 past the row's end)
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xf, 0xf, true); // row_shl:2
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, true); // row_shl:4
-    return v; // (complete in the first lane of every group of eight; the others hold partial ORs)
+    if (L >= 4) v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xf, 0xf, true); // row_shl:2
+    if (L >= 8) v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, true); // row_shl:4
+    return v; // (complete in the first lane of every group; the others hold partial ORs)
 }
 
 // TriDev = {v0, e1 = v0 - v1, e2 = v2 - v0} as three float4; ng = cross(e1, e2) (query.hlsl:93) rides in the
@@ -625,9 +648,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // (Single-level walks only.  The two-level kernels were given the hand-over too - ten words more per ray, 32 rays at most: with it on
     // they run 2.5-4 % faster than with it off, but the kernel that contains the code is 3 % slower on the 4K two-level AO pass than the
     // kernel that does not, profiles/r03_drain_merge.log - the code for it stays below, compiled out.)
-    // Thin waves (incoherent single-level passes, queues dry, at most kThinMax rays left): eight lanes to a ray, see thin_walk.
+    // Thin waves (incoherent single-level passes, queues dry, at most P.thin_max rays left): two, four, eight lanes to a ray, see thin_walk.
     constexpr bool kThin = !TLAS && MODE != kModePrimary && !COUNT;
-    constexpr uint32_t kThinMax = 8u;
     bool go_thin = false; // wave-uniform
     constexpr bool kMerge = !TLAS && MODE != kModePrimary && MODE != kModeFused && !COUNT;
     constexpr uint32_t kMergeWords = TLAS ? 31u : 21u, kMergeMax = TLAS ? 32u : 48u, kMergeClosed = 0xffffffffu;
@@ -818,10 +840,12 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // Thin waves.  An incoherent pass ends when its longest rays do (two thirds of a hairball-class AO pass is its
     // drain), and at the end those rays sit one or two to a wave: the wave then issues alone on its SIMD, one
     // instruction every four to five cycles whatever the instruction is, so a ray's trip costs its INSTRUCTION COUNT -
-    // 213 vector instructions for the node test of one lane while 63 lanes idle.  Once a dry wave is down to kThinMax
-    // rays they are moved to lanes 0, 8, 16 ... and every ray gets eight lanes: lane j of a group tests child j of the
-    // node (its six plane bytes, loaded by address; the same IEEE operations as the per-lane test: node_child_intersect),
-    // the eight contributions are ORed on the DPP network, and a leaf's triangles are tested eight at a time and folded
+    // 213 vector instructions for the node test of one lane while 63 lanes idle - and before that, while four dry waves
+    // still share a SIMD with a third of their lanes in use, every trip they issue is mostly idle lanes.  So once a dry
+    // wave is down to 32 rays they are moved to lanes 0, 2, 4 ... and every ray gets two lanes, four from 16 rays, eight
+    // from 8: lane j of a group tests the children j 8/L ... of the node (their plane bytes, loaded by address; the same
+    // IEEE operations as the per-lane test: node_children_intersect),
+    // the contributions are ORed on the DPP network, and a leaf's triangles are tested L at a time and folded
     // into the ray's 64-bit {t, sequence} key with the same LDS atomic min as the cooperative rounds - node order,
     // triangle order, tie rule and every t are those of the one-lane walk (tested bit for bit).  A trip is about a
     // third of the instructions.  The walk is the plain one, rotated like the pipelined one: triangles of the node
@@ -829,17 +853,30 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // (wave-uniform) may this wave go thin now?  Queues dry, a handful of rays, every stack inside its LDS part, no
     // hand-over with the other wave of the workgroup pending, no lane of a fused frame waiting to become an AO ray.
     auto thin_now = [&](uint32_t alive) -> bool {
-        return exhausted && alive != 0u && alive <= kThinMax && P.no_thin == 0u && !(kMerge && merge_open) &&
+        return exhausted && alive != 0u && alive <= (kFused ? min(P.thin_max, 8u) : P.thin_max) && !(kMerge && merge_open) &&
                __ballot(has_ray && sp > (uint32_t)kLdsStack) == 0ull && !(kFused && __ballot(pend) != 0ull);
     };
-    auto thin_walk = [&]() {
-        const uint32_t sub = lane & 7u, first = lane & ~7u;
-        {   // ---- move ray k (in lane order) to lane 8 k, stack column and all; give its seven helpers the ray
+    auto thin_walk = [&](auto lanes_per_ray) {
+        constexpr uint32_t L = (uint32_t)decltype(lanes_per_ray)::value; // lanes to a ray: 2, 4 or 8
+        constexpr uint32_t C = 8u / L;                                   // children of a node to a lane
+        constexpr uint32_t kCap = (uint32_t)kWave / L;                   // rays the wave holds this way
+        const uint32_t sub = lane & (L - 1u), first = lane & ~(L - 1u);
+        {   // ---- move ray k (in lane order) to lane L k, stack column and all; give its L - 1 helpers the ray
             const unsigned long long act = __ballot(has_ray);
-            unsigned long long m = act;
-            for (uint32_t i = 0; i < (lane >> 3); i++) m &= m - 1ull; // (at most seven rounds; the group's rank picks its ray)
-            const bool filled = m != 0ull;
-            const int src = filled ? __ffsll((long long)m) - 1 : (int)lane;
+#ifdef TRX_TAIL_DIAG
+            // (diagnostic builds, tools/gpu_timeline_ao.py: when the wave first went thin, with how many rays, after how many trips)
+            if (diag_t0 == 0ull) {
+                diag_t0 = wall_clock64();
+                diag_chunk = (unsigned long long)__popcll(act);
+                diag_tiles = trip;
+            }
+#endif
+            // the k-th ray's lane, through a table in LDS (the cooperative rounds' run-head table, idle here)
+            if (has_ray) lds_head[lane_rank(act)] = lane;
+            __builtin_amdgcn_wave_barrier();
+            const bool filled = lane / L < (uint32_t)__popcll(act);
+            const int src = filled ? (int)lds_head[lane / L] : (int)lane;
+            __builtin_amdgcn_wave_barrier();
             const bool owner = filled && sub == 0u;
             r.ox = __shfl(r.ox, src); r.oy = __shfl(r.oy, src); r.oz = __shfl(r.oz, src);
             r.dx = __shfl(r.dx, src); r.dy = __shfl(r.dy, src); r.dz = __shfl(r.dz, src);
@@ -869,14 +906,14 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             if (!owner) {
                 ptri = make_uint2(0u, 0u);
                 cur = make_uint2(0u, 0u);
-                r.oct_inv4 &= 0x7fffffffu | (filled ? 0x80000000u : 0u); // (a group without a ray must not veto the exact-reciprocal shortcut)
+                if (!filled) r.oct_inv4 &= 0x7fffffffu; // (a group without a ray must not veto the exact-reciprocal shortcut)
             }
             if (owner) {
                 lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
                 lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
             }
             fetched = false;
-            __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_s_setprio(L == 8u ? 3 : 2);
         }
         unsigned long long *const lds_key = reinterpret_cast<unsigned long long *>(lds_res);
         // The trip is rotated like the pipelined walk's, and one step further: (1) the ray's next node is chosen and its
@@ -891,9 +928,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         // (the one-launch frame comes back from here into its loop, whose registers stay live meanwhile: it does without
         // the early triangle request, twelve registers carried from trip to trip)
         constexpr bool kPre = !kFused;
-        auto request_triangles = [&]() { // (5): the group's pending triangle group, and this lane's record of its first eight
-            gx = group8_first(ptri.x);
-            gy = group8_first(ptri.y);
+        auto request_triangles = [&]() { // (5): the group's pending triangle group, and this lane's record of its first L
+            gx = group_first<(int)L>(ptri.x);
+            gy = group_first<(int)L>(ptri.y);
             cnt = (uint32_t)__popc(gy);
             if (kPre && sub < cnt) {
                 const float4 *tp = P.tris + (size_t)(gx + select_from_top(gy, sub)) * 3;
@@ -904,7 +941,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             }
         };
         request_triangles(); // (a wave that comes from the pipelined walk brings pending triangle groups)
-        bool leaving = false; // wave-uniform (fused frames): a primary ray has hit, what is in flight is finished, then out
+        // wave-uniform: what is in flight is finished, then out - a fused frame's primary ray has hit, or the rays have
+        // become few enough for twice the lanes each
+        bool leaving = false;
         for (;;) {
             trip++;
             // ---- (1) the next node of every ray that holds a node group; its bytes are requested
@@ -921,26 +960,27 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             }
             const bool gstep = ((__ballot(stepping) >> first) & 1ull) != 0ull;
             if (gstep) {
-                const uint4 *np = P.nodes + (size_t)group8_first(node_index) * 5;
-                const uint8_t *nb = reinterpret_cast<const uint8_t *>(np) + sub;
+                const uint4 *np = P.nodes + (size_t)group_first<(int)L>(node_index) * 5;
+                const uint8_t *nb = reinterpret_cast<const uint8_t *>(np) + sub * C;
                 n0 = np[0];
                 n1 = np[1];
-                // plane bytes by address: min planes at +32 / +48 / +64, max planes eight bytes on; near = max where d < 0
+                // the plane bytes of this lane's C children by address: min planes at +32 / +48 / +64, max planes eight bytes
+                // on; near = max where d < 0
                 const uint32_t xn = r.dx < 0.0f ? 8u : 0u, yn = r.dy < 0.0f ? 8u : 0u, zn = r.dz < 0.0f ? 8u : 0u;
-                q0 = nb[32u + xn]; q1 = nb[32u + (xn ^ 8u)];
-                q2 = nb[48u + yn]; q3 = nb[48u + (yn ^ 8u)];
-                q4 = nb[64u + zn]; q5 = nb[64u + (zn ^ 8u)];
+                q0 = load_bytes<(int)C>(nb + 32u + xn); q1 = load_bytes<(int)C>(nb + 32u + (xn ^ 8u));
+                q2 = load_bytes<(int)C>(nb + 48u + yn); q3 = load_bytes<(int)C>(nb + 48u + (yn ^ 8u));
+                q4 = load_bytes<(int)C>(nb + 64u + zn); q5 = load_bytes<(int)C>(nb + 64u + (zn ^ 8u));
                 asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z), "+v"(n1.w), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5));
             }
-            // ---- (2) triangles of the node tested in the previous trip, eight at a time; the first eight are here already
+            // ---- (2) triangles of the node tested in the previous trip, L at a time; the first L are here already
             if (__ballot(cnt != 0u) != 0ull) {
                 const uint32_t init_lo = tie_first ? 0u : 0xffu;
                 if (sub == 0u) lds_res[lane] = make_uint2(init_lo, ordered_bits(t + 0.0f));
                 __builtin_amdgcn_wave_barrier();
-                for (uint32_t j = sub; __ballot(j < cnt) != 0ull; j += 8u) {
+                for (uint32_t j = sub; __ballot(j < cnt) != 0ull; j += L) {
                     if (j < cnt) {
                         const uint32_t local = select_from_top(gy, j);
-                        if (!kPre || j >= 8u) {
+                        if (!kPre || j >= L) {
                             const float4 *tp = P.tris + (size_t)(gx + local) * 3;
                             ta = tp[0];
                             tb = tp[1];
@@ -984,18 +1024,19 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             // finished first - this trip's node tests, then, in one more trip that chooses no node, their triangles - so
             // that every ray left holds a node group and nothing pending: the state the other walks expect.)
             if (leaving) break;
-            if (kFused && __ballot(pend) != 0ull) leaving = true;
-            // ---- (4) node test, one child per lane, for the rays still there
-            const bool galive = ((__ballot(has_ray) >> first) & 1ull) != 0ull;
-            const float gt = __uint_as_float(group8_first(__float_as_uint(t)));
+            const unsigned long long alive_mask = __ballot(has_ray);
+            if ((kFused && __ballot(pend) != 0ull) || (L < 8u && (uint32_t)__popcll(alive_mask) <= kCap / 2u)) leaving = true;
+            // ---- (4) node test, C children per lane, for the rays still there
+            const bool galive = ((alive_mask >> first) & 1ull) != 0ull;
+            const float gt = __uint_as_float(group_first<(int)L>(__float_as_uint(t)));
             const bool pow2 = (NODE & 1) ? false : pow2_exact(P, r, gstep && galive);
             uint32_t contrib = 0u;
             if (gstep && galive) {
-                const uint32_t meta = ((sub < 4u ? n1.z : n1.w) >> (8u * (sub & 3u))) & 0xffu;
+                const uint32_t meta = (sub * C < 4u ? n1.z : n1.w) >> (8u * ((sub * C) & 3u));
                 const uint32_t q[6] = {q0, q1, q2, q3, q4, q5};
-                contrib = node_child_intersect<NODE>(r, gt, n0, meta, q, pow2);
+                contrib = node_children_intersect<NODE, (int)C>(r, gt, n0, meta, q, pow2);
             }
-            const uint32_t hitmask = group8_or_to_first(contrib);
+            const uint32_t hitmask = group_or_to_first<(int)L>(contrib);
             if (stepping && has_ray) {
                 cur.x = n1.x;
                 ptri.x = n1.y;
@@ -1018,6 +1059,22 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             pn3 = make_uint4(__float_as_uint(u3.x), __float_as_uint(u3.y), __float_as_uint(u3.z), __float_as_uint(u3.w));
             pn4 = make_uint4(__float_as_uint(u4.x), __float_as_uint(u4.y), __float_as_uint(u4.z), __float_as_uint(u4.w));
         }
+    };
+    // The thin walk of a dry wave, with as many lanes to a ray as its rays allow; returns with no ray left or, fused frames,
+    // with a lane waiting to become an AO ray (thin_walk<2 or 4> returns once twice the lanes fit).
+    auto thin_all = [&]() {
+        // (straight-line, not a loop over the three walks: the lanes to a ray only ever double)
+        auto rays_left = [&]() -> uint32_t {
+            return (kFused && __ballot(pend) != 0ull) ? 0u : (uint32_t)__popcll(__ballot(has_ray));
+        };
+        // (the one-launch frame, whose loop the walk returns into, has the registers for the last step only)
+        if constexpr (!kFused && TRX_THIN_LEVELS >= 3) {
+            if (rays_left() > 16u) thin_walk(std::integral_constant<int, 2>{});
+        }
+        if constexpr (!kFused && TRX_THIN_LEVELS >= 2) {
+            if (rays_left() > 8u) thin_walk(std::integral_constant<int, 4>{});
+        }
+        if (rays_left() != 0u) thin_walk(std::integral_constant<int, 8>{});
     };
 
     for (;;) {
@@ -1569,14 +1626,14 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             if (wave_in_block == 1u) {
                 // (a wave that is down to a handful of rays finishes them itself, eight lanes to a ray - thin_walk - rather
                 // than hand them to a wave that steps them one lane each)
-                if (kThin && alive <= kThinMax && !P.no_thin) merge_open = false;
+                if (kThin && alive <= P.thin_max) merge_open = false;
                 else if (alive != 0u && alive <= kMergeMax) (void)merge_offer(alive);
             } else {
                 if (lane == 0u) *reinterpret_cast<volatile uint32_t *>(&merge_ctl[1]) = (uint32_t)kWave - alive;
                 const uint32_t n = *reinterpret_cast<volatile uint32_t *>(&merge_ctl[0]);
                 if (n != 0u) {
                     merge_take(n);
-                } else if (kThin && alive <= kThinMax && !P.no_thin) {
+                } else if (kThin && alive <= P.thin_max) {
                     // ... and the first wave, down to a handful, closes the door - unless an offer has just landed
                     uint32_t old = 0u;
                     if (lane == 0u) old = atomicCAS(&merge_ctl[0], 0u, kMergeClosed);
@@ -1879,10 +1936,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             // ray - so it runs AFTER the loop, where the registers the loop carries are dead)
             if (!kFused) break;
             go_thin = false;
-            thin_walk(); // returns with no ray left, or with a lane waiting to become an AO ray
+            thin_all(); // returns with no ray left, or with a lane waiting to become an AO ray
         }
     }
-    if (kThin && !kFused && go_thin) thin_walk(); // returns with no ray left
+    if (kThin && !kFused && go_thin) thin_all(); // returns with no ray left
 
     // ---- epilogue: flags, counters, queue reset ---------------------------------------
     if (lpt_write && n_pend) flush_pending(P, wr_set, lds_pend, n_pend, lane);
