@@ -1,6 +1,6 @@
 """Profiling target for the rocprofv3 passes of profiles/: replays one BASELINE config's kernel a few times.
 usage (after `--` of rocprofv3): python3 tools/prof_config.py <config> [frames]
-configs: primary_bistro, primary_bistro_dense, ao_bistro, ao_hairball, primary_hairball, tlas_san_miguel_4k, rays_bistro"""
+configs: primary_bistro, primary_bistro_dense, ao_bistro, ao_hairball, ao4_hairball, primary_hairball, tlas_san_miguel_4k, rays_bistro"""
 import os
 import sys
 
@@ -20,6 +20,7 @@ CONFIGS = {
     "primary_hairball": ("hairball", "primary", 1920, 1080, False),
     "ao_bistro": ("bistro", "ao", 1920, 1080, False),
     "ao_hairball": ("hairball", "ao", 1920, 1080, False),
+    "ao4_hairball": ("hairball", "ao4", 1920, 1080, False),   # BASELINE configs[3]: 4 spp = AO frames 0..3 in ONE launch
     "tlas_san_miguel_4k": ("san_miguel", "primary", 3840, 2160, True),
     "rays_bistro": ("bistro", "rays", 1920, 1080, False),
 }
@@ -59,13 +60,17 @@ def main():
         d_prim = torch.empty(w * h, dtype=torch.int64, device="cuda")
         sc.trace_primary_dev(view, w, h, d_prim.data_ptr(), sem=3)
         sc.check()
-        if mode == "ao":
-            d_ao = torch.empty(w * h, dtype=torch.int64, device="cuda")
+        if mode in ("ao", "ao4"):
+            spp = 4 if mode == "ao4" else 1
+            d_ao = torch.empty(spp * w * h, dtype=torch.int64, device="cuda")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             best = 1e9
             for f in range(frames + 3):
                 e0.record()
-                sc.trace_ao_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=3, frame=f % 4, ao_eps=0.01)
+                if spp == 1:
+                    sc.trace_ao_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=3, frame=f % 4, ao_eps=0.01)
+                else:
+                    sc.trace_ao_batch_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), w * h, spp, sem=3, frame0=spp * f, ao_eps=0.01)
                 e1.record()
                 torch.cuda.synchronize()
                 if f >= 3:
@@ -75,7 +80,8 @@ def main():
             ast = L.Stats()
             L.check(L.load().trx_count_ao(sc.handle, C.byref(view), w, h, L.Shard(0, 1, 0, 0), 3, 0, 0.01,
                                           C.c_void_p(d_prim.data_ptr()), C.c_void_p(d_ao.data_ptr()), C.byref(ast)))
-            info.update(rays=hits, n_node=int(ast.n_node), n_tri=int(ast.n_tri), ms_min=best)
+            # (the counts are those of ONE AO frame, seed 0; a batch of spp frames asks for about spp times as much)
+            info.update(rays=hits * spp, n_node=int(ast.n_node) * spp, n_tri=int(ast.n_tri) * spp, ms_min=best, spp=spp)
         else:
             n = w * h
             rays = hemisphere_rays(flat, None, eye, n, 5)

@@ -426,7 +426,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.n_nodes = (uint32_t)s->n_nodes;
     {   // tuning: variant bits 25..27 = compaction threshold (0 = default, 7 = never); bit 28 = no thin waves (A/B runs)
         const uint32_t c = (variant >> 25) & 0x7u;
-        p.thin_max = ((variant >> 28) & 1u) ? 0u : 32u;
+        p.thin_max = ((variant >> 28) & 1u) ? 0u : 8u;
 #ifdef TRX_DEV_TUNE
         {   // (development builds: TRX_THIN_MAX = 0 / 8 / 16 / 32)
             const char *tm = getenv("TRX_THIN_MAX");

@@ -29,8 +29,12 @@
 
 #pragma clang fp contract(off)
 
+// Lanes-per-ray steps of the thin walk: 1 = eight lanes from 8 rays on (shipped), 2 = also four from 16, 3 = also two from
+// 32.  Measured (profiles/r04_thin_waves.log): 8 / 16 / 32 rays = hairball-class AO pass 0.917 / 0.909 / 0.945 ms against
+// 1.044 without, bistro-class 0.984 / 0.999 / 1.035 against 1.008 - the earlier steps cost what they gain (a re-pack and a
+// drain trip per step, and the waves no longer merge), so the product compiles the last step only.
 #ifndef TRX_THIN_LEVELS
-#define TRX_THIN_LEVELS 3 // lanes-per-ray steps of the thin walk: 1 = eight only, 2 = four and eight, 3 = two, four and eight
+#define TRX_THIN_LEVELS 1
 #endif
 
 // TRX_STAMPS (diagnostic builds only): per-wave cycle accounting of the loop's phases.  Every stamp
@@ -840,11 +844,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // Thin waves.  An incoherent pass ends when its longest rays do (two thirds of a hairball-class AO pass is its
     // drain), and at the end those rays sit one or two to a wave: the wave then issues alone on its SIMD, one
     // instruction every four to five cycles whatever the instruction is, so a ray's trip costs its INSTRUCTION COUNT -
-    // 213 vector instructions for the node test of one lane while 63 lanes idle - and before that, while four dry waves
-    // still share a SIMD with a third of their lanes in use, every trip they issue is mostly idle lanes.  So once a dry
-    // wave is down to 32 rays they are moved to lanes 0, 2, 4 ... and every ray gets two lanes, four from 16 rays, eight
-    // from 8: lane j of a group tests the children j 8/L ... of the node (their plane bytes, loaded by address; the same
-    // IEEE operations as the per-lane test: node_children_intersect),
+    // 213 vector instructions for the node test of one lane while 63 lanes idle.  So once a dry wave is down to 8 rays
+    // they are moved to lanes 0, 8, 16 ... and every ray gets L = 8 lanes (the code is generic in L = 2, 4, 8; see
+    // TRX_THIN_LEVELS for why only 8 ships): lane j of a group tests children j 8/L ... of the node (their plane bytes,
+    // loaded by address; the same IEEE operations as the per-lane test: node_children_intersect),
     // the contributions are ORed on the DPP network, and a leaf's triangles are tested L at a time and folded
     // into the ray's 64-bit {t, sequence} key with the same LDS atomic min as the cooperative rounds - node order,
     // triangle order, tie rule and every t are those of the one-lane walk (tested bit for bit).  A trip is about a
