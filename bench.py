@@ -6,9 +6,11 @@ in-kernel; scene resident in HBM before the timed region).
 
 N = 1 measures what SURVEY.md 8(d) defines, the way the reference measures its GPU path
 (src/rt_gpu/rt_gpu_software.rs:289-302,339-344,376): ONE frame in flight — the K timed launches go back to back
-on one HIP stream, each bracketed by a hipEvent pair on that stream — after the warm-up launches.  `value` is
-rays * K / wall-clock of the timed region; `kernel_ms_mean` / `kernel_ms_min` are the per-launch event times
-(their mean times K is the timed region, up to launch gaps).  Beside it, as separate legs that never enter
+on one HIP stream, ONE hipEvent pair on that stream around all of them — after `--wake-frames` untimed frames that take
+the GPU out of its idle clocks and the W warm-up launches.  `value` is rays * K / wall-clock of the timed region;
+`kernel_ms_mean` is that event pair / K (the average launch duration, gaps included); `kernel_ms_min` and
+`kernel_ms_per_step` are per-launch event pairs of the same frames run once more right after the timed region (an event
+pair per launch inside it costs about 5 us of idle GPU per frame).  Beside it, as separate legs that never enter
 `value`: the reference's own protocol (3 passes x [3 discarded + 20 timed frames], min and mean), the first
 frame of a geometry (tile order not yet learnt: `cold_order_ms`), the literal-HLSL arithmetic
 (`sem_hlsl_ms`), frames overlapped on 4 streams (`pipelined_mrays`), a measured HBM copy ceiling, live
@@ -303,15 +305,17 @@ def main():
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
-    def trace(s, ptr, shard, n, stride):
-        """n frames in one launch (n == 1: the plain entry point), bracketed by events on the launching stream."""
-        ev0, ev1 = ev(), ev()
-        ev0.record(s)
+    def trace(s, ptr, shard, n, stride, timed=True):
+        """n frames in one launch (n == 1: the plain entry point), bracketed by events on the launching stream when `timed`."""
+        ev0, ev1 = (ev(), ev()) if timed else (None, None)
+        if timed:
+            ev0.record(s)
         if n == 1:
             scene.trace_primary_dev(view, w, h, ptr, sem=args.sem, shard=shard, stream=s.cuda_stream)
         else:
             scene.trace_primary_batch_dev([view] * n, w, h, ptr, stride, sem=args.sem, shard=shard, stream=s.cuda_stream)
-        ev1.record(s)
+        if timed:
+            ev1.record(s)
         return ev0, ev1, n
 
     def run_frames(n, events, phases=None):
@@ -324,7 +328,9 @@ def main():
                 state["k"] += 1
                 with torch.cuda.stream(streams[j]):
                     # one GPU owns every tile: the kernel writes the row-major frame(s) directly
-                    events.append(trace(streams[j], frames[j].data_ptr(), shard_img, m, n_rays_total))
+                    e = trace(streams[j], frames[j].data_ptr(), shard_img, m, n_rays_total, timed=events is not None)
+                    if events is not None:
+                        events.append(e)
                 state["last"] = frames[j][(m - 1) * n_rays_total: m * n_rays_total]
                 done += m
             return
@@ -396,14 +402,30 @@ def main():
         sync_all()
     run_frames(args.warmup, [])
     sync_all()
+    # One GPU, one frame in flight (the default): the K launches go back to back with ONE hipEvent pair around all of them
+    # on their stream - an event pair per launch puts two markers between consecutive kernels and costs the timed region
+    # about 5 us of idle GPU per frame (measured: 0.4293 ms per step against 0.4224 ms of kernel).  The per-launch series
+    # (kernel_ms_min, kernel_ms_per_step) comes from a second, untimed pass of the same frames right after.
+    one_pair = world == 1 and n_streams == 1
     t0 = time.perf_counter()
     events, phases = [], []
-    run_frames(args.steps, events, phases)
+    if one_pair:
+        r0, r1 = ev(), ev()
+        r0.record(streams[0])
+        run_frames(args.steps, None)
+        r1.record(streams[0])
+    else:
+        run_frames(args.steps, events, phases)
     sync_all()
     elapsed = time.perf_counter() - t0
     for s in streams:
         scene.check(s.cuda_stream)
     frame = state["last"]
+    region_kernel_ms = None
+    if one_pair:
+        region_kernel_ms = r0.elapsed_time(r1) / args.steps   # average launch duration over the timed region, gaps included
+        run_frames(min(args.steps, 64), events)               # untimed: the same frames again, an event pair each
+        sync_all()
     launch_ms = [a.elapsed_time(b) / n for a, b, n in events]   # per frame of each launch
 
     if world > 1:
@@ -419,7 +441,7 @@ def main():
         kernel_ms_ranks = [float(x[0]) for x in allk]
     rays_per_step = st.n_rays if args.sim_shards > 1 else n_rays_total
     value = rays_per_step * args.steps / elapsed / 1e6
-    kernel_ms = sum(launch_ms) / len(launch_ms)
+    kernel_ms = region_kernel_ms if region_kernel_ms is not None else sum(launch_ms) / len(launch_ms)
 
     out = None
     legs = {}
@@ -464,7 +486,60 @@ def main():
         at = [a.elapsed_time(b) for a, b in ao_ev][3:]
         legs["ao_pass_ms"] = {"rays": n_ao, "frames": len(at), "min": round(min(at), 4), "mean": round(sum(at) / len(at), 4),
                               "mrays_at_mean": round(n_ao / (sum(at) / len(at)) / 1e3, 1)}
-        del d_prim, d_ao
+
+        def timed(fn, reps=12, skip=3):
+            """hipEvent time of fn(i) on the default stream, one call in flight: (min, mean) over `reps` after `skip`."""
+            ts = []
+            for i in range(reps + skip):
+                a, b = ev(), ev()
+                a.record()
+                fn(i)
+                b.record()
+                torch.cuda.synchronize()
+                if i >= skip:
+                    ts.append(a.elapsed_time(b))
+            return min(ts), sum(ts) / len(ts)
+        # (c"') BASELINE.json's "4 spp" = AO frames with seeds 0..3 (src/rt_cpu/rt_cpu.rs:95-97): ONE launch
+        #       (trx_trace_ao_batch_dev) - the four passes share one drain
+        d_ao4 = torch.empty(4 * n_rays_total, dtype=torch.int64, device="cuda")
+        a4 = timed(lambda i: scene.trace_ao_batch_dev(view, w, h, d_prim.data_ptr(), d_ao4.data_ptr(), n_rays_total, 4,
+                                                      sem=args.sem, frame0=4 * i, ao_eps=0.01))
+        legs["ao_4spp_ms"] = {"rays": 4 * n_ao, "launches": 1, "min": round(a4[0], 4), "mean": round(a4[1], 4),
+                              "mrays_at_mean": round(4 * n_ao / a4[1] / 1e3, 1)}
+        # (c"") the reference-style frame, device-resident: primary + AO as two launches back to back on one stream, and as
+        #       ONE launch (trx_trace_frame_dev: the reference's single dispatch, a lane whose primary ray hits goes on as
+        #       the pixel's AO ray) - same records either way
+        f2 = timed(lambda i: (scene.trace_primary_dev(view, w, h, d_prim.data_ptr(), sem=args.sem),
+                              scene.trace_ao_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=i % 4, ao_eps=0.01)))
+        f1 = timed(lambda i: scene.trace_frame_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=i % 4, ao_eps=0.01))
+        legs["frame_primary_ao_ms"] = {"two_launches": {"min": round(f2[0], 4), "mean": round(f2[1], 4)},
+                                       "one_launch": {"min": round(f1[0], 4), "mean": round(f1[1], 4)}}
+        del d_prim, d_ao, d_ao4
+        # (c5) BASELINE.json configs[3] itself: the hairball-class stand-in, primary frame, one AO pass, and the 4 spp in one launch
+        if args.scene == "bistro" and args.tris == 0:
+            hv, hc = T.gen_scene("hairball", 0, 1)
+            hflat = T.flat_build(hv, hc, use_tlas=False, threads=threads, preset=args.preset)
+            hscene = T.Scene(hflat, device=local_rank)
+            he, hl, hf = T.scene_camera("hairball")
+            hview = T.view_from_camera(he, hl, hf, w, h)
+            hp = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
+            ha = torch.empty(4 * n_rays_total, dtype=torch.int64, device="cuda")
+            hprim = [hscene.bench_primary(hview, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(2)]
+            hscene.trace_primary_dev(hview, w, h, hp.data_ptr(), sem=args.sem)
+            torch.cuda.synchronize()
+            h_ao = int(((hp & 0xffffffff) != 0x7f800000).sum().item())
+            h1 = timed(lambda i: hscene.trace_ao_dev(hview, w, h, hp.data_ptr(), ha.data_ptr(), sem=args.sem, frame=i % 4, ao_eps=0.01))
+            h4 = timed(lambda i: hscene.trace_ao_batch_dev(hview, w, h, hp.data_ptr(), ha.data_ptr(), n_rays_total, 4, sem=args.sem,
+                                                           frame0=4 * i, ao_eps=0.01))
+            legs["hairball_4spp"] = {
+                "scene": "hairball", "tris": int(hflat.n_tris), "ao_rays_per_frame": h_ao,
+                "primary_ms": round(sum(q[1] for q in hprim) / 2, 4),
+                "ao_pass_ms": {"min": round(h1[0], 4), "mean": round(h1[1], 4), "mrays_at_mean": round(h_ao / h1[1] / 1e3, 1)},
+                "ao_4spp_one_launch_ms": {"min": round(h4[0], 4), "mean": round(h4[1], 4),
+                                          "mrays_at_mean": round(4 * h_ao / h4[1] / 1e3, 1)},
+            }
+            hscene.close()
+            del hv, hc, hflat, hp, ha
         # (d) frames overlapped on 4 streams (independent frames; the tail of one overlaps the next)
         ps = [torch.cuda.Stream() for _ in range(4)]
         pbuf = [torch.empty(n_rays_total, dtype=torch.int64, device="cuda") for _ in ps]
@@ -713,8 +788,11 @@ def main():
             },
             "kernel_ms_mean": round(kernel_ms, 4),
             "kernel_ms_min": round(min(launch_ms), 4),
-            # every timed launch in order, for short runs (the driver's protocol is 20): shows a schedule still settling
+            # per-launch event times in order (for one frame in flight: of the untimed pass that follows the timed region;
+            # kernel_ms_mean is then the timed region's own event pair / steps): shows a schedule or a clock still settling
             "kernel_ms_per_step": [round(x, 4) for x in launch_ms] if len(launch_ms) <= 64 else None,
+            "kernel_ms_mean_source": ("one hipEvent pair around the K timed launches / K" if region_kernel_ms is not None else
+                                      "mean of the per-launch hipEvent pairs of the timed region"),
             "timed_region_ms": round(elapsed * 1e3, 3),
             "roofline": roof,
             "roofline_hbm": hbm,
@@ -770,7 +848,12 @@ def main():
         # shading (src/rt_cpu/rt_cpu.rs:35-92,98,113); two frames of that, with the GPU's primary + AO frame beside it
         frame_s = min(osc.render_frame(ov, w, h, sem=args.sem, frame=f, ao_eps=0.01, threads=cores) for f in range(2))
         O.set_simd(False)
-        gpu_frame_ms = min(scene.trace_primary_ao(view, w, h, sem=args.sem, frame=f, ao_eps=0.01)[2] for f in range(4))
+        # (kernel time of the same rays on the GPU: the device-resident two-launch frame of legs.frame_primary_ao_ms where the
+        # legs ran, else the host-buffer entry point's event time)
+        if "frame_primary_ao_ms" in legs:
+            gpu_frame_ms = legs["frame_primary_ao_ms"]["two_launches"]["min"]
+        else:
+            gpu_frame_ms = min(scene.trace_primary_ao(view, w, h, sem=args.sem, frame=f, ao_eps=0.01)[2] for f in range(4))
         out["cpu_baseline"] = {
             "value": round(n_rays_total * n_frames / secs / 1e6, 3),
             "unit": "Mrays/s",
