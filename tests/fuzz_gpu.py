@@ -119,9 +119,35 @@ def one_case(T, O, rng, case):
         sc = T.Scene(flat)
         osc = O.Scene.from_flat(flat)
     bad = []
-    kind = int(rng.integers(4))
+    kind = int(rng.integers(6))
     try:
-        if kind == 0:      # primary + AO, host entry point
+        if kind == 4:      # round 4: n AO frames in one launch (trx_trace_ao_batch_dev), odd frame stride
+            m, frame0, eps = int(rng.integers(2, 9)), int(rng.integers(0, 5000)), float(rng.choice([0.01, 0.0001]))
+            stride = w * h + int(rng.integers(0, 7))
+            d_p = torch.empty(w * h, dtype=torch.int64, device="cuda")
+            d_a = torch.full((m * stride,), -1, dtype=torch.int64, device="cuda")
+            sc.trace_primary_dev(view, w, h, d_p.data_ptr(), sem=sem)
+            sc.trace_ao_batch_dev(view, w, h, d_p.data_ptr(), d_a.data_ptr(), stride, m, sem=sem, frame0=frame0, ao_eps=eps)
+            sc.check()
+            wp, _ = osc.trace_primary(ov, w, h, sem=sem)
+            bad += [("primary", differs(D.int64_to_hits(d_p), wp))]
+            for f in range(m):
+                wa, _ = osc.trace_ao(ov, w, h, wp, sem=sem, frame=frame0 + f, ao_eps=eps)
+                bad += [("ao batch frame %d/%d" % (f, m), differs(D.int64_to_hits(d_a[f * stride:f * stride + w * h]), wa))]
+        elif kind == 5:    # round 4: the one-launch frame (trx_trace_frame_dev; two launches inside for two-level scenes)
+            frame, eps = int(rng.integers(0, 5000)), float(rng.choice([0.01, 0.0001]))
+            d_p = torch.full((w * h,), -1, dtype=torch.int64, device="cuda")
+            d_a = torch.full((w * h,), -1, dtype=torch.int64, device="cuda")
+            T.load().trx_set_kernel_variant(int(rng.choice([0, 1, 24, 64, 8 | (1 << 14), 32 | (3 << 14)])))
+            try:
+                sc.trace_frame_dev(view, w, h, d_p.data_ptr(), d_a.data_ptr(), sem=sem, frame=frame, ao_eps=eps)
+                sc.check()
+            finally:
+                T.load().trx_set_kernel_variant(0)
+            wp, _ = osc.trace_primary(ov, w, h, sem=sem)
+            wa, _ = osc.trace_ao(ov, w, h, wp, sem=sem, frame=frame, ao_eps=eps)
+            bad += [("frame primary", differs(D.int64_to_hits(d_p), wp)), ("frame ao", differs(D.int64_to_hits(d_a), wa))]
+        elif kind == 0:      # primary + AO, host entry point
             frame, eps = int(rng.integers(0, 5000)), float(rng.choice([0.01, 0.0001]))
             prim, ao, _ = sc.trace_primary_ao(view, w, h, sem=sem, frame=frame, ao_eps=eps)
             wp, _ = osc.trace_primary(ov, w, h, sem=sem)

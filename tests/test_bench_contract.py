@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on the committed line of the round (profiles/r03_bench_default.json is the
+"""The bench line's contract, checked on the committed line of the round (profiles/r04_bench_default.json is the
 verbatim output of `python bench.py` on the GPU box) and on bench.py's own argument defaults: the keys the driver
 reads, BASELINE.json's metric spelled exactly, the roofline and cpu_baseline objects, and the internal consistency
 the review asked for (kernel time x steps ~ timed region, fractions below 1 where they must be)."""
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def line():
-    path = os.path.join(ROOT, "profiles", "r03_bench_default.json")
+    path = os.path.join(ROOT, "profiles", "r04_bench_default.json")
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
@@ -85,6 +85,30 @@ def test_cpu_baseline_and_legs(line):
     assert legs["ploc_pipeline"]["nodes_per_ray"] > 0 and legs["dense_scene"]["nodes_per_ray"] > 25
     # the AO pass over the bench frame's primary hits: one ray per hit, timed per launch
     assert 0 < legs["ao_pass_ms"]["rays"] <= 1920 * 1080 and legs["ao_pass_ms"]["mean"] >= legs["ao_pass_ms"]["min"] > 0
+    # round 4: BASELINE's "4 spp" as ONE launch (the four AO frames share a drain: more rays per second than one pass),
+    # the reference-style frame as two launches and as one, configs[3]'s own scene
+    a4 = legs["ao_4spp_ms"]
+    assert a4["launches"] == 1 and a4["rays"] == 4 * legs["ao_pass_ms"]["rays"] and a4["mrays_at_mean"] > legs["ao_pass_ms"]["mrays_at_mean"]
+    fr = legs["frame_primary_ao_ms"]
+    assert 0 < fr["two_launches"]["min"] <= fr["two_launches"]["mean"] and 0 < fr["one_launch"]["min"] <= fr["one_launch"]["mean"]
+    assert fr["two_launches"]["mean"] < legs["ao_pass_ms"]["mean"] + 1.2 * line["kernel_ms_mean"]   # the sum of its passes, no more
+    hb = legs["hairball_4spp"]
+    assert hb["tris"] == 2880000 and hb["ao_4spp_one_launch_ms"]["mrays_at_mean"] > 1.3 * hb["ao_pass_ms"]["mrays_at_mean"]
+
+
+def test_the_drivers_protocol_lines_of_the_round():
+    """`python bench.py --steps 20 --warmup 5` twice on one box (profiles/r04_bench_driver_protocol.json), and once with
+    --wake-frames 0 on a GPU at idle clocks (…_no_wake.json): the contract's keys, and what the wake frames are worth."""
+    lines = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r04_bench_driver_protocol.json")).read().strip().splitlines()]
+    cold = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_driver_protocol_no_wake.json")).read().strip().splitlines()[-1])
+    for d in lines + [cold]:
+        assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and d["config"]["frames_in_flight"] == 1
+        assert d["value"] == pytest.approx(1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+        assert len(d["kernel_ms_per_step"]) == 20
+    assert all(d["config"]["wake_frames"] == 64 and d["value"] > 4800 for d in lines)
+    assert cold["config"]["wake_frames"] == 0 and cold["value"] < min(d["value"] for d in lines)
+    # a GPU still at idle clocks: the per-launch series falls through the timed region
+    assert cold["kernel_ms_per_step"][0] > cold["kernel_ms_per_step"][-1] * 1.02
 
 
 def test_default_arguments_finish_in_minutes():

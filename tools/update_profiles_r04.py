@@ -122,7 +122,7 @@ def summarise(cfg):
 
 def main():
     results = []
-    for cfg in ("primary_bistro", "primary_bistro_dense", "primary_hairball", "ao_bistro", "ao_hairball",
+    for cfg in ("primary_bistro", "primary_bistro_dense", "primary_hairball", "ao_bistro", "ao_hairball", "ao4_hairball",
                 "tlas_san_miguel_4k", "rays_bistro"):
         r = summarise(cfg)
         if not r:
