@@ -62,6 +62,28 @@ def test_transformed_instances_primary_and_ao_frames(trx, orc):
         sc.trace_ao_dev(view, w, h, d_p.data_ptr(), d_a.data_ptr(), sem=3)
     assert "instance" in str(e.value)
     torch.cuda.synchronize()
+    # the frame entry point (one dispatch in the reference; two launches here for a two-level scene) and the AO batch carry
+    # the instance ids themselves - same records and ids as above; without the id buffer the frame refuses as well
+    d_pi = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    d_ai = torch.zeros(2 * w * h, dtype=torch.int32, device="cuda")
+    d_a2 = torch.zeros(2 * w * h, dtype=torch.int64, device="cuda")
+    with pytest.raises(trx.TrxError) as e:
+        sc.trace_frame_dev(view, w, h, d_p.data_ptr(), d_a.data_ptr(), sem=3, frame=3, ao_eps=0.01)
+    assert "instance" in str(e.value)
+    sc.trace_frame_dev(view, w, h, d_p.data_ptr(), d_a.data_ptr(), sem=3, frame=3, ao_eps=0.01, d_primary_inst=d_pi.data_ptr(),
+                       d_ao_inst=d_ai.data_ptr())
+    sc.trace_ao_batch_dev(view, w, h, d_p.data_ptr(), d_a2.data_ptr(), w * h, 2, sem=3, frame0=3, ao_eps=0.01,
+                          d_primary_inst=d_pi.data_ptr(), d_ao_inst=d_ai.data_ptr())
+    torch.cuda.synchronize()
+    sc.check()
+    from tray_racing_amd import dist as D
+    assert_hits_equal(D.int64_to_hits(d_p), wp, "instanced frame, primary")
+    assert_hits_equal(D.int64_to_hits(d_a), wao, "instanced frame, AO")
+    assert_hits_equal(D.int64_to_hits(d_a2[: w * h]), wao, "instanced AO batch, frame 0")
+    assert (d_pi.cpu().numpy().view(np.uint32) == wpi).all() and (d_ai[: w * h].cpu().numpy().view(np.uint32) == waoi).all()
+    wao4, waoi4, _ = osc.trace_ao_inst(ov, w, h, wp, wpi, sem=3, frame=4, ao_eps=0.01)
+    assert_hits_equal(D.int64_to_hits(d_a2[w * h:]), wao4, "instanced AO batch, frame 1")
+    assert (d_ai[w * h:].cpu().numpy().view(np.uint32) == waoi4).all()
     sc.close()
 
 
