@@ -123,3 +123,25 @@ def test_default_arguments_finish_in_minutes():
         sys.argv = argv
     assert a.gpus == 1 and a.steps * 0.5e-3 < 5 and a.warmup < a.steps and a.cpu_seconds <= 30
     assert mod.baseline_metric() == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+
+
+def test_bench_starts_its_own_ranks_and_relays_their_failure():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two ranks through torch.distributed.run
+    before it touches the GPU and relays the launcher's return code.  Without a GPU every rank stops at "no HIP device"
+    (libtrx.so has no CPU fallback), so here the relayed code is a failure - and the parent neither hangs nor prints a
+    bench line.  (With a GPU the same command is tests/test_gpu_parity.py::test_bench_launches_its_own_ranks.)"""
+    import subprocess
+    import sys
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present: covered by the GPU suite")
+    except ImportError:
+        pytest.skip("no torch")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tris", "2000",
+                          "--width", "64", "--height", "64", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert "no HIP device" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+

@@ -606,6 +606,26 @@ def test_full_size_config(trx, orc, name, w, h, tlas):
     assert (bits(scaled["t"][same]) == bits(base["t"][same] * np.float32(s))).all()
 
 
+def test_full_size_bistro_one_launch_frame(trx, orc):
+    """configs[2] at full size through trx_trace_frame_dev (the reference's single dispatch: primary ray, then the AO ray of
+    every hit pixel in place): both hit buffers of the 1920x1080 frame against the oracle, bit for bit."""
+    import torch
+    from tray_racing_amd import dist as D
+    w, h = 1920, 1080
+    flat, view, osc, ov = make_scene(trx, orc, "bistro", 0, w, h)
+    sc = trx.Scene(flat)
+    d_p = torch.full((w * h,), -1, dtype=torch.int64, device="cuda")
+    d_a = torch.full((w * h,), -1, dtype=torch.int64, device="cuda")
+    sc.trace_frame_dev(view, w, h, d_p.data_ptr(), d_a.data_ptr(), sem=3, frame=1, ao_eps=0.01)
+    torch.cuda.synchronize()
+    sc.check()
+    op, _ = osc.trace_primary(ov, w, h, sem=3)
+    oa, _ = osc.trace_ao(ov, w, h, op, sem=3, frame=1, ao_eps=0.01)
+    assert_hits_equal(D.int64_to_hits(d_p), op, "bistro one-launch frame, primary")
+    assert_hits_equal(D.int64_to_hits(d_a), oa, "bistro one-launch frame, ao")
+    sc.close()
+
+
 def test_full_size_hairball_4spp_whole_frames(trx, orc):
     """configs[3]: hairball-class at 1920x1080, primary + the four AO frames ("4 spp" = frame seeds 0..3), every pixel
     of every frame against the oracle."""
