@@ -135,14 +135,15 @@ struct TraceParams {
     uint32_t waves_per_block;        // 1, 2 or 4
     uint32_t merge;                  // 2 waves per workgroup, incoherent BLAS pass: the second wave may hand its last rays to the first (kernels.hip, drain)
     unsigned long long *wave_times;  // diagnostics: [8*wave] start, [8*wave+1] end (wall_clock64), [+2..7] phase cycles in TRX_STAMPS builds; or null
-    // frames per launch (image modes): frame f = local_tile / tiles_per_frame uses views[f] and writes its
-    // records at out + f * frame_stride; one launch then balances n_frames x the tiles
     FbState *fb;          // image passes with tile-order feedback: the schedule tuner's state (null = feedback always on)
     uint32_t exp_exact;   // every exponent byte of the scene's nodes is 0 or >= 21: e / d may be computed as e * (1/d) exactly (kernels.hip, pow2)
-    uint32_t no_order;    // ignore the lists of the previous frame (they are emptied as usual): first frame of an image geometry
+    uint32_t no_order;    // ignore the order on file (this frame files a new one): first frame of an image geometry
     uint32_t new_view;    // camera cut: the schedule tuner starts over
     uint32_t uni_decode;  // coherent primary walk: decode the child planes of a node step once per wave when every lane visits the same node
     uint32_t any_hit;     // explicit rays only: stop at the first accepted hit, write one byte (0/1) per ray
+    // frames per launch: primary passes - frame f = local_tile / tiles_per_frame uses views[f]; AO passes - one view
+    // (views[0]) and one primary buffer, frame f uses the noise seed frame + f (a tile's seeds are consecutive tickets of
+    // one queue); either way frame f writes its records at out + f * frame_stride
     uint32_t n_frames, tiles_per_frame, frame_stride;
     ViewDev views[kMaxBatchFrames];
 };

@@ -2,7 +2,7 @@
 //
 // One persistent wave = 64 ray slots.  Waves pull 64-item chunks (an 8x8 pixel
 // tile, or 64 explicit rays) from one work queue per XCD, heaviest tiles first
-// (order learnt from the previous frame's measured tile times), traverse with a
+// (order filed by the first frame of a view from each tile's measured work), traverse with a
 // per-lane stack striped through LDS (entry i of lane l at [i*64 + l]:
 // conflict-free ds_write_b64/ds_read_b64) that spills to HBM past kLdsStack
 // entries, and run the triangle tests of a node step cooperatively: the wave's
@@ -682,13 +682,14 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // Work is cut into chunks of 64 items (one 8x8 tile, or 64 explicit rays).  Chunk p belongs
     // to queue p % 8 (ticket k of queue q is chunk 8k + q); a wave pulls from the queue of the XCD
     // it runs on (one atomic head per XCD: a single head saturates near 90 dequeues/us) and
-    // steals from the other queues when its own runs dry.  The next ticket is requested as soon
-    // as the current one is taken, so the atomic's round trip overlaps the traversal.
+    // steals from the other queues when its own runs dry.  The next ticket is taken when it is needed
+    // (heavy tiles, passes without an order) or a tile ahead (light tiles of an ordered frame), see below.
     //
-    // Tile order feedback: a wave that finishes a tile files it in one of 16 cost buckets
-    // (sqrt(2)-wide classes of the tile's traversal-loop trips; its wall-clock time until round 3) of the NEXT frame's lists; this frame
-    // reads the lists the previous frame wrote, heaviest bucket first, so chunk p is the p-th
-    // heaviest tile (longest-processing-time-first) and every queue starts with heavy tiles.
+    // Tile order: a wave that finishes a tile of a LEARNING frame (the first frame of a view; every frame of
+    // a moving camera) files it in one of 16 cost buckets (sqrt(2)-wide classes of the tile's traversal-loop
+    // trips) of the other list set; a frame reads the set on file heaviest bucket first, so chunk p is the p-th
+    // heaviest tile (longest-processing-time-first) and every queue starts with heavy tiles - and while the
+    // view stays the same it reads that set unchanged and files nothing (`frozen`, below).
     const uint32_t n_chunks = (P.n_items + 63u) >> 6;
     uint32_t my_q = P.single_queue ? 0u : (read_xcc_id() & 7u);
     uint32_t q_probes = 0;
