@@ -26,6 +26,8 @@ def test_no_product_kernel_spills_or_exceeds_128_vgprs():
         seen += 1
         if count:
             continue  # the counting kernels (diagnostics, trx_count_*) may spill: they are never timed
+        # (<= 128 VGPRs = four waves to a SIMD for EVERY variant: the persistent grid is sized from one variant per TLAS
+        # flavour, trace_grid_size, and must be resident whichever variant is launched)
         assert vgpr <= 128, "k_trace<mode %d, tlas %d, node %d, pipe %d>: %d VGPRs" % (mode, tlas, node, pipe, vgpr)
         assert scratch == 0, "k_trace<mode %d, tlas %d, node %d, pipe %d> spills %d bytes" % (mode, tlas, node, pipe, scratch)
     assert seen >= 3 * 2 * 4, "kernel metadata not found (%d kernels)" % seen

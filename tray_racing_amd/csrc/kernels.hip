@@ -2104,7 +2104,9 @@ int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count) {
     (void)count;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-    // occupancy of the variants is within one wave of each other; query one per TLAS flavour
+    // Every product variant is held to <= 128 VGPRs without scratch (tests/test_kernel_resources.py) and owns the same
+    // kLdsBytesPerWave of LDS, so all of them fit four waves to a SIMD (16 to a CU: 16 x 10 176 B of the 160 KB): the
+    // grid sized from one variant per TLAS flavour is resident for every variant, whatever the workgroup shape
     int per_cu = tlas ? occupancy_one<kModePrimary, true, 1, false, false>() : occupancy_one<kModePrimary, false, 1, false, false>();
     if (per_cu <= 0) per_cu = 8;
     if (per_cu > 32) per_cu = 32;
