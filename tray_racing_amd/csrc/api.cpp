@@ -424,6 +424,13 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
 #endif
     p.n_tris = (uint32_t)s->n_tris;
     p.n_nodes = (uint32_t)s->n_nodes;
+    {   // (kernels.hip, div_uniform)
+        auto rcp32 = [](uint32_t d) -> uint32_t { return d <= 1u ? 0xffffffffu : (uint32_t)((1ull << 32) / d); };
+        p.rcp_tiles_x = rcp32(p.tiles_x);
+        p.rcp_width = rcp32(p.width);
+        p.rcp_tiles_per_frame = rcp32(p.tiles_per_frame);
+        p.rcp_n_frames = rcp32(p.n_frames);
+    }
     {   // tuning: variant bits 25..27 = compaction threshold (0 = default, 7 = never); bit 28 = no thin waves (A/B runs)
         const uint32_t c = (variant >> 25) & 0x7u;
         p.thin_max = ((variant >> 28) & 1u) ? 0u : 8u;

@@ -145,6 +145,9 @@ struct TraceParams {
     // (views[0]) and one primary buffer, frame f uses the noise seed frame + f (a tile's seeds are consecutive tickets of
     // one queue); either way frame f writes its records at out + f * frame_stride
     uint32_t n_frames, tiles_per_frame, frame_stride;
+    // floor(2^32 / d) of the four launch-uniform divisors the refill divides by (kernels.hip, div_uniform): filled in by
+    // enqueue(); left to the compiler each division keeps its reciprocal in a VECTOR register for the whole kernel
+    uint32_t rcp_tiles_x, rcp_width, rcp_tiles_per_frame, rcp_n_frames;
     ViewDev views[kMaxBatchFrames];
 };
 

@@ -525,6 +525,37 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// x / d for a launch-uniform d whose m = floor(2^32 / d) comes with the launch parameters (m = 2^32 - 1 for d <= 1): the
+// estimate mulhi(x, m) is x / d or one less for every 32-bit x, one correction step makes it exact.  (A division left to
+// the compiler computes the same kind of reciprocal on the vector unit and keeps it in a vector register across the
+// whole walk - four of them in the refill of kernels that sit at the register budget.)
+__device__ __forceinline__ uint32_t div_uniform(uint32_t x, uint32_t d, uint32_t m) {
+    const uint32_t q = __umulhi(x, m);
+    return x - q * d >= d ? q + 1u : q;
+}
+
+// The kernel arguments, through a pointer whose origin the compiler cannot see (k_trace's refill): loads through it
+// are scalar loads from the kernel-argument segment that stay where they are written.
+__device__ __forceinline__ const TraceParams *refill_params() {
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    zero = __builtin_amdgcn_readfirstlane(zero); // (tells the compiler what the constraint cannot: wave-uniform)
+    return (const TraceParams *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + zero);
+}
+
+// The LDS part of the per-lane stacks is addressed through an explicit LDS (address space 3) pointer.  A pop reads either
+// LDS or, past kLdsStack entries, HBM: as two loads through generic pointers of the same shape the optimizer merges them
+// into ONE load of a selected address - a flat load on the walk's hot path, which also waits for every node record
+// requested ahead (vmcnt).  Round 4 shipped that for a while: AO passes +8-10 %, profiles/r04_flat_stack_pop.log.
+// tests/test_kernel_resources.py holds the line (no flat_load_dwordx2 in any trace kernel).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+__device__ __forceinline__ uint2 lds_ld(const lds_u32x2 *p) {
+    const u32x2 v = *p;
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void lds_st(lds_u32x2 *p, uint2 e) { *p = u32x2{e.x, e.y}; }
+
 // Appends the parked {tile, list} entries to the next frame's tile lists.  A wave files all its tiles of a class under one
 // shard, so its entries fall into a few groups (one per class it met); the first lane of a group claims the group's
 // slots with ONE returning atomic, the groups' atomics go out together, and every lane stores its tile at its rank
@@ -593,7 +624,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     };
 #define wave_global (wave_id())
     char *const lds_wave = reinterpret_cast<char *>(lds_dyn) + wave_in_block * kLdsBytesPerWave;
-    uint2 *const lds_stack = reinterpret_cast<uint2 *>(lds_wave);                          // [kLdsStack][64]
+    lds_u32x2 *const lds_stack =                                                           // [kLdsStack][64], see lds_u32x2
+        (lds_u32x2 *)((__attribute__((address_space(3))) char *)lds_dyn + wave_in_block * kLdsBytesPerWave);
     float4 *const lds_ray = reinterpret_cast<float4 *>(lds_wave + kLdsStack * kWave * 8);  // [64][2]: o,tmin | d
     uint2 *const lds_grp = reinterpret_cast<uint2 *>(lds_ray + 2 * kWave);                 // [64] triangle group of the lane
     uint2 *const lds_res = lds_grp + kWave;                                                // [64] {tt bits, triangle}
@@ -653,7 +685,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // they run 2.5-4 % faster than with it off, but the kernel that contains the code is 3 % slower on the 4K two-level AO pass than the
     // kernel that does not, profiles/r03_drain_merge.log - the code for it stays below, compiled out.)
     // Thin waves (incoherent single-level passes, queues dry, at most P.thin_max rays left): two, four, eight lanes to a ray, see thin_walk.
+#ifdef TRX_NO_THIN_CODE // (A/B builds: the kernels without the thin walk's code at all)
+    constexpr bool kThin = false;
+#else
     constexpr bool kThin = !TLAS && MODE != kModePrimary && !COUNT;
+#endif
     bool go_thin = false; // wave-uniform
     constexpr bool kMerge = !TLAS && MODE != kModePrimary && MODE != kModeFused && !COUNT;
     constexpr uint32_t kMergeWords = TLAS ? 31u : 21u, kMergeMax = TLAS ? 32u : 48u, kMergeClosed = 0xffffffffu;
@@ -710,13 +746,15 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     bool ordered = false;
     // The feedback machinery tunes itself (exit protocol below): a slot whose frames measured faster WITHOUT it runs without
     // it - natural order, no tile timing, no list appends - until the next re-evaluation.  Every wave reads the same word.
-    const uint32_t fb_mode = (P.fb != nullptr && !P.new_view) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)P.fb->mode) : 0u;
+    // (the host files an order for primary and one-seed AO passes only: explicit-ray batches and one-launch frames carry none of this)
+    constexpr bool kOrder = MODE != kModeRays;
+    const uint32_t fb_mode = (kOrder && P.fb != nullptr && !P.new_view) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)P.fb->mode) : 0u;
     const bool fb_off = fb_mode != 0u;
     // (mode 2: a frame whose tiles are ragged - a few rays of a tile run ten times longer than the rest - keeps its lanes
     // busier by replacing finished rays mid-tile; one frame per launch only, the frame of a batch is taken from whole tiles)
     constexpr uint32_t kFbRefill = 16u;
     const uint32_t refill_idle = (fb_mode == 2u && P.n_frames == 1u) ? kFbRefill : P.refill_idle;
-    if (P.fb && wave_global == 0u && lane == 0u) P.fb->t0 = wall_clock64(); // (about when the frame's first waves start)
+    if (kOrder && P.fb && wave_global == 0u && lane == 0u) P.fb->t0 = wall_clock64(); // (about when the frame's first waves start)
     // The order lives in one of two list sets; the word *lpt_sel (flipped by the exit wave of a frame that filed a new
     // order) says which one is read.  The other set is empty and takes what this frame files - unless the frame finds a
     // COMPLETE order and its views are the previous frame's (same_view): then the order is frozen - replayed as it is, no
@@ -725,10 +763,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // concatenate them again, a permutation with short cycles: frame times settle over 10-30 frames or alternate between
     // two values 5 % apart - while the order filed by the very FIRST frame of a view, frozen, runs 1 % faster than the
     // settled one from its second frame on (bistro-class frame 0.420 against 0.425 ms; the filing machinery is off too).
-    const uint32_t lpt_rd = (P.lpt_sets != nullptr && __builtin_amdgcn_readfirstlane((int)*P.lpt_sel) != 0) ? P.lpt_set_words : 0u;
+    const bool have_lists = kOrder && P.lpt_sets != nullptr;
+    const uint32_t lpt_rd = (have_lists && __builtin_amdgcn_readfirstlane((int)*P.lpt_sel) != 0) ? P.lpt_set_words : 0u;
     uint32_t *const rd_set = P.lpt_sets + lpt_rd, *const wr_set = P.lpt_sets + (P.lpt_set_words - lpt_rd);
     const uint32_t *const rd_lists = rd_set + 16u * kLptShards;
-    if (P.lpt_sets && !fb_off && !P.no_order) {
+    if (have_lists && !fb_off && !P.no_order) {
         end_a = rd_set[(15u - (lane >> 3)) * kLptShards + (lane & 7u)];
         end_b = rd_set[(15u - ((lane + 64u) >> 3)) * kLptShards + (lane & 7u)];
         // a list that overflowed its capacity dropped entries: fall back to the natural order
@@ -747,7 +786,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 #ifdef TRX_DEV_TUNE
     if (P.tune & 0x400u) frozen = false; // (A/B: the order is rewritten by every frame, as until round 3)
 #endif
-    const bool lpt_write = P.lpt_sets != nullptr && !fb_off && !frozen;
+    // (through readfirstlane: a wave-uniform flag that lives to the epilogue belongs in a scalar register)
+    const bool lpt_write = __builtin_amdgcn_readfirstlane((have_lists && !fb_off && !frozen) ? 1 : 0) != 0;
 
     // Chunks below this index of the heaviest-first order take their successor's ticket LATE (when the wave is idle), the
     // rest a tile ahead (hides the atomic's 1-2 us round trip, which only matters next to a tile of a few us).  Round 2
@@ -787,12 +827,12 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     auto stack_push = [&](uint2 e, bool cond) {
         if (__builtin_expect(__ballot(sp >= (uint32_t)kLdsStack) != 0ull, 0)) {
             if (cond) {
-                if (sp < (uint32_t)kLdsStack) lds_stack[sp * kWave + lane] = e;
+                if (sp < (uint32_t)kLdsStack) lds_st(&lds_stack[sp * kWave + lane], e);
                 else if (sp < (uint32_t)(kLdsStack + kSpillStack)) spill[(sp - kLdsStack) * kWave + lane] = e;
                 else overflow = 1u;
             }
         } else {
-            lds_stack[sp * kWave + lane] = e;
+            lds_st(&lds_stack[sp * kWave + lane], e);
         }
         sp += cond ? 1u : 0u;
         if (COUNT) c_maxsp = max(c_maxsp, sp);
@@ -800,11 +840,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     auto stack_pop = [&]() -> uint2 { // callers guarantee sp != 0
         sp--;
         if (__builtin_expect(__ballot(sp >= (uint32_t)kLdsStack) != 0ull, 0)) {
-            if (sp < (uint32_t)kLdsStack) return lds_stack[sp * kWave + lane];
+            if (sp < (uint32_t)kLdsStack) return lds_ld(&lds_stack[sp * kWave + lane]);
             if (sp < (uint32_t)(kLdsStack + kSpillStack)) return spill[(sp - kLdsStack) * kWave + lane];
             return make_uint2(0u, 0u);
         }
-        return lds_stack[sp * kWave + lane];
+        return lds_ld(&lds_stack[sp * kWave + lane]);
     };
 
     // Finished ray: the hit record (or the any-hit flag) leaves the lane.
@@ -899,10 +939,14 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             const uint32_t sp_src = (uint32_t)__shfl((int)sp, src);
             uint32_t sp_max = owner ? sp_src : 0u;
             for (int off = 32; off > 0; off >>= 1) sp_max = max(sp_max, (uint32_t)__shfl_xor((int)sp_max, off));
+            // (the destination address is formed HERE: left alone the compiler forms it at kernel start and the one-launch
+            // frame, at the register budget, spills it)
+            uint32_t dst = lane;
+            asm volatile("" : "+v"(dst));
             for (uint32_t k = 0; k < sp_max; k++) { // (entries beyond a ray's own top are copied too: harmless)
-                const uint2 e = lds_stack[k * kWave + (uint32_t)src];
+                const uint2 e = lds_ld(&lds_stack[k * kWave + (uint32_t)src]);
                 __builtin_amdgcn_wave_barrier();
-                if (owner) lds_stack[k * kWave + lane] = e;
+                if (owner) lds_st(&lds_stack[k * kWave + dst], e);
                 __builtin_amdgcn_wave_barrier();
             }
             sp = owner ? sp_src : 0u;
@@ -1197,7 +1241,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         // seeds of a tile are consecutive tickets of ONE queue, so the same XCD walks the same origins
                         // through the same upper nodes n_frames times over; a tile id past the image is the padding of
                         // the last group of eight tiles (every queue has the same number of tickets)
-                        const uint32_t tq = ticket / P.n_frames;
+                        const uint32_t tq = div_uniform(ticket, P.n_frames, P.rcp_n_frames);
                         cur_vf = ticket - tq * P.n_frames;
                         cur_tile = P.single_queue ? tq : tq * 8u + my_q;
                         if (cur_tile >= P.tiles_per_frame) {
@@ -1263,41 +1307,52 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     out_index = item;
                     ok = true;
                 } else {
+                    // The launch parameters only a refill needs - the view, the image geometry, the primary hits - are read from
+                    // the kernel-argument segment HERE, through a pointer the compiler cannot trace back to it: left alone it
+                    // loads them once, ahead of the walk, and the walk then carries (or spills to vector-register lanes) some
+                    // forty scalar registers it never reads.
+                    // (Where refills are whole tiles - primary rays, a wave refills a few times per frame - or the kernel sits at
+                    // the register budget; the single-level AO pass refills whenever sixteen lanes idle and would wait on
+                    // these loads thirty times as often: +5 % measured, profiles/r04_ab_procs.log.)
+                    constexpr bool kReload = MODE == kModePrimary || MODE == kModeFused || TLAS;
+                    const TraceParams &R = kReload ? *refill_params() : P;
                     // whole-tile refills only when frames are batched, so the frame is wave-uniform
-                    uint32_t local_tile = my_tile, frame_base = 0u, vf = 0u, seed = P.frame;
+                    uint32_t local_tile = my_tile, frame_base = 0u, vf = 0u, seed = R.frame;
                     if (MODE == kModeAo) {
                         // an AO batch shares its view and its primary hits; the lanes of a wave may hold different seeds
                         // (mid-tile refills stay on), so nothing here is wave-uniform
-                        if (P.n_frames > 1u) {
-                            frame_base = my_vf * P.frame_stride;
+                        if (R.n_frames > 1u) {
+                            frame_base = my_vf * R.frame_stride;
                             seed += my_vf;
                         }
-                    } else if (P.n_frames > 1u) {
-                        vf = __builtin_amdgcn_readfirstlane(my_tile / P.tiles_per_frame);
-                        local_tile = my_tile - vf * P.tiles_per_frame;
-                        frame_base = vf * P.frame_stride;
+                    } else if (R.n_frames > 1u) {
+                        vf = __builtin_amdgcn_readfirstlane(div_uniform(my_tile, R.tiles_per_frame, R.rcp_tiles_per_frame));
+                        local_tile = my_tile - vf * R.tiles_per_frame;
+                        frame_base = vf * R.frame_stride;
                     }
-                    const ViewDev &view = P.views[vf];
+                    const ViewDev &view = R.views[vf];
                     uint32_t px, py;
                     if (conv) {
                         // the pixel this lane's primary ray belonged to, back from its record index
-                        if (P.compact) {
-                            const uint32_t tile = (out_index >> 6) * P.shard_count + P.shard_index, k = out_index & 63u;
-                            px = (tile % P.tiles_x) * 8u + (k & 7u);
-                            py = (tile / P.tiles_x) * 8u + (k >> 3);
+                        if (R.compact) {
+                            const uint32_t tile = (out_index >> 6) * R.shard_count + R.shard_index, k = out_index & 63u;
+                            const uint32_t ty = div_uniform(tile, R.tiles_x, R.rcp_tiles_x);
+                            px = (tile - ty * R.tiles_x) * 8u + (k & 7u);
+                            py = ty * 8u + (k >> 3);
                         } else {
-                            py = out_index / P.width;
-                            px = out_index - py * P.width;
+                            py = div_uniform(out_index, R.width, R.rcp_width);
+                            px = out_index - py * R.width;
                         }
                     } else {
-                        const uint32_t tile = local_tile * P.shard_count + P.shard_index;
+                        const uint32_t tile = local_tile * R.shard_count + R.shard_index;
                         const uint32_t k = item & 63u;
-                        px = (tile % P.tiles_x) * 8u + (k & 7u);
-                        py = (tile / P.tiles_x) * 8u + (k >> 3);
-                        if (px < P.width && py < P.height) out_index = frame_base + (P.compact ? local_tile * 64u + k : py * P.width + px);
+                        const uint32_t ty = div_uniform(tile, R.tiles_x, R.rcp_tiles_x);
+                        px = (tile - ty * R.tiles_x) * 8u + (k & 7u);
+                        py = ty * 8u + (k >> 3);
+                        if (px < R.width && py < R.height) out_index = frame_base + (R.compact ? local_tile * 64u + k : py * R.width + px);
                     }
-                    if (px < P.width && py < P.height) {
-                        primary_dir(view, P.width, P.height, px, py, dx, dy, dz);
+                    if (px < R.width && py < R.height) {
+                        primary_dir(view, R.width, R.height, px, py, dx, dy, dz);
                         if (MODE == kModePrimary || (kFused && !conv)) {
                             r.ox = view.eye[0]; r.oy = view.eye[1]; r.oz = view.eye[2];
                             if (kFused) is_ao = false;
@@ -1309,17 +1364,17 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                                 ph.prim = prim;
                                 is_ao = true;
                             } else {
-                                ph = P.primary[out_index - frame_base];
+                                ph = R.primary[out_index - frame_base];
                             }
                             if (ph.t < TRX_F32_MAX && ph.prim != TRX_INVALID) {
                                 // normal of the hit triangle, flipped toward the viewer
                                 const float4 *tp = P.tris + (size_t)ph.prim * 3;
                                 float nx = tp[0].w, ny = tp[1].w, nz = tp[2].w; // cross(e1, e2)
-                                if (TLAS && P.inst_xform) {
+                                if (TLAS && R.inst_xform) {
                                     // object-space normal -> world: transpose of world-to-object
-                                    const uint32_t pi = kFused ? hit_inst : P.primary_inst[out_index - frame_base];
+                                    const uint32_t pi = kFused ? hit_inst : R.primary_inst[out_index - frame_base];
                                     if (pi != TRX_INVALID) {
-                                        const float4 *m = P.inst_xform + (size_t)pi * 3;
+                                        const float4 *m = R.inst_xform + (size_t)pi * 3;
                                         const float4 r0 = m[0], r1 = m[1], r2 = m[2];
                                         const float ax = (r0.x * nx + r1.x * ny) + r2.x * nz;
                                         const float ay = (r0.y * nx + r1.y * ny) + r2.y * nz;
@@ -1332,9 +1387,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                                 const float nd = (nx * -dx + ny * -dy) + nz * -dz;
                                 const float sg = copysignf(1.0f, nd);
                                 nx *= sg; ny *= sg; nz *= sg;
-                                r.ox = (view.eye[0] + dx * ph.t) - dx * P.ao_eps;
-                                r.oy = (view.eye[1] + dy * ph.t) - dy * P.ao_eps;
-                                r.oz = (view.eye[2] + dz * ph.t) - dz * P.ao_eps;
+                                r.ox = (view.eye[0] + dx * ph.t) - dx * R.ao_eps;
+                                r.oy = (view.eye[1] + dy * ph.t) - dy * R.ao_eps;
+                                r.oz = (view.eye[2] + dz * ph.t) - dz * R.ao_eps;
                                 const float u1 = hash_noise(px, py, seed);
                                 const float u2 = hash_noise(px, py, seed + 1024u);
                                 const float rr = sqrtf(u1);
@@ -1615,7 +1670,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     wdx = __uint_as_float(m[28]); wdy = __uint_as_float(m[29]); wdz = __uint_as_float(m[30]);
                 }
                 const uint32_t from = m[20];
-                for (uint32_t k = 0; k < sp; k++) lds_stack[k * kWave + lane] = merge_stack1[k * kWave + from];
+                for (uint32_t k = 0; k < sp; k++) lds_st(&lds_stack[k * kWave + lane], merge_stack1[k * kWave + from]);
                 lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
                 lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
                 fetched = false;
@@ -1863,6 +1918,13 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 if (!(P.tune & 0x10000000u)) // (A/B: no priority by ray age)
 #endif
                 if (!TLAS && MODE != kModePrimary && (trip & 7u) == 0u) old_ray_priority(); // (measured without effect in the two-level kernels)
+                // The fetched node record lives from (1) to (4) of ONE trip and is deliberately left uninitialised here:
+                // carried across trips (a variable of the kernel, as it was) the five loads merge with the previous
+                // trip's values, the register allocator is free to land them in scratch registers and copy them home at
+                // once - and that copy waits for the loads thirteen instructions after they were issued instead of a
+                // triangle phase later.  Round 4 shipped that for a while (AO passes +5-8 %): tests/test_kernel_resources.py
+                // now measures the distance from the fetch to the first wait in the compiled walk.
+                uint4 fn0, fn1, fn2, fn3, fn4;
                 // (1)
                 if (act && !fetched && (cur.y & 0xff000000u)) {
                     const uint32_t hits_imask = cur.y;
@@ -1873,7 +1935,12 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
                     const uint32_t node_index = child_base + rel;
                     const uint4 *np = P.nodes + (size_t)node_index * 5;
-                    pn0 = np[0]; pn1 = np[1]; pn2 = np[2]; pn3 = np[3]; pn4 = np[4];
+                    fn0 = np[0]; fn1 = np[1]; fn2 = np[2]; fn3 = np[3];
+                    {   // (the last 16 bytes as two 8-byte loads: pairs of registers are easier to keep than a fifth quadruple)
+                        const uint2 *h = reinterpret_cast<const uint2 *>(np + 4);
+                        const uint2 a = h[0], b = h[1];
+                        fn4 = make_uint4(a.x, a.y, b.x, b.y);
+                    }
                     stack_push(cur, (cur.y & 0xff000000u) != 0u); // after the loads are on their way
                     fetched = true;
                     if (COUNT) {
@@ -1910,10 +1977,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 TRX_STAMP(k_pop);
                 // (4)
                 if (fetched) {
-                    const uint32_t hitmask = node_intersect<NODE>(r, t, pn0, pn1, pn2, pn3, pn4, pow2);
-                    cur.x = pn1.x;
-                    ptri.x = pn1.y;
-                    cur.y = (hitmask & 0xff000000u) | (pn0.w >> 24);
+                    const uint32_t hitmask = node_intersect<NODE>(r, t, fn0, fn1, fn2, fn3, fn4, pow2);
+                    cur.x = fn1.x;
+                    ptri.x = fn1.y;
+                    cur.y = (hitmask & 0xff000000u) | (fn0.w >> 24);
                     ptri.y = hitmask & 0x00ffffffu;
                     fetched = false;
                     if ((cur.y & 0xff000000u) == 0u && sp != 0u) {
@@ -1983,7 +2050,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 for (uint32_t b = 0; b < 16u * kLptShards; b++) atomicExch(&rd_set[b], 0u);
                 atomicExch(P.lpt_sel, lpt_rd ? 0u : 1u);
             }
-            if (P.fb) {
+            if (kOrder && P.fb) {
                 // Which schedule suits this slot's frames?  The tile-order feedback costs about 2 us a tile (timing, the list
                 // look-up behind the queue atomic, the appends) and repays that many times over where a few tiles set the
                 // frame's critical path - not on a room seen from inside (the kitchen-class frame runs 13 % faster without
