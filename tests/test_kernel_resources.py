@@ -73,4 +73,4 @@ def test_stack_pops_are_lds_reads_and_the_node_fetch_is_not_waited_for_at_once()
             n += _is_inst(l)
         assert n >= 100, what + ": the node fetch is waited for after %d instructions" % n
         pipes += 1
-    assert pipes == 2 * 4   # AO and explicit rays, four node-test semantics
+    assert pipes == 3 * 4   # AO, explicit rays and the one-launch frame, four node-test semantics

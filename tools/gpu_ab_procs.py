@@ -55,8 +55,18 @@ def child(scenes, variant):
         a_min, a_med = batches(lambda i: sc.trace_ao_dev(view, w, h, prim.data_ptr(), ao.data_ptr(), sem=3, frame=i, ao_eps=0.01))
         r_min, r_med = batches(lambda i: sc.trace_rays_dev(d_rays.data_ptr(), len(rays), hits.data_ptr(), sem=3))
         p_min, p_med = batches(lambda i: sc.trace_primary_dev(view, w, h, prim.data_ptr(), sem=3), warm=140)
-        lib.trx_set_kernel_variant(0)
         out[name] = {"ao": a_med, "ao_min": a_min, "rays": r_med, "rays_min": r_min, "primary": p_med, "primary_min": p_min}
+        if hasattr(lib, "trx_trace_frame_dev"):   # the reference-style frame: two launches / one launch; 4 spp in one launch
+            prim1 = torch.zeros(w * h, dtype=torch.int64, device="cuda")
+            ao4 = torch.zeros(4 * w * h, dtype=torch.int64, device="cuda")
+
+            def two(i):
+                sc.trace_primary_dev(view, w, h, prim.data_ptr(), sem=3)
+                sc.trace_ao_dev(view, w, h, prim.data_ptr(), ao.data_ptr(), sem=3, frame=i, ao_eps=0.01)
+            out[name]["frame2"] = batches(two)[1]
+            out[name]["frame1"] = batches(lambda i: sc.trace_frame_dev(view, w, h, prim1.data_ptr(), ao.data_ptr(), sem=3, frame=i, ao_eps=0.01))[1]
+            out[name]["ao4"] = batches(lambda i: sc.trace_ao_batch_dev(view, w, h, prim.data_ptr(), ao4.data_ptr(), w * h, 4, sem=3, frame0=4 * i, ao_eps=0.01), per=4)[1]
+        lib.trx_set_kernel_variant(0)
         sc.close()
     print("AB_CHILD " + json.dumps(out), flush=True)
 
@@ -89,9 +99,10 @@ def main():
                 return 1
             res[l].append(json.loads(line[0][9:]))
             print("round %d %-8s " % (r, l) + "  ".join("%s ao %.3f rays %.3f prim %.4f" % (s, v["ao"], v["rays"], v["primary"]) for s, v in res[l][-1].items()), flush=True)
+    keys = ["ao", "rays", "primary"] + [k for k in ("frame2", "frame1", "ao4") if all(k in x[s] for l in libs for x in res[l] for s in x)]
     print("\nmedian over %d processes [min .. max] of each process's median batch (ms per launch)" % rounds)
     for s in scenes.split(","):
-        for key in ("ao", "rays", "primary"):
+        for key in keys:
             row = []
             for l in libs:
                 v = [x[s][key] for x in res[l]]

@@ -2138,9 +2138,8 @@ hipError_t launch_mode(const TraceParams &p, bool tlas, int node, bool count, bo
         if (count) return launch_node<MODE, true, false, true>(p, node, grid, stream);
         return launch_node<MODE, true, false, false>(p, node, grid, stream);
     }
-    // (coherent primary rays do not gain from the pipelined walk; the one-launch frame with it and
-    // the thin-wave code spills)
-    if constexpr (MODE != kModePrimary && MODE != kModeFused) {
+    // (coherent primary rays do not gain from the pipelined walk)
+    if constexpr (MODE != kModePrimary) {
         if (pipe) {
             if (count) return launch_node<MODE, false, true, true>(p, node, grid, stream);
             return launch_node<MODE, false, true, false>(p, node, grid, stream);
