@@ -172,12 +172,15 @@ __device__ __forceinline__ uint32_t node_intersect(const Ray &r, float max_dista
 
 // The same test over child planes that were converted to floats ONCE for the wave (a wave-uniform node step: every
 // lane visits the same node, so the 48 byte-to-float conversions and the 12 near / far selects of the per-lane test are
-// the same work 64 times over).  dec = [6 planes: min_x max_x min_y max_y min_z max_z][8 children] floats in LDS; a lane
-// picks its near and far plane of an axis by ADDRESS (the sign of its direction) and reads four children at a time -
-// every lane of a sign class reads the same 16 bytes, which LDS broadcasts.  Same values, same operations, same mask.
+// the same work 64 times over).  Two tables in LDS, [3 axes][8 children][2]: dec_pos holds {min, max} of a child's
+// axis, dec_neg {max, min}; a lane picks the table of an axis by ADDRESS (the sign of its direction: the near plane is
+// the max plane when the direction is negative) and reads two children at a time - every lane of a sign class reads
+// the same 16 bytes, which LDS broadcasts - so that each {near, far} pair arrives in the two consecutive registers the
+// packed arithmetic of plane2 wants.  (Until round 4 the table was plane-major and the pairs were put together with
+// two register moves each: 37 moves in a 178-instruction test.)  Same values, same operations, same mask.
 template <int NODE>
 __device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_distance, const uint4 n0, const uint4 n1,
-                                                       const float *dec, const bool pow2) {
+                                                       const float *dec_pos, const float *dec_neg, const bool pow2) {
     const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
     const uint32_t e_imask = n0.w;
     const float ex = __uint_as_float((e_imask & 0xffu) << 23);
@@ -211,9 +214,9 @@ __device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_d
         by = (py - r.oy) / r.dy;
         bz = (pz - r.oz) / r.dz;
     }
-    // plane p of the table starts at float 8 p; near plane of an axis = its max plane when the direction is negative
-    const uint32_t xn = r.dx < 0.0f ? 8u : 0u, yn = r.dy < 0.0f ? 24u : 16u, zn = r.dz < 0.0f ? 40u : 32u;
-    const uint32_t xf = xn ^ 8u, yf = yn ^ 8u, zf = zn ^ 8u;
+    const float4 *const qx = reinterpret_cast<const float4 *>(r.dx < 0.0f ? dec_neg : dec_pos);
+    const float4 *const qy = reinterpret_cast<const float4 *>((r.dy < 0.0f ? dec_neg : dec_pos) + 16);
+    const float4 *const qz = reinterpret_cast<const float4 *>((r.dz < 0.0f ? dec_neg : dec_pos) + 32);
     uint32_t hit_mask = 0;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -222,22 +225,22 @@ __device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_d
         const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
         const uint32_t bit_index4 = (meta4 ^ (r.oct_inv4 & inner_mask4)) & 0x1f1f1f1fu;
         const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
-        const float4 qxn = *reinterpret_cast<const float4 *>(dec + xn + 4 * i), qxf = *reinterpret_cast<const float4 *>(dec + xf + 4 * i);
-        const float4 qyn = *reinterpret_cast<const float4 *>(dec + yn + 4 * i), qyf = *reinterpret_cast<const float4 *>(dec + yf + 4 * i);
-        const float4 qzn = *reinterpret_cast<const float4 *>(dec + zn + 4 * i), qzf = *reinterpret_cast<const float4 *>(dec + zf + 4 * i);
-        const float an[4][3] = {{qxn.x, qyn.x, qzn.x}, {qxn.y, qyn.y, qzn.y}, {qxn.z, qyn.z, qzn.z}, {qxn.w, qyn.w, qzn.w}};
-        const float af[4][3] = {{qxf.x, qyf.x, qzf.x}, {qxf.y, qyf.y, qzf.y}, {qxf.z, qyf.z, qzf.z}, {qxf.w, qyf.w, qzf.w}};
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const f32x2 tx = plane2<NODE>(f32x2{an[j][0], af[j][0]}, ax, bx);
-            const f32x2 ty = plane2<NODE>(f32x2{an[j][1], af[j][1]}, ay, by);
-            const f32x2 tz = plane2<NODE>(f32x2{an[j][2], af[j][2]}, az, bz);
-            const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0001f);
-            const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), max_distance);
-            if (tmin <= tmax) {
-                const uint32_t child_bits = (child_bits4 >> (8 * j)) & 0xffu;
-                const uint32_t bit_index = (bit_index4 >> (8 * j)) & 0xffu;
-                hit_mask |= child_bits << bit_index;
+        for (int h = 0; h < 2; h++) { // children 4 i + 2 h, 4 i + 2 h + 1
+            const float4 x2 = qx[2 * i + h], y2 = qy[2 * i + h], z2 = qz[2 * i + h]; // {near, far, near, far}
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int j = 2 * h + k;
+                const f32x2 tx = plane2<NODE>(k == 0 ? f32x2{x2.x, x2.y} : f32x2{x2.z, x2.w}, ax, bx);
+                const f32x2 ty = plane2<NODE>(k == 0 ? f32x2{y2.x, y2.y} : f32x2{y2.z, y2.w}, ay, by);
+                const f32x2 tz = plane2<NODE>(k == 0 ? f32x2{z2.x, z2.y} : f32x2{z2.z, z2.w}, az, bz);
+                const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0001f);
+                const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), max_distance);
+                if (tmin <= tmax) {
+                    const uint32_t child_bits = (child_bits4 >> (8 * j)) & 0xffu;
+                    const uint32_t bit_index = (bit_index4 >> (8 * j)) & 0xffu;
+                    hit_mask |= child_bits << bit_index;
+                }
             }
         }
     }
@@ -632,7 +635,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint32_t *const lds_pref = reinterpret_cast<uint32_t *>(lds_res + kWave);              // [64] first pair of the lane
     uint32_t *const lds_head = lds_pref + kWave;                                           // [64] run starts of a window
     uint2 *const lds_pend = reinterpret_cast<uint2 *>(lds_head + kWave);                   // [kLptPend] {tile, list} to append
-    float *const lds_dec = reinterpret_cast<float *>(lds_pend + kLptPend);                 // [6][8] decoded child planes of a wave-uniform node step
+    float *const lds_dec = reinterpret_cast<float *>(lds_pend + kLptPend);                 // [3][8][2] decoded child planes {min, max} of a wave-uniform node step
+    float *const lds_dec_neg = reinterpret_cast<float *>(lds_head);                        // [3][8][2] the same as {max, min} (node_intersect_dec); shares lds_head
     // (wave-uniform base, so that it lives in scalar registers: the HBM part of a stack is touched on rare paths only)
     uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave);
     const bool tie_first = P.tie_first != 0;
@@ -1749,13 +1753,20 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         if (__ballot(act && node_index != first) == 0ull) { // wave-uniform: every lane takes this branch or none does
                             const uint4 *np = P.nodes + (size_t)first * 5;
                             // 48 lanes convert one byte each (whether or not they hold a ray), LDS hands the floats to all
-                            if (lane < 48u) lds_dec[lane] = (float)reinterpret_cast<const uint8_t *>(np)[32u + lane];
+                            // (byte 32 + 8 p + c = plane p of child c, planes in the order min_x max_x min_y max_y min_z max_z; the
+                            // second table lives in the triangle phase's window area, idle during a node step)
+                            if (lane < 48u) {
+                                const float v = (float)reinterpret_cast<const uint8_t *>(np)[32u + lane];
+                                const uint32_t slot = (lane >> 4) * 16u + (lane & 7u) * 2u, is_max = (lane >> 3) & 1u;
+                                lds_dec[slot + is_max] = v;
+                                lds_dec_neg[slot + (is_max ^ 1u)] = v;
+                            }
                             __builtin_amdgcn_wave_barrier();
                             if (act) {
                                 const uint4 n0 = np[0], n1 = np[1];
                                 cur.y &= ~(1u << child_bit);
                                 stack_push(cur, (cur.y & 0xff000000u) != 0u);
-                                const uint32_t hitmask = node_intersect_dec<NODE>(r, t, n0, n1, lds_dec, pow2);
+                                const uint32_t hitmask = node_intersect_dec<NODE>(r, t, n0, n1, lds_dec, lds_dec_neg, pow2);
                                 cur.x = n1.x;
                                 tri.x = n1.y;
                                 cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
