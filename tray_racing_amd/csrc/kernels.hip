@@ -969,10 +969,14 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         }
         unsigned long long *const lds_key = reinterpret_cast<unsigned long long *>(lds_res);
         // The trip is rotated like the pipelined walk's, and one step further: (1) the ray's next node is chosen and its
-        // bytes are requested, (2) the triangles of the node tested in the PREVIOUS trip are tested - the first eight
+        // bytes are requested, (2) the triangles of the node tested in the PREVIOUS trip are tested - the first L
         // records were requested at the end of that trip - (3) a ray with no node left is finished, (4) the requested node
-        // is tested with the t those triangles left, (5) the first eight triangle records of the new leaf hits are
-        // requested.  A thin wave's time is its rays' dependent round trips to memory: two per trip run in parallel now.
+        // is tested with the t those triangles left, (5) the first L triangle records of the new leaf hits are
+        // requested.  A thin wave's time is its rays' dependent round trips to memory.  (The requests are plain loads: an
+        // `asm volatile` barrier naming the loaded registers right behind them - there until late in round 4 "to keep
+        // the loads early" - makes the compiler wait for them on the spot; without it the AO pass of a hairball-class
+        // scene runs 6 % faster, random rays 6-7 %.  Requesting (5) right behind (1) instead, both in flight together
+        // and nothing across the back-edge, was built as well and measures the same to slightly slower.)
         uint4 n0 = make_uint4(0u, 0u, 0u, 0u), n1 = n0;
         uint32_t q0 = 0u, q1 = 0u, q2 = 0u, q3 = 0u, q4 = 0u, q5 = 0u;
         float4 ta = unspecified4(), tb = unspecified4(), tc = unspecified4();
@@ -989,7 +993,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 ta = tp[0];
                 tb = tp[1];
                 tc = tp[2];
-                asm volatile("" : "+v"(ta.x), "+v"(ta.y), "+v"(ta.z), "+v"(ta.w), "+v"(tb.x), "+v"(tb.y), "+v"(tb.z), "+v"(tb.w), "+v"(tc.x), "+v"(tc.y), "+v"(tc.z), "+v"(tc.w));
             }
         };
         request_triangles(); // (a wave that comes from the pipelined walk brings pending triangle groups)
@@ -1022,29 +1025,33 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 q0 = load_bytes<(int)C>(nb + 32u + xn); q1 = load_bytes<(int)C>(nb + 32u + (xn ^ 8u));
                 q2 = load_bytes<(int)C>(nb + 48u + yn); q3 = load_bytes<(int)C>(nb + 48u + (yn ^ 8u));
                 q4 = load_bytes<(int)C>(nb + 64u + zn); q5 = load_bytes<(int)C>(nb + 64u + (zn ^ 8u));
-                asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z), "+v"(n1.w), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5));
             }
             // ---- (2) triangles of the node tested in the previous trip, L at a time; the first L are here already
             if (__ballot(cnt != 0u) != 0ull) {
                 const uint32_t init_lo = tie_first ? 0u : 0xffu;
                 if (sub == 0u) lds_res[lane] = make_uint2(init_lo, ordered_bits(t + 0.0f));
                 __builtin_amdgcn_wave_barrier();
-                for (uint32_t j = sub; __ballot(j < cnt) != 0ull; j += L) {
+                auto test_one = [&](uint32_t local, const float4 &a, const float4 &b, const float4 &c) {
+                    float tt = TRX_F32_MAX; // the tie test against the ray's t is the atomic min (see the cooperative rounds)
+                    if (intersect_tri(r, a, b, c, tt, false)) {
+                        const uint32_t neg_zero = __float_as_uint(tt) == 0x80000000u ? 1u : 0u;
+                        const uint32_t lo = ((tie_first ? 31u - local : local) << 1) | neg_zero;
+                        atomicMin(&lds_key[first], ((unsigned long long)ordered_bits(tt + 0.0f) << 32) | lo);
+                    }
+                };
+                // (the first L stand apart from the loop: a loop that loads waits at its head for everything in flight -
+                // the node bytes requested in (1) included - where these only need their own records)
+                uint32_t j = sub;
+                if (kPre) {
+                    if (j < cnt) test_one(select_from_top(gy, j), ta, tb, tc);
+                    j += L;
+                }
+                for (; __ballot(j < cnt) != 0ull; j += L) {
                     if (j < cnt) {
                         const uint32_t local = select_from_top(gy, j);
-                        if (!kPre || j >= L) {
-                            const float4 *tp = P.tris + (size_t)(gx + local) * 3;
-                            ta = tp[0];
-                            tb = tp[1];
-                            tc = tp[2];
-                            asm volatile("" : "+v"(ta.x), "+v"(ta.y), "+v"(ta.z), "+v"(ta.w), "+v"(tb.x), "+v"(tb.y), "+v"(tb.z), "+v"(tb.w), "+v"(tc.x), "+v"(tc.y), "+v"(tc.z), "+v"(tc.w));
-                        }
-                        float tt = TRX_F32_MAX; // the tie test against the ray's t is the atomic min (see the cooperative rounds)
-                        if (intersect_tri(r, ta, tb, tc, tt, false)) {
-                            const uint32_t neg_zero = __float_as_uint(tt) == 0x80000000u ? 1u : 0u;
-                            const uint32_t lo = ((tie_first ? 31u - local : local) << 1) | neg_zero;
-                            atomicMin(&lds_key[first], ((unsigned long long)ordered_bits(tt + 0.0f) << 32) | lo);
-                        }
+                        const float4 *tp = P.tris + (size_t)(gx + local) * 3;
+                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        test_one(local, a, b, c);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
