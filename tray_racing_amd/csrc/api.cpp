@@ -433,7 +433,10 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     }
     {   // tuning: variant bits 25..27 = compaction threshold (0 = default, 7 = never); bit 28 = no thin waves (A/B runs)
         const uint32_t c = (variant >> 25) & 0x7u;
-        p.thin_max = ((variant >> 28) & 1u) ? 0u : 8u;
+#ifndef TRX_THIN_MAX_DEFAULT
+#define TRX_THIN_MAX_DEFAULT 8u // (tuning builds: 16 with -DTRX_THIN_LEVELS=2, 32 with 3)
+#endif
+        p.thin_max = ((variant >> 28) & 1u) ? 0u : TRX_THIN_MAX_DEFAULT;
 #ifdef TRX_DEV_TUNE
         {   // (development builds: TRX_THIN_MAX = 0 / 8 / 16 / 32)
             const char *tm = getenv("TRX_THIN_MAX");
