@@ -563,7 +563,10 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     // The pipelined walk (next node's fetch issued under the triangle phase) pays where a node fetch leaves the L2s:
     // incoherent passes over scenes larger than the eight L2s together (measured: hairball-class AO -4..-6 %, dense
     // bistro-class -3 %, a 3 MB kitchen-class scene +4 %; coherent primary rays +-1 %: DESIGN.md section 4).
-    bool pipe = mode != kModePrimary && !s->tlas && s->n_nodes * TRX_NODE_BYTES + s->n_tris * sizeof(TriDev) > (32ull << 20);
+#ifndef TRX_PIPE_MIN_BYTES
+#define TRX_PIPE_MIN_BYTES (32ull << 20) // (tuning builds: 0 = always)
+#endif
+    bool pipe = mode != kModePrimary && !s->tlas && s->n_nodes * TRX_NODE_BYTES + s->n_tris * sizeof(TriDev) >= (size_t)TRX_PIPE_MIN_BYTES + 1u;
 #ifdef TRX_DEV_TUNE
     if (p.tune & 0x1000u) pipe = true;
     if (p.tune & 0x10000u) pipe = false;
