@@ -25,7 +25,7 @@ def child(scenes, variant):
     out = {}
     for name in scenes:
         verts, counts = T.gen_scene(name, 0, 1)
-        flat = T.flat_build(verts, counts)
+        flat = T.flat_build(verts, counts, use_tlas=os.environ.get("TLAS", "0") == "1")   # TLAS=1: the two-level kernels
         eye, look, fov = T.scene_camera(name)
         view = T.view_from_camera(eye, look, fov, w, h)
         sc = T.Scene(flat)

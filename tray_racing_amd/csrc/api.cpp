@@ -451,11 +451,12 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     }
     p.waves_per_block = wpb;
     p.merge = merge_default ? 1u : 0u;
-    // Decode-once node test on wave-uniform node steps (kernels.hip, node_intersect_dec): pays where almost every step is
-    // uniform - a scene small enough for the L2s, seen by coherent primary rays (kitchen-class frame -4 %, 90 % of its
-    // steps uniform) - is neutral on the bistro-class frame (-1 %, 47 %) and costs 1-2 % on the dense and hairball-class
-    // ones, whose steps rarely are (profiles/r03_decode_once.log): on for scenes up to the eight L2s' 32 MiB.
-    p.uni_decode = (mode == kModePrimary && !s->tlas && s->n_nodes * TRX_NODE_BYTES + s->n_tris * sizeof(TriDev) <= (32ull << 20)) ? 1u : 0u;
+    // Decode-once node test on wave-uniform node steps (kernels.hip, node_intersect_dec): every single-level primary pass.
+    // With the plane-major table of round 3 it paid only where almost every step is uniform (kitchen-class frame -4 %, 90 %
+    // of its steps) and was kept to scenes of up to 32 MiB; with the {near, far} pair tables of round 4 the bistro-class
+    // frame (47 % uniform steps) gains 2 % and the dense and hairball-class frames, whose steps rarely are uniform, pay
+    // 0.3 % for the test that finds that out (profiles/r04_ab_procs_15_decode_once.log).
+    p.uni_decode = (mode == kModePrimary && !s->tlas) ? 1u : 0u;
 #ifdef TRX_DEV_TUNE
     if (p.tune & 0x40000u) p.uni_decode = 1u;
     if (p.tune & 0x80000u) p.uni_decode = 0u;

@@ -1744,20 +1744,27 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 // Coherent primary rays (BLAS only): when every lane that steps visits the SAME node - 47 % of the wave-level
                 // node steps on the bistro-class frame, 90 % on the kitchen-class one - its 48 quantised plane bytes are
                 // converted once, one byte per lane, parked in LDS as floats and read back by address (node_intersect_dec)
+                // (single-level walks: built for the two-level primary kernel as well - absolute node indices, lanes with a
+                // parked triangle group excluded - it spills there and the 4K frame runs 4 % slower, profiles/r04_ab_procs_16)
                 constexpr bool kUni = !TLAS && MODE == kModePrimary && !COUNT;
                 bool uni_done = false;
                 if constexpr (kUni) {
                     if (P.uni_decode) {
                         uint32_t node_index = 0u, child_bit = 0u;
-                        if (act) {
+                        // (two-level walks: a lane may hold a parked triangle group instead of a node group, and node
+                        // indices are absolute - rays inside different instances of one BLAS do share its nodes, each
+                        // with its own object-space ray)
+                        const bool group = act && (!TLAS || (cur.y & 0xff000000u) != 0u);
+                        if (group) {
                             const uint32_t hits_imask = cur.y;
                             child_bit = 31u - (uint32_t)__builtin_clz(hits_imask);
                             const uint32_t slot = (child_bit - 24u) ^ (r.oct_inv4 & 0xffu);
                             node_index = cur.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
+                            if (TLAS) node_index += bvh_off;
                         }
                         const unsigned long long stepping = __ballot(act);
                         const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)node_index, (int)(__ffsll((long long)stepping) - 1));
-                        if (__ballot(act && node_index != first) == 0ull) { // wave-uniform: every lane takes this branch or none does
+                        if (__ballot(act && (!group || node_index != first)) == 0ull) { // wave-uniform: every lane takes this branch or none does
                             const uint4 *np = P.nodes + (size_t)first * 5;
                             // 48 lanes convert one byte each (whether or not they hold a ray), LDS hands the floats to all
                             // (byte 32 + 8 p + c = plane p of child c, planes in the order min_x max_x min_y max_y min_z max_z; the
@@ -1835,37 +1842,37 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         tri = cur;
                         cur = make_uint2(0u, 0u);
                     }
-                    if (TLAS && tlas_sp == TRX_INVALID && tri.y != 0u) {
-                        // a TLAS primitive is an instance (query_tlas.hlsl:410-446): enter its BLAS
-                        const uint32_t local = 31u - (uint32_t)__clz((int)tri.y);
-                        tri.y &= ~(1u << local);
-                        const uint32_t gidx = tri.x + local;
-                        stack_push(tri, tri.y != 0u);
-                        stack_push(cur, (cur.y & 0xff000000u) != 0u);
-                        tlas_sp = sp;
-                        bvh_off = P.inst[gidx];
-                        cur_inst = gidx;
-                        if (P.inst_xform) {
-                            // the ray in the instance's object space; the direction is not renormalised, so t keeps
-                            // its world-space meaning (the TODO at query_tlas.hlsl:433)
-                            const float4 *m = P.inst_xform + (size_t)gidx * 3;
-                            const float4 r0 = m[0], r1 = m[1], r2 = m[2];
-                            r.ox = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
-                            r.oy = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
-                            r.oz = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
-                            const float odx = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
-                            const float ody = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
-                            const float odz = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
-                            finish_ray_dir(r, odx, ody, odz);
-                            lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
-                            lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
-                        }
-                        // the walk of the BLAS starts at its node 0 (query_tlas.hlsl:443) - or, for a TLAS primitive that
-                        // stands for a SUBTREE of its BLAS (re-braided scenes, trx_scene_set_instance_entry_nodes), at
-                        // that subtree's node: the group {child_base = entry, one hit} makes the next node step fetch it
-                        cur = make_uint2(P.inst_entry ? P.inst_entry[gidx] : 0u, 0x80000000u);
-                        tri.y = 0u;
+                }
+                if (TLAS && act && tlas_sp == TRX_INVALID && tri.y != 0u) { // (after either kind of node step)
+                    // a TLAS primitive is an instance (query_tlas.hlsl:410-446): enter its BLAS
+                    const uint32_t local = 31u - (uint32_t)__clz((int)tri.y);
+                    tri.y &= ~(1u << local);
+                    const uint32_t gidx = tri.x + local;
+                    stack_push(tri, tri.y != 0u);
+                    stack_push(cur, (cur.y & 0xff000000u) != 0u);
+                    tlas_sp = sp;
+                    bvh_off = P.inst[gidx];
+                    cur_inst = gidx;
+                    if (P.inst_xform) {
+                        // the ray in the instance's object space; the direction is not renormalised, so t keeps
+                        // its world-space meaning (the TODO at query_tlas.hlsl:433)
+                        const float4 *m = P.inst_xform + (size_t)gidx * 3;
+                        const float4 r0 = m[0], r1 = m[1], r2 = m[2];
+                        r.ox = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
+                        r.oy = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
+                        r.oz = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
+                        const float odx = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
+                        const float ody = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
+                        const float odz = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
+                        finish_ray_dir(r, odx, ody, odz);
+                        lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+                        lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
                     }
+                    // the walk of the BLAS starts at its node 0 (query_tlas.hlsl:443) - or, for a TLAS primitive that
+                    // stands for a SUBTREE of its BLAS (re-braided scenes, trx_scene_set_instance_entry_nodes), at
+                    // that subtree's node: the group {child_base = entry, one hit} makes the next node step fetch it
+                    cur = make_uint2(P.inst_entry ? P.inst_entry[gidx] : 0u, 0x80000000u);
+                    tri.y = 0u;
                 }
 
                 TRX_STAMP(k_test);
