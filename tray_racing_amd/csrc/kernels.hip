@@ -980,16 +980,19 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         uint4 n0 = make_uint4(0u, 0u, 0u, 0u), n1 = n0;
         uint32_t q0 = 0u, q1 = 0u, q2 = 0u, q3 = 0u, q4 = 0u, q5 = 0u;
         float4 ta = unspecified4(), tb = unspecified4(), tc = unspecified4();
-        uint32_t gx = 0u, gy = 0u, cnt = 0u;
+        uint32_t gx = 0u, gy = 0u, cnt = 0u, pre_local = 0u;
         // (the one-launch frame comes back from here into its loop, whose registers stay live meanwhile: it does without
         // the early triangle request, twelve registers carried from trip to trip)
         constexpr bool kPre = !kFused;
         auto request_triangles = [&]() { // (5): the group's pending triangle group, and this lane's record of its first L
+            cnt = 0u;
+            if (__ballot(ptri.y != 0u) == 0ull) return; // (most trips of a handful of rays find no leaf)
             gx = group_first<(int)L>(ptri.x);
             gy = group_first<(int)L>(ptri.y);
             cnt = (uint32_t)__popc(gy);
             if (kPre && sub < cnt) {
-                const float4 *tp = P.tris + (size_t)(gx + select_from_top(gy, sub)) * 3;
+                pre_local = select_from_top(gy, sub); // (kept for (2): the search is thirty-five instructions of a lone wave's trip)
+                const float4 *tp = P.tris + (size_t)(gx + pre_local) * 3;
                 ta = tp[0];
                 tb = tp[1];
                 tc = tp[2];
@@ -1043,7 +1046,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 // the node bytes requested in (1) included - where these only need their own records)
                 uint32_t j = sub;
                 if (kPre) {
-                    if (j < cnt) test_one(select_from_top(gy, j), ta, tb, tc);
+                    if (j < cnt) test_one(pre_local, ta, tb, tc);
                     j += L;
                 }
                 for (; __ballot(j < cnt) != 0ull; j += L) {
