@@ -32,7 +32,9 @@
 // Lanes-per-ray steps of the thin walk: 1 = eight lanes from 8 rays on (shipped), 2 = also four from 16, 3 = also two from
 // 32.  Measured (profiles/r04_thin_waves.log): 8 / 16 / 32 rays = hairball-class AO pass 0.917 / 0.909 / 0.945 ms against
 // 1.044 without, bistro-class 0.984 / 0.999 / 1.035 against 1.008 - the earlier steps cost what they gain (a re-pack and a
-// drain trip per step, and the waves no longer merge), so the product compiles the last step only.
+// drain trip per step, and the waves no longer merge), so the product compiles the last step only.  Measured again over
+// fresh processes once the thin walk's requests had become plain loads (profiles/r04_ab_procs_11_thin_levels.log):
+// 0.810 / 0.817 / 0.857 ms hairball-class, 0.896 / 0.899 / 0.924 bistro-class - the same conclusion.
 #ifndef TRX_THIN_LEVELS
 #define TRX_THIN_LEVELS 1
 #endif
