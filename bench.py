@@ -692,6 +692,11 @@ def main():
             roof["issued_over_useful"] = round(valu / useful, 3) if valu else None
             roof["useful_note"] = ("(node steps x %d + triangle tests x %d) / 64 wave-instructions per launch over the "
                                    "same peak as `frac`" % (NODE_TEST_VALU, TRI_TEST_VALU))
+            # SURVEY.md section 8(d)'s own (secondary) figure: algorithmic VALU work ~ 250 lane-ops per node step + 50 per
+            # triangle test - independent of this kernel's instruction counts, so it rises only when the frame gets faster
+            algo = (st.n_node * 250.0 + st.n_tri * 50.0) / 64.0
+            roof["algorithmic_valu_wave_insts_per_launch"] = int(algo)
+            roof["algorithmic_frac"] = round(algo / (kernel_ms * 1e-3) / 1e9 / peak_ginstr, 4)
         # the vector-memory front end: every lane requests its node / triangle bytes through TA / L1 whatever the caches
         # then serve, so the requested bytes price the L1 data path (64 B per CU and clock), and TA_TA_BUSY says how
         # long the address unit was occupied
