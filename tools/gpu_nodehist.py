@@ -12,7 +12,7 @@ import tray_racing_amd as T  # noqa: E402
 from tray_racing_amd import _lib as L  # noqa: E402
 
 lib = L.load()
-w, h = 1920, 1080
+w, h = (int(v) for v in os.environ.get("WH", "1920x1080").split("x"))
 for name in sys.argv[1:] or ["bistro", "bistro_dense", "hairball", "kitchen"]:
     verts, counts = T.gen_scene(name, 0, 1)
     flat = T.flat_build(verts, counts)
