@@ -614,6 +614,7 @@ __device__ __forceinline__ void flush_pending_plain(const TraceParams &P, uint32
 // for one trip more (its last trip has triangle work only), which is why coherent, issue-bound frames do not want it.
 template <int MODE, bool TLAS, int NODE, bool PIPE, bool COUNT>
 __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceParams P) {
+    // (P is the kernel's ONLY parameter: refill_params() reads it back from offset 0 of the kernel-argument segment)
     static_assert(!(PIPE && TLAS), "the pipelined walk is BLAS-only");
     // triangles of a lane requested together in a per-lane triangle round (the two-level walk has fewer registers to spare)
     constexpr int kBatch = TLAS ? kTriBatchTlas : (PIPE ? kTriBatchPipe : kTriBatch);
