@@ -122,6 +122,9 @@ def parse():
                          "scene and its clocks take about 20 ms of load to come back up (profiles/r04_clock_ramp.log: the same "
                          "kernel runs 5-7 %% slower for its first ~40 frames after an idle second, whatever the tile order); 0 = "
                          "none, the warm-up steps then run on a GPU at idle clocks")
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="the timed region is run this many times in all; `value` is the FIRST (the contract's K steps), "
+                         "legs.timed_region_repeats carries median / min / max over all of them")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (child processes)")
@@ -218,15 +221,12 @@ def launch_ranks(n):
     GPU (nothing below `import` level does; libtrx.so is not even loaded yet), so the ranks are FRESH children of
     `python -m torch.distributed.run` - never an exec of a process that initialised HIP - one per GPU, rendezvous on
     127.0.0.1.  Their stdout / stderr are ours (rank 0 prints the JSON line); the launcher's return code is ours."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # (--standalone: the launcher binds its own rendezvous port - a port picked here and closed again could be taken by
+    # another bench starting at the same moment)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
@@ -427,11 +427,53 @@ def main():
         run_frames(min(args.steps, 64), events)               # untimed: the same frames again, an event pair each
         sync_all()
     launch_ms = [a.elapsed_time(b) / n for a, b, n in events]   # per frame of each launch
+    # The timed region again, REPEATS - 1 more times (same K steps, same barriers; never part of `value`): a K = 20 region at
+    # N = 8 is about a millisecond of wall clock, so the line carries the median and the spread of the repetitions next to
+    # the one region the contract defines.
+    repeat_s = [elapsed]
+    for _ in range(max(args.repeats, 1) - 1):
+        sync_all()
+        tr = time.perf_counter()
+        run_frames(args.steps, None if one_pair else [])
+        sync_all()
+        repeat_s.append(time.perf_counter() - tr)
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        tmax = torch.tensor(repeat_s, dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax[0])
+        repeat_s = [float(x) for x in tmax]
+        elapsed = repeat_s[0]
+    # N > 1 runs more frames in flight and more frames per launch than the N = 1 metric does, and that protocol alone is
+    # worth something on ONE GPU (independent frames overlap each other's tails): rank 0 traces WHOLE frames on its GPU under
+    # this run's streams / frames-per-launch, no gather, while the other ranks wait - the figure a scaling factor has to be
+    # quoted against (`scaling_vs_same_protocol`), next to the driver's own N = 1 line.
+    n1_same = None
+    if world > 1 and args.sim_shards == 1:
+        if rank == 0:
+            solo = [torch.empty(L_launch * n_rays_total, dtype=torch.int64, device="cuda") for _ in range(n_streams)]
+
+            def run_solo(n):
+                done, k = 0, 0
+                while done < n:
+                    m = min(L_launch, n - done)
+                    j = k % n_streams
+                    k += 1
+                    with torch.cuda.stream(streams[j]):
+                        trace(streams[j], solo[j].data_ptr(), (0, 1, 0), m, n_rays_total, timed=False)
+                    done += m
+            run_solo(n_streams * L_launch + max(args.warmup, 16))   # every slot learns the whole-frame geometry; warm-up
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                tr = time.perf_counter()
+                run_solo(args.steps)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - tr)
+            n1_same = n_rays_total * args.steps / sorted(ts)[1] / 1e6
+            for s in streams:
+                scene.check(s.cuda_stream)
+            del solo
+        sync_all()
     kernel_ms_ranks = None
     if world > 1:  # every rank's mean kernel time per frame: the spread says how even the tile deal was
         mine = torch.tensor([sum(launch_ms) / max(len(launch_ms), 1)], dtype=torch.float64,
@@ -623,6 +665,21 @@ def main():
             }
             pscene.close()
             del pflat
+        # (j) the timed region WITHOUT the wake frames: the GPU idles for a second (as it does while a host builds a scene),
+        #     then the W warm-up steps and K timed steps run straight away, on clocks that are still coming up - what the
+        #     round-3 protocol measured (profiles/r04_clock_ramp.log); one event pair around the K launches, like `value`
+        if one_pair:
+            torch.cuda.synchronize()
+            time.sleep(1.0)
+            run_frames(args.warmup, None)
+            n0, n1 = ev(), ev()
+            n0.record(streams[0])
+            run_frames(args.steps, None)
+            n1.record(streams[0])
+            torch.cuda.synchronize()
+            nw_ms = n0.elapsed_time(n1) / args.steps
+            legs["no_wake"] = {"idle_s": 1.0, "warmup": args.warmup, "steps": args.steps, "kernel_ms_mean": round(nw_ms, 4),
+                               "mrays": round(n_rays_total / (nw_ms * 1e-3) / 1e6, 1)}
         # (f) compulsory footprint: distinct nodes / triangles one frame touches
         fn, ft = scene.footprint(view, w, h, sem=args.sem)
         legs["footprint"] = {"nodes": fn, "tris": ft, "bytes": NODE_BYTES * fn + TRI_BYTES * ft + HIT_BYTES * n_rays_total}
@@ -668,23 +725,36 @@ def main():
             valu = pmc.get("SQ_INSTS_VALU")
         peak_ginstr = SIMDS * CLOCK_GHZ / VALU_CYCLES
         ach_ginstr = (valu / (kernel_ms * 1e-3) / 1e9) if valu else None
+        # algorithmic VALU work = 250 lane-operations per node step + 50 per triangle test, 64 lanes
+        # to a wave-instruction - a property of the rays and the tree (the counts are the oracle's exactly), independent of
+        # this kernel's instruction stream, so the fraction rises only when the frame gets faster.  (Until round 4 `frac`
+        # divided the ISSUED instructions instead, a figure that goes up when the kernel wastes instructions: that one is
+        # `issued_frac` now.)
+        algo = (st.n_node * 250.0 + st.n_tri * 50.0) / 64.0
+        algo_ginstr = algo / (kernel_ms * 1e-3) / 1e9
         roof = {
-            # the kernel is bound by vector-instruction issue, not by bytes: achieved = VALU
-            # wave-instructions per second (SQ_INSTS_VALU per launch / this run's kernel time), peak = one wave64
-            # instruction per 2 cycles per SIMD-32 x 1024 SIMDs x 2.4 GHz
+            # the kernel is bound by vector-instruction issue, not by bytes: achieved = algorithmic
+            # wave-instructions per second, peak = one wave64 instruction per 2 cycles per SIMD-32 x 1024 SIMDs x 2.4 GHz
             "bound": "valu",
-            "achieved": round(ach_ginstr, 1) if ach_ginstr else None,
+            "achieved": round(algo_ginstr, 1),
             "peak": round(peak_ginstr, 1),
             "unit": "Ginstr/s",
-            "frac": round(ach_ginstr / peak_ginstr, 4) if ach_ginstr else None,
+            "frac": round(algo_ginstr / peak_ginstr, 4),
             "traffic": traffic,   # HBM bytes per launch from FETCH_SIZE (doubled) + WRITE_SIZE
             "source": pmc_src,
             "kernel_ms": round(kernel_ms, 4),
+            "algorithmic_valu_wave_insts_per_launch": int(algo),
+            "algorithmic_note": "(node steps x 250 + triangle tests x 50) / 64 wave-instructions per launch (SURVEY.md 8(d)), "
+                                "node steps and triangle tests counted by the COUNT kernel = the oracle's counts",
+            # what the kernel actually issued (SQ_INSTS_VALU per launch, live rocprofv3 child passes) over the same peak
             "valu_wave_insts_per_launch": int(valu) if valu else None,
+            "issued_ginstr_s": round(ach_ginstr, 1) if ach_ginstr else None,
+            "issued_frac": round(ach_ginstr / peak_ginstr, 4) if ach_ginstr else None,
+            "issued_over_algorithmic": round(valu / algo, 3) if valu else None,
         }
-        # what a divergence-free walk of the same rays would issue: every COUNTED lane-level node step and triangle test
-        # (the reference's PROFILE_RT counters, rt_gpu_software_query.hlsl:377-379,407-409) at the static instruction
-        # count of the test, 64 lanes to a wave-instruction; issued / useful = divergence + bookkeeping
+        # what a divergence-free walk of the same rays would issue with THIS kernel's tests: every COUNTED lane-level node
+        # step and triangle test (the reference's PROFILE_RT counters, rt_gpu_software_query.hlsl:377-379,407-409) at the
+        # static instruction count of the test, 64 lanes to a wave-instruction; issued / useful = divergence + bookkeeping
         useful = (st.n_node * NODE_TEST_VALU + st.n_tri * TRI_TEST_VALU) / 64.0
         if args.sim_shards == 1:
             roof["useful_valu_wave_insts_per_launch"] = int(useful)
@@ -692,11 +762,6 @@ def main():
             roof["issued_over_useful"] = round(valu / useful, 3) if valu else None
             roof["useful_note"] = ("(node steps x %d + triangle tests x %d) / 64 wave-instructions per launch over the "
                                    "same peak as `frac`" % (NODE_TEST_VALU, TRI_TEST_VALU))
-            # SURVEY.md section 8(d)'s own (secondary) figure: algorithmic VALU work ~ 250 lane-ops per node step + 50 per
-            # triangle test - independent of this kernel's instruction counts, so it rises only when the frame gets faster
-            algo = (st.n_node * 250.0 + st.n_tri * 50.0) / 64.0
-            roof["algorithmic_valu_wave_insts_per_launch"] = int(algo)
-            roof["algorithmic_frac"] = round(algo / (kernel_ms * 1e-3) / 1e9 / peak_ginstr, 4)
         # the vector-memory front end: every lane requests its node / triangle bytes through TA / L1 whatever the caches
         # then serve, so the requested bytes price the L1 data path (64 B per CU and clock), and TA_TA_BUSY says how
         # long the address unit was occupied
@@ -735,26 +800,39 @@ def main():
             # wave64 instruction at 4 cycles, so it reads about twice `frac` and can pass 100 on the TLAS kernel);
             # VALUUtilization = active lanes per VALU instruction
             roof["rocprof_derived_pct"] = {k: round(pmc[k], 1) for k in ("VALUBusy", "VALUUtilization", "SALUBusy") if k in pmc}
+        hbm_gbs = (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None
         hbm = {
-            # SURVEY 8(d)'s requested-bytes figure: what the rays ask for, mostly served by L1 / L2 / Infinity Cache
+            # the byte side, measured: HBM / fabric bytes per launch from the counters over the kernel time.  (The REQUESTED
+            # bytes of SURVEY 8(d) - what the rays ask for - are mostly served by L1 / L2 / Infinity Cache and exceed the
+            # HBM peak on coherent frames, so they are reported as `requested_gbs`, not as a fraction of anything.)
             "bound": "hbm",
-            "achieved": round(req_gbs, 1),
+            "achieved": round(hbm_gbs, 1) if hbm_gbs else None,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            # NOT a roofline fraction: requested bytes are served by L1 / L2 / Infinity Cache and this ratio passes 1;
-            # the measured fabric traffic below is the HBM-side figure
-            "requested_over_hbm_peak": round(req_gbs / HBM_PEAK_GBS, 4),
-            "measured_over_hbm_peak": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+            "frac": round(hbm_gbs / HBM_PEAK_GBS, 4) if hbm_gbs else None,
+            "traffic": traffic,
             "peak_measured": legs.get("hbm_copy_gbs"),
+            "requested_gbs": round(req_gbs, 1),
             "bytes_per_launch": int(launch_bytes),
             "compulsory_bytes": legs.get("footprint", {}).get("bytes"),
-            "traffic": traffic,
-            "hbm_gbs_measured": round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None,
             "nodes_per_ray": round(st.n_node / max(st.n_rays, 1), 3),
             "tris_per_ray": round(st.n_tri / max(st.n_rays, 1), 3),
-            "note": "algorithmic (requested) bytes = 80 x node fetches + 48 x triangle tests + 8 x rays; this figure "
-                    "can exceed the HBM peak because coherent rays share cache lines",
+            "note": "requested (algorithmic) bytes = 80 x node fetches + 48 x triangle tests + 8 x rays per launch; "
+                    "achieved / frac = MEASURED HBM traffic (FETCH_SIZE doubled + WRITE_SIZE), the requested bytes are "
+                    "served by the caches because coherent rays share lines",
         }
+        rep_ms = sorted(x / args.steps * 1e3 for x in repeat_s)
+        legs["timed_region_repeats"] = {
+            "n": len(rep_ms), "steps_each": args.steps, "ms_per_step_median": round(rep_ms[len(rep_ms) // 2], 4),
+            "ms_per_step_min": round(rep_ms[0], 4), "ms_per_step_max": round(rep_ms[-1], 4),
+            "mrays_median": round(rays_per_step / (rep_ms[len(rep_ms) // 2] * 1e-3) / 1e6, 1),
+            "note": "`value` / `ms_per_step` are the FIRST region (the contract's K steps); the others follow it, each behind a barrier",
+        }
+        # the collective's world as the communicator itself reports it (ncclCommCount through trx_comm_world_size, or
+        # torch.distributed's own count): 1 at N = 1, where no communicator exists
+        rccl_world = 1
+        if world > 1:
+            rccl_world = fgs[0].world_size() if hasattr(fgs[0], "world_size") else dist.get_world_size()
         out = {
             "metric": baseline_metric(),
             "value": round(value, 2),
@@ -791,8 +869,17 @@ def main():
                               "the reference benches); a first frame (natural order while the tiles are measured) in "
                               "legs.first_frame_ms, feedback off in legs.cold_order_ms",
             },
+            # round 5: roofline.frac is the algorithmic fraction (issued_frac = the old figure), roofline_hbm carries the
+            # measured traffic, timed-region repeats, same-protocol N = 1 figure at N > 1, no-wake leg (the round-3 / round-4
+            # lines differ from each other by the wake frames: README "Bench protocol")
+            "protocol_version": 5,
+            "rccl_world": rccl_world,
+            "n1_same_protocol_mrays": round(n1_same, 2) if n1_same else None,
+            "scaling_vs_same_protocol": round(value / n1_same, 3) if n1_same else None,
             "kernel_ms_mean": round(kernel_ms, 4),
             "kernel_ms_min": round(min(launch_ms), 4),
+            "kernel_ms_min_source": ("per-launch hipEvent pairs of an untimed REPLAY of the same frames right after the timed "
+                                     "region" if region_kernel_ms is not None else "per-launch hipEvent pairs of the timed region"),
             # per-launch event times in order (for one frame in flight: of the untimed pass that follows the timed region;
             # kernel_ms_mean is then the timed region's own event pair / steps): shows a schedule or a clock still settling
             "kernel_ms_per_step": [round(x, 4) for x in launch_ms] if len(launch_ms) <= 64 else None,
