@@ -680,6 +680,37 @@ def main():
             nw_ms = n0.elapsed_time(n1) / args.steps
             legs["no_wake"] = {"idle_s": 1.0, "warmup": args.warmup, "steps": args.steps, "kernel_ms_mean": round(nw_ms, 4),
                                "mrays": round(n_rays_total / (nw_ms * 1e-3) / 1e6, 1)}
+        # (k) Traversable::traverse called the way the reference's CPU loop calls it (src/rt_cpu/rt_cpu.rs:35-57): 16 host
+        #     threads, ONE ray per call, every call blocking for its RayHit.  Concurrent callers share launches (the
+        #     per-scene combiner behind trx_traverse1); a caller still waits one GPU round trip per ray, so this is a latency
+        #     figure - threads / round trip - next to which trx_traverse_batch (the same rays in one call) is the throughput one
+        rng = np.random.default_rng(11)
+        n_t1 = 16 * 1500
+        px = rng.integers(0, n_rays_total, n_t1)
+        fx = (px % w + 0.5) / w * 2.0 - 1.0
+        fy = 1.0 - (px // w + 0.5) / h * 2.0
+        fwd = np.array(look, dtype=np.float64) - np.array(eye, dtype=np.float64)
+        fwd /= np.linalg.norm(fwd)
+        right = np.cross(fwd, [0.0, 1.0, 0.0])
+        right /= np.linalg.norm(right)
+        up = np.cross(right, fwd)
+        th = np.tan(np.radians(fov) / 2.0)
+        dirs = fwd[None, :] + (fx * th * w / h)[:, None] * right[None, :] + (fy * th)[:, None] * up[None, :]
+        dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+        t1_rays = np.zeros(n_t1, dtype=T.RAY_DTYPE)
+        t1_rays["origin"] = np.array(eye, dtype=np.float32)
+        t1_rays["direction"] = dirs.astype(np.float32)
+        t1_rays["tmax"] = 3.4028234663852886e38
+        scene.traverse_threads(t1_rays[:512], threads=16, sem=args.sem)           # (creates the combiner, warms the slots)
+        t1_hits, t1_s, t1_launches = scene.traverse_threads(t1_rays, threads=16, sem=args.sem)
+        tb_hits, tb_ms = scene.traverse_batch(t1_rays, sem=args.sem)
+        legs["traverse1_threads"] = {
+            "threads": 16, "rays": n_t1, "mrays": round(n_t1 / t1_s / 1e6, 4), "launches": t1_launches,
+            "rays_per_launch": round(n_t1 / max(t1_launches, 1), 1), "us_per_launch": round(t1_s / max(t1_launches, 1) * 1e6, 1),
+            "equals_traverse_batch": bool((t1_hits == tb_hits).all()),
+            "traverse_batch_kernel_mrays": round(n_t1 / (tb_ms * 1e-3) / 1e6, 1),
+            "note": "one blocking trx_traverse1 call per ray from 16 Python threads; rate = callers in flight / GPU round trip",
+        }
         # (f) compulsory footprint: distinct nodes / triangles one frame touches
         fn, ft = scene.footprint(view, w, h, sem=args.sem)
         legs["footprint"] = {"nodes": fn, "tris": ft, "bytes": NODE_BYTES * fn + TRI_BYTES * ft + HIT_BYTES * n_rays_total}

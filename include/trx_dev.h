@@ -45,6 +45,10 @@ int trx_debug_tri_histogram(trx_scene *scene, const trx_view *view, uint32_t wid
 int trx_debug_tile_profile(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
                            uint32_t semantics, uint32_t *out_cost, uint32_t *out_iters, uint32_t n_tiles);
 
+/* Launches issued and rays served by trx_traverse1's combiner on this scene so far (rays / launches = callers that
+ * shared a launch on average).  Either pointer may be NULL. */
+int trx_debug_traverse1_stats(trx_scene *scene, uint64_t *out_launches, uint64_t *out_rays);
+
 /* Kernel variant selection (tuning aid; 0 = default).  Returns the previous
  * value.  Variants compute identical results. */
 uint32_t trx_set_kernel_variant(uint32_t variant);

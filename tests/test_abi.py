@@ -137,7 +137,7 @@ def build_c_consumer(name, tmp_path):
     exe = str(tmp_path / name)
     libdir = os.path.join(root, "tray_racing_amd")
     subprocess.check_call(["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
-                           os.path.join(root, "tests", "c_abi", name + ".c"), "-o", exe, "-L", libdir, "-ltrx",
+                           os.path.join(root, "tests", "c_abi", name + ".c"), "-o", exe, "-pthread", "-L", libdir, "-ltrx",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 

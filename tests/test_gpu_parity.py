@@ -815,6 +815,37 @@ def test_c_program_over_the_abi_matches_the_oracle(trx, orc, tmp_path):
     assert (got_p, got_a) == (fnv(prim), fnv(ao))
 
 
+def test_sixteen_threads_call_traverse_for_their_pixels(trx, orc, tmp_path):
+    """The reference's CPU pixel loop over the LITERAL Traversable::traverse (src/rt_cpu/rt_cpu.rs:35-57,
+    traversable/src/lib.rs:13-28): tests/c_abi/traverse_threads.c runs 16 host threads, each calling trx_traverse1 for
+    its pixels of the 512x1080 demoscene-class frame (configs[0]'s image; 500 000 triangles), one ray per call.  Every
+    RayHit equals the oracle's hit for that ray, and the calls shared launches (the per-scene combiner): far fewer
+    launches than rays."""
+    import subprocess
+    from test_abi import build_c_consumer
+    exe = build_c_consumer("traverse_threads", tmp_path)
+    w, h, tris, threads = 512, 1080, 500000, 16
+    flat, _view, osc, ov = make_scene(trx, orc, "demoscene", tris, w, h)
+    rays = osc.primary_rays(ov, w, h)
+    rays_path, hits_path = str(tmp_path / "rays.bin"), str(tmp_path / "hits.bin")
+    np.ascontiguousarray(rays).tofile(rays_path)
+    out = subprocess.run([exe, "demoscene", str(tris), str(threads), "3", rays_path, hits_path], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr
+    n, secs, launches = out.stdout.split()
+    assert int(n) == w * h
+    got = np.fromfile(hits_path, dtype=np.dtype([("primitive_id", "<u4"), ("geometry_id", "<u4"), ("instance_id", "<u4"), ("t", "<f4")]))
+    want, _ = osc.trace_rays(rays, sem=3)
+    miss = want["prim"] == 0xFFFFFFFF
+    assert (~miss).any()
+    assert (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+    assert (got["primitive_id"] == want["prim"]).all()
+    assert (got["geometry_id"][~miss] == 0).all() and (got["geometry_id"][miss] == 0xFFFFFFFF).all()
+    # 16 callers blocked at a time: a launch carries up to 16 rays (and at least a few on average)
+    assert int(launches) < w * h / 3, (launches, secs)
+    print("traverse1 x %d threads: %.3f Mrays/s, %.1f rays per launch" % (threads, w * h / float(secs) / 1e6, w * h / int(launches)))
+
+
 def test_fixed_seed_slice_of_the_fuzzer(trx, orc):
     """tests/fuzz_gpu.py: random scenes, cameras, sizes, semantics, triangle formats, TLAS, shards, batch launches
     and query kinds against the oracle, bit for bit; a fixed-seed slice here, `python tests/fuzz_gpu.py --minutes N`

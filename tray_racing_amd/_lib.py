@@ -120,6 +120,7 @@ SIGNATURES = {
     "trx_trace_rays": (_i, [_P, _P, _u64, _u32, _P, C.POINTER(_f)]),
     "trx_trace_rays_inst": (_i, [_P, _P, _u64, _u32, _P, _P, C.POINTER(_f)]),
     "trx_traverse1": (_i, [_P, C.POINTER(Ray), _u32, C.POINTER(RayHit)]),
+    "trx_debug_traverse1_stats": (_i, [_P, C.POINTER(_u64), C.POINTER(_u64)]),
     "trx_traverse_batch": (_i, [_P, _P, _u64, _u32, _P, C.POINTER(_f)]),
     "trx_bench_primary": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _u32, _u32, C.POINTER(_f), C.POINTER(_f)]),
     "trx_set_kernel_variant": (_u32, [_u32]),
@@ -186,7 +187,14 @@ def load():
         pass
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            # (an OLDER build under TRX_LIB, for A/B runs: diagnostics added since are simply absent; the product library
+            # exports every symbol - tests/test_abi.py)
+            if name.startswith("trx_debug_") and os.environ.get("TRX_LIB"):
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     _lib = lib

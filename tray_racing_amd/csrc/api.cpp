@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -23,6 +24,11 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <climits>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "../../include/trx.h"
 #include "../../include/trx_dev.h"
@@ -133,6 +139,103 @@ int fail_msg(int code, const char *fmt, ...) {
 }
 } // namespace trx
 
+// trx_traverse1 is Traversable::traverse(&self, Ray) -> RayHit (traversable/src/lib.rs:13-28), called per pixel from every
+// worker of a thread pool at once (src/rt_cpu/rt_cpu.rs:35-57).  One launch per ray would be a host-to-device copy, a
+// one-wave launch, a copy back and a stream synchronisation for 32 bytes of work (rounds 1-4: ~25 k rays a second per
+// thread); so the callers that are inside trx_traverse1 at the same time share launches.  A caller drops its ray into the
+// open batch (pinned host memory the kernel reads and writes in place: no copies) and takes a ticket; the first one in
+// is the batch's leader: it waits until arrivals stop for a few microseconds (or kCap rays, or kMaxWait), closes the
+// batch, launches it on the batch's own stream, waits for it and wakes the others, who read their records by ticket.
+// Rays and results are those of the single-ray path; a caller still blocks for one GPU round trip (launch + completion,
+// 15-30 us), so the rate is (callers inside at once) / (round trip): it scales with the thread count, not with the GPU.
+struct RayCombiner {
+    static constexpr uint32_t kCap = 4096, kBatches = 4;
+    static constexpr int64_t kQuietNs = 3000, kMaxWaitNs = 50000;
+    // A wave steps a handful of rays about twice as fast as a few dozen (eight lanes to a ray, kernels.hip "thin waves"),
+    // and a small batch is all latency: its first kSpread rays are dealt eight to a 64-ray chunk - one wave each - the rest
+    // of a chunk being rays that end at the root (tmax < 0).  Ticket i's record sits at slot(i).
+    static constexpr uint32_t kSpread = 512, kSpreadSlots = kSpread / 8 * 64, kSlots = kSpreadSlots + (kCap - kSpread);
+    static uint32_t slot(uint32_t i) { return i < kSpread ? (i >> 3) * 64u + (i & 7u) : kSpreadSlots + (i - kSpread); }
+    static uint32_t slots_used(uint32_t n) { return n <= kSpread ? ((n + 7u) >> 3) * 64u : kSpreadSlots + (n - kSpread); }
+    static trx_ray null_ray() {
+        trx_ray r;
+        std::memset(&r, 0, sizeof(r));
+        r.direction[0] = 1.0f;
+        r.tmax = -1.0f; // nothing lies in [0, -1]: the root's test fails and the ray is finished after one step
+        return r;
+    }
+    struct Batch {
+        trx_ray *rays = nullptr;  // pinned, device-visible
+        trx_hit *hits = nullptr;
+        uint32_t *inst = nullptr;
+        uint32_t *over = nullptr; // pinned word the kernel sets when a ray of the batch overflowed its stack / hit the step cap
+        hipStream_t stream = nullptr;
+        uint32_t n = 0, sem = 0;
+        std::atomic<uint32_t> read{0};       // callers that have taken their record (the last one frees the batch)
+        int rc = 0;
+        std::string err;
+        enum State { kFree, kOpen, kFlying, kDone } state = kFree;
+        // bumped when the batch's results are in: followers spin on it, then sleep on it (a futex: a woken follower reads
+        // its record and leaves without taking any lock - woken through a condition variable they queued up on its mutex,
+        // 5-10 us each, and arrived at the next batch one by one)
+        std::atomic<uint32_t> done_epoch{0};
+    } batch[kBatches];
+    std::mutex mu;
+    std::condition_variable cv;              // the open batch changed, or a batch became free
+    std::atomic<int> inside{0};              // callers inside trx_traverse1 (spinning only pays while they fit the host's cores)
+    int cores = 1;
+    int open = -1;
+    int device = 0;
+    bool ok = false;
+    std::string init_err;
+    uint64_t launches = 0, rays = 0; // statistics (trx_debug_traverse1_stats)
+
+    explicit RayCombiner(int dev) : device(dev) {
+        for (Batch &b : batch) {
+            hipError_t e = hipHostMalloc((void **)&b.rays, kSlots * sizeof(trx_ray), hipHostMallocDefault);
+            if (e == hipSuccess) e = hipHostMalloc((void **)&b.hits, kSlots * sizeof(trx_hit), hipHostMallocDefault);
+            if (e == hipSuccess) e = hipHostMalloc((void **)&b.inst, kSlots * sizeof(uint32_t), hipHostMallocDefault);
+            if (e == hipSuccess)
+                for (uint32_t i = 0; i < kSpreadSlots; i++) b.rays[i] = null_ray();
+            if (e == hipSuccess) e = hipHostMalloc((void **)&b.over, 64, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking);
+            if (e != hipSuccess) {
+                init_err = hipGetErrorString(e);
+                return;
+            }
+        }
+        cores = (int)std::max(1u, std::thread::hardware_concurrency());
+        ok = true;
+    }
+    ~RayCombiner() {
+        for (Batch &b : batch) {
+            if (b.stream) (void)hipStreamDestroy(b.stream);
+            if (b.rays) (void)hipHostFree(b.rays);
+            if (b.hits) (void)hipHostFree(b.hits);
+            if (b.inst) (void)hipHostFree(b.inst);
+            if (b.over) (void)hipHostFree(b.over);
+        }
+    }
+};
+
+static void futex_wait(std::atomic<uint32_t> *a, uint32_t while_value) {
+    static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(a), FUTEX_WAIT_PRIVATE, while_value, nullptr, nullptr, 0);
+}
+static void futex_wake_all(std::atomic<uint32_t> *a) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(a), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+static int64_t now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
 struct trx_scene {
     int device = 0;
     uint4 *d_nodes = nullptr;
@@ -160,6 +263,8 @@ struct trx_scene {
     uint64_t scratch_hits = 0, scratch_rays = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<uint32_t> blas_tri_start; // geometry_id lookup for trx_traverse1
+    RayCombiner *comb = nullptr;   // trx_traverse1: concurrent single-ray callers share launches (created on first use)
+    std::once_flag comb_once;
     // instance transforms (TLAS scenes): object-to-world as given (get_instance_transform), world-to-object rows as
     // the kernels use them, and their device copy; empty / null = identity
     std::vector<float> inst_o2w, inst_w2o;
@@ -462,7 +567,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     if (p.tune & 0x80000u) p.uni_decode = 0u;
 #endif
     p.wave_times = s->d_wave_times;
-    p.single_queue = (variant >> 21) & 1u;
+    p.single_queue = ((variant >> 21) & 1u) | (p.single_queue ? 1u : 0u); // (a caller may ask for it: trx_traverse1's small batches)
     // tile order feedback (image modes, whole-tile refills only)
     // (an AO batch deals its tiles seed by seed within a queue: it has no tile order to learn)
     const bool lpt = mode != kModeRays && mode != kModeFused && p.refill_idle == 64u && !((variant >> 20) & 1u) &&
@@ -764,6 +869,7 @@ void trx_scene_destroy(trx_scene *s) {
     }
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s->comb;
     delete s;
 }
 
@@ -1108,7 +1214,7 @@ int trx_trace_ao_batch_dev(trx_scene *s, const trx_view *view, uint32_t w, uint3
 
 static int trace_rays_impl(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint32_t sem, trx_hit *d_hits,
                            hipStream_t stream, bool count, SlotCounters **ctr, bool any_hit = false,
-                           uint32_t *d_inst = nullptr) {
+                           uint32_t *d_inst = nullptr, uint32_t *over_host = nullptr, bool one_queue = false) {
     // the work queue is 32-bit: split very large batches
     const uint64_t chunk = 1ull << 30;
     for (uint64_t off = 0; off < n; off += chunk) {
@@ -1118,6 +1224,8 @@ static int trace_rays_impl(trx_scene *s, const trx_ray *d_rays, uint64_t n, uint
         p.out = any_hit ? reinterpret_cast<trx_hit *>(reinterpret_cast<uint8_t *>(d_hits) + off) : d_hits + off;
         p.any_hit = any_hit ? 1u : 0u;
         p.out_inst = d_inst ? d_inst + off : nullptr;
+        p.over_host = over_host;
+        p.single_queue = one_queue ? 1u : 0u;
         p.n_items = (uint32_t)std::min(chunk, n - off);
         int rc = enqueue(s, p, kModeRays, sem, count, stream, ctr);
         if (rc) return rc;
@@ -1408,50 +1516,6 @@ int trx_trace_occluded(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t s
     return trx_scene_check(s, nullptr);
 }
 
-namespace {
-// One stream + one {ray, hit} device pair per calling thread and device: a thread's successive single-ray
-// queries reuse them (and therefore one launch slot), concurrent threads never share them (Traversable: Sync).
-struct ThreadRayLane {
-    int device = -1;
-    hipStream_t stream = nullptr;
-    trx_ray *d_ray = nullptr;
-    trx_hit *d_hit = nullptr; // {hit, instance id}: 12 bytes
-};
-struct ThreadRayLanes {
-    std::vector<ThreadRayLane> lanes;
-    ~ThreadRayLanes() {
-        for (ThreadRayLane &l : lanes) {
-            if (hipSetDevice(l.device) != hipSuccess) continue;
-            if (l.stream) (void)hipStreamDestroy(l.stream);
-            if (l.d_ray) (void)hipFree(l.d_ray);
-            if (l.d_hit) (void)hipFree(l.d_hit);
-        }
-    }
-};
-thread_local ThreadRayLanes t_ray_lanes;
-
-int thread_ray_lane(int device, ThreadRayLane **out) {
-    for (ThreadRayLane &l : t_ray_lanes.lanes)
-        if (l.device == device) {
-            *out = &l;
-            return TRX_OK;
-        }
-    ThreadRayLane l;
-    l.device = device;
-    HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-    hipError_t e = hipMalloc(&l.d_ray, sizeof(trx_ray));
-    if (e == hipSuccess) e = hipMalloc(&l.d_hit, sizeof(trx_hit) + sizeof(uint32_t));
-    if (e != hipSuccess) {
-        (void)hipStreamDestroy(l.stream);
-        if (l.d_ray) (void)hipFree(l.d_ray);
-        return fail(TRX_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e));
-    }
-    t_ray_lanes.lanes.push_back(l);
-    *out = &t_ray_lanes.lanes.back();
-    return TRX_OK;
-}
-} // namespace
-
 // {t, global triangle} (+ the TLAS primitive it was found in) as obvhs' RayHit: (geometry_id, primitive_id local to
 // that geometry) like src/cwbvh.rs:151-160 when the geometry ranges are known, RayHit::none() for a miss.
 static void to_rayhit(const trx_scene *s, const trx_hit h, uint32_t inst, trx_rayhit *out) {
@@ -1475,20 +1539,128 @@ static void to_rayhit(const trx_scene *s, const trx_hit h, uint32_t inst, trx_ra
 
 int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *out) {
     if (!s || !ray || !out) return fail(TRX_ERR_INVALID, "null argument");
+    if (sem & ~7u) return fail(TRX_ERR_INVALID, "unknown semantics bits 0x%x", sem);
     HIP_TRY(hipSetDevice(s->device));
-    ThreadRayLane *lane = nullptr;
-    int rc = thread_ray_lane(s->device, &lane);
+    std::call_once(s->comb_once, [s]() { s->comb = new (std::nothrow) RayCombiner(s->device); });
+    RayCombiner *c = s->comb;
+    if (!c || !c->ok) return fail(TRX_ERR_OOM, "single-ray combiner: %s", c ? c->init_err.c_str() : "allocation failed");
+    struct Inside { // (counted while inside: a caller spins for its batch only while the callers fit the host's cores)
+        std::atomic<int> &n;
+        explicit Inside(std::atomic<int> &a) : n(a) { n.fetch_add(1, std::memory_order_relaxed); }
+        ~Inside() { n.fetch_sub(1, std::memory_order_relaxed); }
+    } inside(c->inside);
+    std::unique_lock<std::mutex> lock(c->mu);
+    bool leader = false;
+    int bi = -1;
+    for (;;) {
+        if (c->open >= 0) {
+            if (c->batch[c->open].sem == sem) {
+                bi = c->open;
+                break;
+            }
+            c->cv.wait(lock); // an open batch of another semantics closes within kMaxWait: wait for it rather than mix
+            continue;
+        }
+        for (int i = 0; i < (int)RayCombiner::kBatches && bi < 0; i++)
+            if (c->batch[i].state == RayCombiner::Batch::kFree) bi = i;
+        if (bi >= 0) {
+            RayCombiner::Batch &nb = c->batch[bi];
+            nb.state = RayCombiner::Batch::kOpen;
+            nb.sem = sem;
+            nb.n = 0;
+            nb.read.store(0, std::memory_order_relaxed);
+            nb.rc = 0;
+            c->open = bi;
+            leader = true;
+            break;
+        }
+        c->cv.wait(lock); // every batch is in flight or being read: one frees up when its last reader leaves
+    }
+    RayCombiner::Batch &b = c->batch[bi];
+    const uint32_t idx = b.n++;
+    b.rays[RayCombiner::slot(idx)] = *ray;
+    const uint32_t epoch = b.done_epoch.load(std::memory_order_relaxed);
+    if (b.n == RayCombiner::kCap) c->open = -1; // full: closed to later arrivals (its leader notices)
+    if (leader) {
+        // Wait for company.  Everyone who can still join is inside this function and not attached to another batch: once
+        // they are all here (and nobody new has turned up for kQuiet), go; kMaxWait bounds the wait either way.
+        const int64_t t0 = now_ns();
+        int64_t t_last = t0;
+        uint32_t seen = b.n;
+        while (c->open == bi) {
+            lock.unlock();
+            if (c->inside.load(std::memory_order_relaxed) > c->cores) std::this_thread::yield(); // (callers that have no core yet)
+            else for (int k = 0; k < 16; k++) cpu_relax();
+            lock.lock();
+            const int64_t t = now_ns();
+            if (b.n != seen) {
+                seen = b.n;
+                t_last = t;
+            }
+            uint32_t elsewhere = 0;
+            for (int j = 0; j < (int)RayCombiner::kBatches; j++)
+                if (j != bi && c->batch[j].state != RayCombiner::Batch::kFree)
+                    elsewhere += c->batch[j].n - std::min(c->batch[j].n, c->batch[j].read.load(std::memory_order_relaxed));
+            const int expected = c->inside.load(std::memory_order_relaxed) - (int)elsewhere;
+            if (((int)b.n >= expected && t - t_last > RayCombiner::kQuietNs) || t - t0 > RayCombiner::kMaxWaitNs) break;
+        }
+        if (c->open == bi) c->open = -1;
+        const uint32_t n = b.n;
+        b.state = RayCombiner::Batch::kFlying;
+        c->launches++;
+        c->rays += n;
+        lock.unlock();
+        c->cv.notify_all(); // (callers waiting for an open batch of their own semantics)
+        *b.over = 0u;
+        int rc = trace_rays_impl(s, b.rays, RayCombiner::slots_used(n), sem, b.hits, b.stream, false, nullptr, false,
+                                 s->tlas ? b.inst : nullptr, b.over, n <= RayCombiner::kSpread);
+        if (!rc && hipStreamSynchronize(b.stream) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "sync failed");
+        if (!rc && *reinterpret_cast<volatile uint32_t *>(b.over) != 0u)
+            rc = fail(TRX_ERR_STACK_OVERFLOW, "a ray overflowed the %d-entry traversal stack (or the step cap)", kLdsStack + kSpillStack);
+        b.rc = rc;
+        if (rc) b.err = g_err;
+        b.done_epoch.fetch_add(1, std::memory_order_release);
+        if (n > 1) futex_wake_all(&b.done_epoch);
+    } else {
+        // a follower spins on the batch's epoch for about a round trip (when it has a core to spin on), then sleeps on it
+        lock.unlock();
+        if (c->inside.load(std::memory_order_relaxed) <= c->cores) {
+            const int64_t t0 = now_ns();
+            while (b.done_epoch.load(std::memory_order_acquire) == epoch && now_ns() - t0 < 300000)
+                for (int k = 0; k < 16; k++) cpu_relax();
+        }
+        while (b.done_epoch.load(std::memory_order_acquire) == epoch) futex_wait(&b.done_epoch, epoch);
+    }
+    // (no lock: the batch's records stay put until its last reader has left)
+    const int rc = b.rc;
+    if (rc && !leader) g_err = b.err;
+    const uint32_t at = RayCombiner::slot(idx);
+    const trx_hit h = b.hits[at];
+    const uint32_t inst = s->tlas ? b.inst[at] : 0xFFFFFFFFu;
+    if (idx < RayCombiner::kSpread) b.rays[at] = RayCombiner::null_ray(); // (the slot goes back to being padding)
+    const uint32_t n_final = b.n;
+    if (b.read.fetch_add(1, std::memory_order_acq_rel) + 1 == n_final) { // last reader out: the batch can be opened again
+        lock.lock();
+        b.state = RayCombiner::Batch::kFree;
+        lock.unlock();
+        c->cv.notify_all();
+    }
     if (rc) return rc;
-    hipStream_t st = lane->stream;
-    struct { trx_hit h; uint32_t inst; } rec{};
-    rec.inst = 0xFFFFFFFFu;
-    uint32_t *d_inst = reinterpret_cast<uint32_t *>(lane->d_hit + 1);
-    if (hipMemcpyAsync(lane->d_ray, ray, sizeof(trx_ray), hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "copy failed");
-    if (!rc) rc = trace_rays_impl(s, lane->d_ray, 1, sem, lane->d_hit, st, false, nullptr, false, s->tlas ? d_inst : nullptr);
-    if (!rc && hipMemcpyAsync(&rec, lane->d_hit, s->tlas ? 12 : 8, hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "copy failed");
-    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "sync failed");
-    if (rc) return rc;
-    to_rayhit(s, rec.h, rec.inst, out);
+    to_rayhit(s, h, inst, out);
+    return TRX_OK;
+}
+
+// Launches and rays the single-ray combiner has served so far (development / tests: rays / launches = callers per launch).
+int trx_debug_traverse1_stats(trx_scene *s, uint64_t *out_launches, uint64_t *out_rays) {
+    if (!s) return fail(TRX_ERR_INVALID, "null argument");
+    uint64_t l = 0, r = 0;
+    if (s->comb) {
+        std::lock_guard<std::mutex> lock(s->comb->mu);
+        l = s->comb->launches;
+        r = s->comb->rays;
+    }
+    if (out_launches) *out_launches = l;
+    if (out_rays) *out_rays = r;
     return TRX_OK;
 }
 

@@ -141,6 +141,8 @@ struct TraceParams {
     uint32_t new_view;    // camera cut: the schedule tuner starts over
     uint32_t uni_decode;  // coherent primary walk: decode the child planes of a node step once per wave when every lane visits the same node
     uint32_t any_hit;     // explicit rays only: stop at the first accepted hit, write one byte (0/1) per ray
+    uint32_t *over_host;  // null, or a word in pinned host memory that is set when a ray of THIS launch overflows (trx_traverse1:
+                          // the caller learns it from the word, without a device-to-host copy of the slot's sticky counter)
     // frames per launch: primary passes - frame f = local_tile / tiles_per_frame uses views[f]; AO passes - one view
     // (views[0]) and one primary buffer, frame f uses the noise seed frame + f (a tile's seeds are consecutive tickets of
     // one queue); either way frame f writes its records at out + f * frame_stride

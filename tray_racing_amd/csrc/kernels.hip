@@ -2045,7 +2045,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 
     // ---- epilogue: flags, counters, queue reset ---------------------------------------
     if (lpt_write && n_pend) flush_pending(P, wr_set, lds_pend, n_pend, lane);
-    if (c_over) atomicAdd(&P.ctr->overflow, c_over);
+    if (c_over) {
+        atomicAdd(&P.ctr->overflow, c_over);
+        if (P.over_host) *P.over_host = 1u;
+    }
     if (COUNT) {
         atomicAdd(&P.ctr->n_rays, (unsigned long long)c_rays);
         atomicAdd(&P.ctr->n_node, (unsigned long long)c_node);
