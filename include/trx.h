@@ -281,8 +281,10 @@ int trx_trace_primary_batch_dev(trx_scene *scene, const trx_view *views, uint32_
  * primary ray missed get a miss record.  ao_eps: 0.0001 (GPU) / 0.01 (CPU).
  * The direction's sin / cos (sampling.hlsl:33-34 calls the platform's; on the CPU path Rust's f32::sin / cos are the C
  * library's sinf / cosf) are evaluated explicitly so that results reproduce bit for bit across machines: the binary64
- * algorithm the GNU C library (2.28 and later) publishes for sinf / cosf, rounded once to binary32 - identical to glibc's
- * sinf / cosf for every binary32 in [0, 2 pi], so on a Linux host the AO directions are the reference CPU path's own.
+ * algorithm the GNU C library (2.28 and later) publishes for sinf / cosf, rounded once to binary32 - measured identical to
+ * glibc 2.35's sinf / cosf on x86_64 for every binary32 in [0, 2 pi] (tests/test_oracle.py; other glibc versions and
+ * architectures pick other variants and may differ in the last bit), so on such a host the AO directions are the
+ * reference CPU path's own.
  * Against a correctly rounded sin / cos (another C library) the AO hit's t moves in its last bits on a fraction of a
  * per cent of the rays. */
 int trx_trace_ao_dev(trx_scene *scene, const trx_view *view, uint32_t width,

@@ -140,8 +140,13 @@ def test_sincos_is_the_c_librarys_sinf_and_cosf_bit_for_bit(orc):
     directions are those of the reference's CPU path (Rust's f32::sin / cos call the C library).  Every binary32 in
     [0, 2 pi] - the whole domain of theta = u2 * tau, 1.09e9 values, a few seconds on all cores."""
     import platform
-    if platform.libc_ver()[0] != "glibc":
+    name, ver = platform.libc_ver()
+    if name != "glibc":
         pytest.skip("the C library here is not glibc")
+    if tuple(int(x) for x in ver.split(".")[:2]) < (2, 28):
+        pytest.skip("glibc %s predates the sinf / cosf algorithm this restates (2.28)" % ver)
+    if platform.machine() not in ("x86_64", "AMD64"):
+        pytest.skip("measured identical on x86_64 only (glibc picks its sinf variant per architecture)")
     lib = orc.load()
     hi = int(np.float32(6.28318530717958647692).view(np.uint32))
     assert lib.orc_sincos_libm_mismatches(0, hi + 64, 1) == 0

@@ -1,8 +1,11 @@
-"""Prints the per-config table of DESIGN.md section 5 from profiles/r04_traffic_<config>.json (tools/update_profiles_r04.py)."""
+"""Prints the per-config table of DESIGN.md section 5 from profiles/rNN_traffic_<config>.json (tools/profile_summary.py).
+usage: python tools/design_table.py [--round N]"""
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = int(sys.argv[sys.argv.index("--round") + 1]) if "--round" in sys.argv else 5
 ROWS = [("primary_bistro", "bistro-class primary 1080p (configs[2])"), ("primary_bistro_dense", "dense bistro-class primary"),
         ("primary_hairball", "hairball-class primary"), ("ao_bistro", "bistro-class AO pass (1.94 M rays)"),
         ("ao_hairball", "hairball-class AO pass (0.59 M rays)"), ("ao4_hairball", "hairball-class 4 spp, one launch (configs[3])"),
@@ -10,7 +13,7 @@ ROWS = [("primary_bistro", "bistro-class primary 1080p (configs[2])"), ("primary
 print("| config | kernel | ms | Mrays/s | nodes / tris per ray | requested GB/s | HBM GB/s measured (of 8 TB/s) | L1 / L2 hit | VALU issue | waitcnt / issue-stall |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 for cfg, label in ROWS:
-    path = os.path.join(ROOT, "profiles", "r04_traffic_%s.json" % cfg)
+    path = os.path.join(ROOT, "profiles", "r%02d_traffic_%s.json" % (ROUND, cfg))
     if not os.path.exists(path):
         continue
     d = json.load(open(path))

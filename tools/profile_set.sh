@@ -1,10 +1,11 @@
 #!/bin/bash
-# Round-4 profile set (run on the GPU box; output under gpurun_out/prof_r04, summarised by tools/update_profiles_r04.py).
+# The profile set of a round (run on the GPU box: ROUND=5 tools/profile_set.sh; output under gpurun_out/prof_rNN, summarised by
+# tools/profile_summary.py --round N).  One script for every round: rounds 1-4 each carried a copy with the tag changed.
 # Every rocprofv3 pass runs under `timeout`; the program itself follows `--` (no wrappers); counters in their own
 # passes with --kernel-trace only.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/prof_r04
+out=gpurun_out/prof_r$(printf %02d "${ROUND:-5}")
 mkdir -p "$out"
 if [ -z "$SKIP_BENCH" ]; then   # (a call is limited to 20 minutes: the seven configs go in three calls, the bench line in the first)
 python3 bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"
@@ -25,4 +26,4 @@ for cfg in ${CONFIGS:-primary_bistro primary_bistro_dense primary_hairball ao_bi
     tail -1 "$out/$cfg.pmc$i.log" | cut -c1-160
   done
 done
-python3 tools/update_profiles_r04.py "$out" --dry
+python3 tools/profile_summary.py --round "${ROUND:-5}" "$out" --dry

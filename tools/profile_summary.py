@@ -1,7 +1,8 @@
-"""Summarises the output of tools/gpu_profiles_r04.sh into profiles/ (round 4): the bench line, the rocprofv3 kernel
+"""Summarises the output of tools/profile_set.sh into profiles/ (files rNN_*): the bench line, the rocprofv3 kernel
 stats of the bench command, and per config one traffic_<config>.json (requested GB/s, measured HBM GB/s, L1 / L2 hit
 rates, VALU issue, wave-cycle split) plus the counter CSV rows of the traversal kernel it was computed from.
-usage: python tools/update_profiles_r03.py [gpurun_out/prof_r04] [--dry]"""
+(One script for every round: rounds 2-4 each carried a copy of it with the tag changed.)
+usage: python tools/profile_summary.py --round N [gpurun_out/prof_rNN] [--dry]"""
 import ast
 import csv
 import glob
@@ -12,11 +13,17 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
-dry = "--dry" in sys.argv
-src = args[0] if args else os.path.join(ROOT, "gpurun_out", "prof_r04")
+argv = sys.argv[1:]
+ROUND = 5
+if "--round" in argv:
+    k = argv.index("--round")
+    ROUND = int(argv[k + 1])
+    del argv[k:k + 2]
+args = [a for a in argv if not a.startswith("--")]
+dry = "--dry" in argv
+TAG = "r%02d" % ROUND
+src = args[0] if args else os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
 dst = os.path.join(ROOT, "profiles")
-TAG = "r04"
 NODE_B, TRI_B, HIT_B = 80, 48, 8
 SIMDS, CLOCK_GHZ, VALU_CYCLES = 1024, 2.4, 2.0
 HBM_PEAK = 8000.0
@@ -157,8 +164,8 @@ def main():
                    "FETCH_SIZE_KB_per_launch": t["FETCH_SIZE_KB"], "WRITE_SIZE_KB_per_launch": t["WRITE_SIZE_KB"],
                    "correction": t["correction"], "algorithmic_bytes_per_launch": t["requested_bytes_per_launch"],
                    "valu_wave_insts_per_launch": t.get("valu_wave_insts_per_launch"),
-                   "command": "tools/gpu_profiles_r04.sh (rocprofv3 --kernel-trace --pmc <group> -- python3 tools/prof_config.py primary_bistro 6)",
-                   "round": 3}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+                   "command": "tools/profile_set.sh (rocprofv3 --kernel-trace --pmc <group> -- python3 tools/prof_config.py primary_bistro 6)",
+                   "round": ROUND}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     # table for DESIGN.md
     print("\n| config | kernel ms | Mrays/s | nodes/ray | tris/ray | requested GB/s | HBM GB/s (measured) | L1 hit | L2 hit | VALU issue | waitcnt / issue stall |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")

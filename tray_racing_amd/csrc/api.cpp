@@ -894,6 +894,14 @@ int trx_scene_set_geometry_ranges(trx_scene *s, const uint32_t *blas_tri_start, 
     return TRX_OK;
 }
 
+// The scene under a launch slot's frozen tile order changed (instances moved, entry nodes replaced): the next frame of
+// every slot files a new order even if its camera has not moved - an order learnt for other geometry is only stale, never
+// wrong, but a static camera would replay it for ever.  Call with s->mu held.
+static void forget_tile_orders(trx_scene *s) {
+    for (Slot &sl : s->slots)
+        for (auto &o : sl.order) o.have_views = false;
+}
+
 // Entry nodes: TLAS primitive k starts its BLAS walk at node entry_nodes[k] of the BLAS at instance_offsets[k] instead
 // of node 0, so one BLAS can be referenced as several subtrees (re-braiding: a BLAS whose box spans the scene no longer
 // makes every ray enter it at the root).  Validated like the node buffer: an entry must lie inside its BLAS segment.
@@ -926,6 +934,7 @@ int trx_scene_set_instance_entry_nodes(trx_scene *s, const uint32_t *entry_nodes
         std::lock_guard<std::mutex> lock(s->mu);
         old = s->d_inst_entry;
         s->d_inst_entry = fresh;
+        forget_tile_orders(s);
     }
     HIP_TRY(hipDeviceSynchronize());
     if (old) (void)hipFree(old);
@@ -947,6 +956,7 @@ int trx_scene_set_instance_transforms(trx_scene *s, const float *object_to_world
             std::lock_guard<std::mutex> lock(s->mu);
             old = s->d_inst_xform;
             s->d_inst_xform = fresh;
+            forget_tile_orders(s);
         }
         HIP_TRY(hipDeviceSynchronize());
         if (old) (void)hipFree(old);

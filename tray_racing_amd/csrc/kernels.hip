@@ -644,6 +644,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave);
     const bool tie_first = P.tie_first != 0;
     if (P.wave_times && lane == 0) P.wave_times[kWaveTimeStride * wave_global] = wall_clock64();
+    // (counting kernels, never timed: what refill_params() reads back IS this launch's parameter block - a second kernel
+    // parameter or kernel-argument preloading would move it; a mismatch is reported as a failed launch)
+    if (COUNT && lane == 0 && refill_params()->n_items != P.n_items) atomicAdd(&P.ctr->overflow, 1u);
 #ifdef TRX_TAIL_DIAG
     // (diagnostic builds only, tools/gpu_tail.py: what was every wave's LAST tile, and when did it start?)
     unsigned long long diag_t0 = 0ull, diag_chunk = 0ull, diag_tiles = 0ull;
@@ -904,7 +907,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // (wave-uniform) may this wave go thin now?  Queues dry, a handful of rays, every stack inside its LDS part, no
     // hand-over with the other wave of the workgroup pending, no lane of a fused frame waiting to become an AO ray.
     auto thin_now = [&](uint32_t alive) -> bool {
-        return exhausted && alive != 0u && alive <= (kFused ? min(P.thin_max, 8u) : P.thin_max) && !(kMerge && merge_open) &&
+        // (never more rays than the walks compiled in can hold, whatever the launch parameter says: 8 << (TRX_THIN_LEVELS - 1))
+        constexpr uint32_t kHold = kFused ? 8u : 8u << (TRX_THIN_LEVELS - 1);
+        return exhausted && alive != 0u && alive <= (P.thin_max < kHold ? P.thin_max : kHold) && !(kMerge && merge_open) &&
                __ballot(has_ray && sp > (uint32_t)kLdsStack) == 0ull && !(kFused && __ballot(pend) != 0ull);
     };
     auto thin_walk = [&](auto lanes_per_ray) {
