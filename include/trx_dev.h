@@ -45,11 +45,6 @@ int trx_debug_tri_histogram(trx_scene *scene, const trx_view *view, uint32_t wid
 int trx_debug_tile_profile(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
                            uint32_t semantics, uint32_t *out_cost, uint32_t *out_iters, uint32_t n_tiles);
 
-/* Experiment builds (-DTRX_POOL=1): the drain pool's counters since the last call, summed over the scene's launch slots -
- * rays parked, taken, turned away, records refused by the sanity check, reservations, slots reserved, 0, 0.  Synchronises
- * the device.  (Zeros in the product build.) */
-int trx_debug_pool_stats(trx_scene *scene, uint32_t out[8]);
-
 /* Launches issued and rays served by trx_traverse1's combiner on this scene so far (rays / launches = callers that
  * shared a launch on average).  Either pointer may be NULL. */
 int trx_debug_traverse1_stats(trx_scene *scene, uint64_t *out_launches, uint64_t *out_rays);

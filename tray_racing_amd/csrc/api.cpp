@@ -108,9 +108,6 @@ struct Slot {
     SlotCounters *ctr = nullptr;
     uint2 *spill = nullptr;
     uint32_t spill_waves = 0;  // waves the spill area is sized for
-    PoolCtl *pool_ctl = nullptr;        // the drain's orphan pool (TRX_POOL builds): cursors, records, slot tags
-    unsigned long long *pool = nullptr, *pool_tags = nullptr;
-    uint32_t pool_cap = 0, pool_waves = 0; // slots; waves the record area is sized for
     hipEvent_t done = nullptr; // everything enqueued for this slot has finished
     bool used = false;
     hipStream_t last_stream = nullptr; // stream of the last launch on this slot
@@ -495,42 +492,6 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         HIP_TRY(hipMalloc(&slot.spill, (size_t)grid * kSpillStack * kWave * sizeof(uint2)));
         slot.spill_waves = (uint32_t)grid;
     }
-#if TRX_POOL
-    {   // the drain's orphan pool: incoherent single-level passes (kernels.hip, "The pool")
-#ifndef TRX_POOL_PARK
-#define TRX_POOL_PARK 32
-#endif
-        static const int pool_env[2] = {getenv("TRX_POOL_OFF") ? 1 : 0, getenv("TRX_POOL_PARK") ? atoi(getenv("TRX_POOL_PARK")) : TRX_POOL_PARK};
-        const bool want_pool = !pool_env[0] && mode != kModePrimary && mode != kModeFused && !s->tlas && !count && grid >= 64;
-        p.pool_ctl = nullptr;
-        if (want_pool) {
-            const uint32_t waves = (uint32_t)grid;
-            if (slot.pool_waves < waves) {
-                if (slot.used) HIP_TRY(hipEventSynchronize(slot.done));
-                if (slot.pool) (void)hipFree(slot.pool);
-                if (slot.pool_tags) (void)hipFree(slot.pool_tags);
-                slot.pool = slot.pool_tags = nullptr;
-                slot.pool_waves = 0;
-                slot.pool_cap = waves * 256u; // slots a launch may hand out: every wave reserving its idle lanes a few times over
-                HIP_TRY(hipMalloc(&slot.pool, (size_t)waves * kPoolLocs * kPoolRecWords * 4));
-                HIP_TRY(hipMalloc(&slot.pool_tags, (size_t)slot.pool_cap * 8));
-                HIP_TRY(hipMemsetAsync(slot.pool_tags, 0, (size_t)slot.pool_cap * 8, stream));
-                slot.pool_waves = waves;
-            }
-            if (!slot.pool_ctl) {
-                HIP_TRY(hipMalloc(&slot.pool_ctl, sizeof(PoolCtl)));
-                HIP_TRY(hipMemsetAsync(slot.pool_ctl, 0, sizeof(PoolCtl), stream));
-            }
-            p.pool_ctl = slot.pool_ctl;
-            p.pool = slot.pool;
-            p.pool_tags = slot.pool_tags;
-            p.pool_cap = slot.pool_cap;
-            p.pool_epoch = (uint32_t)(s->launches + 1) | 0x80000000u; // (never 0: fresh tags are zeroes)
-            p.pool_park = (uint32_t)std::min(std::max(pool_env[1], 1), 64);
-            p.pool_stats = slot.ctr->hist_max; // (the counting kernels' histogram words: idle in the kernels that pool)
-        }
-    }
-#endif
     slot.last_stream = stream;
     slot.last_use = ++s->launches;
     p.nodes = s->d_nodes;
@@ -568,8 +529,6 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
 #endif
     p.n_tris = (uint32_t)s->n_tris;
     p.n_nodes = (uint32_t)s->n_nodes;
-    p.out_limit = mode == kModeRays ? p.n_items
-                                     : (p.n_frames > 1 ? (p.n_frames - 1) * p.frame_stride : 0u) + (p.compact ? p.tiles_per_frame * 64u : p.width * p.height);
     {   // (kernels.hip, div_uniform)
         auto rcp32 = [](uint32_t d) -> uint32_t { return d <= 1u ? 0xffffffffu : (uint32_t)((1ull << 32) / d); };
         p.rcp_tiles_x = rcp32(p.tiles_x);
@@ -904,9 +863,6 @@ void trx_scene_destroy(trx_scene *s) {
     for (Slot &sl : s->slots) {
         if (sl.ctr) (void)hipFree(sl.ctr);
         if (sl.spill) (void)hipFree(sl.spill);
-        if (sl.pool) (void)hipFree(sl.pool);
-        if (sl.pool_tags) (void)hipFree(sl.pool_tags);
-        if (sl.pool_ctl) (void)hipFree(sl.pool_ctl);
         for (auto &o : sl.order)
             if (o.lists) (void)hipFree(o.lists);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -1701,23 +1657,6 @@ int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *ou
     }
     if (rc) return rc;
     to_rayhit(s, h, inst, out);
-    return TRX_OK;
-}
-
-// TRX_POOL builds: the pool's counters summed over the scene's launch slots since the last call (reads and clears them).
-int trx_debug_pool_stats(trx_scene *s, uint32_t out[8]) {
-    if (!s || !out) return fail(TRX_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipDeviceSynchronize());
-    std::memset(out, 0, 8 * sizeof(uint32_t));
-    std::lock_guard<std::mutex> lock(s->mu);
-    for (Slot &sl : s->slots) {
-        if (!sl.ctr) continue;
-        unsigned int h[8];
-        HIP_TRY(hipMemcpy(h, sl.ctr->hist_max, sizeof(h), hipMemcpyDeviceToHost));
-        for (int i = 0; i < 8; i++) out[i] += h[i];
-        HIP_TRY(hipMemset(sl.ctr->hist_max, 0, sizeof(h)));
-    }
     return TRX_OK;
 }
 

@@ -83,22 +83,6 @@ struct SlotCounters {
     unsigned int lpt_sel[2]; // which of a kind's two tile-list sets holds the order to read (TraceParams::lpt_sel)
 };
 
-// The drain's orphan pool (kernels.hip, "The pool"): two cursors on lines of their own, self-resetting (the last wave out of
-// a launch zeroes them).  head = slots RESERVED by waves with idle lanes, tail = slots FILLED by waves that park their rays.
-struct alignas(128) PoolWord {
-    unsigned int v;
-    unsigned int pad[31];
-};
-struct PoolCtl {
-    PoolWord tail;
-    PoolWord head;
-};
-// A record is 44 GRANULES of 8 bytes, {value, tag = the launch's epoch} each, every one written by ONE agent-scope store: the
-// data is its own flag (cdna_hip_programming.md Guideline 16, R2) - a reader that finds a tag of another launch has read a
-// line that is not there yet and reads again.  20 words of ray state + 2 x kLdsStack words of stack.
-constexpr uint32_t kPoolRecWords = 88;
-constexpr uint32_t kPoolLocs = 48;     // record locations a wave may use over its life (it parks once; rays turned away once more)
-
 struct TraceParams {
     const uint4 *nodes;
     const float4 *tris;
@@ -157,15 +141,6 @@ struct TraceParams {
     uint32_t new_view;    // camera cut: the schedule tuner starts over
     uint32_t uni_decode;  // coherent primary walk: decode the child planes of a node step once per wave when every lane visits the same node
     uint32_t any_hit;     // explicit rays only: stop at the first accepted hit, write one byte (0/1) per ray
-    // the drain's orphan pool (incoherent single-level passes; null = none): cursors, one 8-byte tag per slot (pool_cap of
-    // them), records (kPoolRecWords words each, kPoolLocs per wave), the launch's epoch (a tag of another launch says
-    // nothing), and the policy: a dry wave with fewer than pool_park rays parks them when that many slots are on order
-    PoolCtl *pool_ctl;
-    unsigned long long *pool_tags;
-    unsigned long long *pool;
-    uint32_t pool_cap, pool_epoch, pool_park;
-    uint32_t out_limit;   // records in the out buffer (a ray that comes out of the pool is checked before it is trusted)
-    unsigned int *pool_stats; // null, or 8 counters: rays parked, taken, turned away (slot given up), records refused by the check, reservations, slots reserved
     uint32_t *over_host;  // null, or a word in pinned host memory that is set when a ray of THIS launch overflows (trx_traverse1:
                           // the caller learns it from the word, without a device-to-host copy of the slot's sticky counter)
     // frames per launch: primary passes - frame f = local_tile / tiles_per_frame uses views[f]; AO passes - one view

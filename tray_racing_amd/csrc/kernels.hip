@@ -39,28 +39,6 @@
 #define TRX_THIN_LEVELS 1
 #endif
 
-// TRX_POOL (experiment builds): the drain's chip-wide orphan pool instead of the hand-over between the two waves of a
-// workgroup, see "The pool" in k_trace.
-#ifndef TRX_POOL
-#define TRX_POOL 0
-#endif
-// TRX_POOL_CHECK (debugging the pool): every index the walk or the pool forms is range-checked before it is used; a failure
-// is recorded as a code in P.pool_stats[7] (the largest one seen) and the index is replaced by 0.
-#ifndef TRX_POOL_CHECK
-#define TRX_POOL_CHECK 0
-#endif
-#if TRX_POOL_CHECK
-#define TRX_CHK(index, limit, code)                                             \
-    do {                                                                        \
-        if ((index) >= (limit)) {                                               \
-            if (P.pool_stats) atomicMax(&P.pool_stats[7], (unsigned int)(code)); \
-            (index) = 0;                                                        \
-        }                                                                       \
-    } while (0)
-#else
-#define TRX_CHK(index, limit, code) do { } while (0)
-#endif
-
 // TRX_STAMPS (diagnostic builds only): per-wave cycle accounting of the loop's phases.  Every stamp
 // drains the memory counters first, so a phase owns the latency of what it issued.
 #ifdef TRX_STAMPS
@@ -723,7 +701,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     constexpr bool kThin = !TLAS && MODE != kModePrimary && !COUNT;
 #endif
     bool go_thin = false; // wave-uniform
-    constexpr bool kMerge = !TRX_POOL && !TLAS && MODE != kModePrimary && MODE != kModeFused && !COUNT;
+    constexpr bool kMerge = !TLAS && MODE != kModePrimary && MODE != kModeFused && !COUNT;
     constexpr uint32_t kMergeWords = TLAS ? 31u : 21u, kMergeMax = TLAS ? 32u : 48u, kMergeClosed = 0xffffffffu;
     const bool merging = kMerge && P.merge != 0u && blockDim.x == 2u * kWave;
     bool merge_open = merging; // wave-uniform: this wave has not offered / taken / refused rays yet
@@ -884,9 +862,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         if (MODE == kModeRays && P.any_hit != 0u) {
             reinterpret_cast<uint8_t *>(P.out)[out_index] = prim != TRX_INVALID ? 1u : 0u;
         } else {
-#if TRX_POOL_CHECK
-            if (P.out_limit) TRX_CHK(out_index, P.out_limit, 8);
-#endif
             trx_hit h;
             h.t = prim != TRX_INVALID ? t : __builtin_inff();
             h.prim = prim;
@@ -1025,9 +1000,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             cnt = (uint32_t)__popc(gy);
             if (kPre && sub < cnt) {
                 pre_local = select_from_top(gy, sub); // (kept for (2): the search is thirty-five instructions of a lone wave's trip)
-                uint32_t ti = gx + pre_local;
-                TRX_CHK(ti, P.n_tris, 4);
-                const float4 *tp = P.tris + (size_t)ti * 3;
+                const float4 *tp = P.tris + (size_t)(gx + pre_local) * 3;
                 ta = tp[0];
                 tb = tp[1];
                 tc = tp[2];
@@ -1053,9 +1026,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             }
             const bool gstep = ((__ballot(stepping) >> first) & 1ull) != 0ull;
             if (gstep) {
-                uint32_t ni = group_first<(int)L>(node_index);
-                TRX_CHK(ni, P.n_nodes, 1);
-                const uint4 *np = P.nodes + (size_t)ni * 5;
+                const uint4 *np = P.nodes + (size_t)group_first<(int)L>(node_index) * 5;
                 const uint8_t *nb = reinterpret_cast<const uint8_t *>(np) + sub * C;
                 n0 = np[0];
                 n1 = np[1];
@@ -1089,9 +1060,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 for (; __ballot(j < cnt) != 0ull; j += L) {
                     if (j < cnt) {
                         const uint32_t local = select_from_top(gy, j);
-                        uint32_t ti = gx + local;
-                        TRX_CHK(ti, P.n_tris, 5);
-                        const float4 *tp = P.tris + (size_t)ti * 3;
+                        const float4 *tp = P.tris + (size_t)(gx + local) * 3;
                         const float4 a = tp[0], b = tp[1], c = tp[2];
                         test_one(local, a, b, c);
                     }
@@ -1176,195 +1145,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
             if (rays_left() > 8u) thin_walk(std::integral_constant<int, 4>{});
         }
         if (rays_left() != 0u) thin_walk(std::integral_constant<int, 8>{});
-    };
-
-    // The pool (TRX_POOL builds; incoherent single-level passes).  When the queues run dry every wave holds about 43 rays and
-    // the pass then spends a third of its time stepping waves that are a half, a quarter, an eighth full - a wave-instruction
-    // costs the same whatever its lanes hold.  So a dry wave that is down to fewer than P.pool_park rays PARKS them with the
-    // waves that have lanes to spare, and leaves: fewer, fuller waves walk the same rays (a ray is the same ray whichever
-    // wave steps it: the hits are those of the pass without the pool).
-    //   Demand first.  A shared queue that thousands of waves poll for work melts under its own failed claims (built first:
-    // a 0.8 ms pass took 47 ms), so here the TAKERS queue up: a dry wave with sixteen idle lanes reserves one slot per idle lane with
-    // ONE returning add on `head` and from then on looks only at its own slots' tags (every lane its own 8 bytes: no word
-    // that two waves fight over).  A PARKING wave claims as many slots as it has rays with one compare-and-swap on `tail`,
-    // never past `head`: every slot it fills is a slot some lane is waiting on.  Per ray it writes the record (state + the
-    // LDS part of the stack, agent-scope stores, to a location of its own), waits, and swaps the slot's tag to
-    // {epoch, READY, location}; the waiting lane sees the tag (agent-scope load), loads the record and walks on.
-    //   Nobody is left behind, and nobody waits.  A lane gives a reservation up (the wave wants to leave, park or go thin) by
-    // swapping {epoch, VOID} into the tag: if the swap returns READY the ray had just arrived and is taken after all; a
-    // parking lane whose swap returns VOID keeps its ray (and walks on, or parks it again on later slots).  Whichever swap
-    // lands second sees the other, so a ray is never in two places and never in none.  No loop in here waits for another wave.
-#if TRX_POOL
-    constexpr bool kPool = !TLAS && MODE != kModePrimary && MODE != kModeFused && !COUNT;
-#else
-    constexpr bool kPool = false;
-#endif
-    static_assert(!kPool || (kLdsStack * 2 + 20) * 2 == (int)kPoolRecWords, "pool record layout");
-    const bool pooling = kPool && P.pool_ctl != nullptr; // wave-uniform
-    bool pool_off = !pooling;                            // wave-uniform: this wave reserves no more (the slots ran out)
-    bool pool_small = false;                             // wave-uniform: the wave held fewer than P.pool_park rays when its last trip ended
-    uint32_t my_slot = TRX_INVALID;                      // per lane: the slot this idle lane waits on
-    uint32_t pool_locs = 0u;                             // wave-uniform: record locations used so far
-    uint32_t pool_peek = 0u;                             // lanes 0, 1: tail, head as read at the top of the trip
-    constexpr unsigned long long kTagReady = 0x80000000ull, kTagVoid = 0x40000000ull;
-    auto pack2 = [](uint32_t lo, uint32_t hi) -> unsigned long long { return ((unsigned long long)hi << 32) | lo; };
-    auto pool_st = [](unsigned long long *w, unsigned long long v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto pool_ld = [](const unsigned long long *w) -> unsigned long long { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    // this lane's ray, from record location `loc`: false = some granule of the record has not arrived yet (nothing is changed)
-    auto pool_load = [&](uint32_t loc) -> bool {
-        TRX_CHK(loc, gridDim.x * (blockDim.x / kWave) * kPoolLocs, 12);
-        const unsigned long long *rec = P.pool + (size_t)loc * (kPoolRecWords / 2);
-        // (two passes: the tags first, a few at a time - 44 granules held at once are 88 registers - then the values of a
-        // record known to be whole: a granule that has arrived stays, its location is written once per launch)
-        uint32_t stale = 0u;
-#pragma unroll 4
-        for (int k = 0; k < 20 + 2 * kLdsStack; k++) stale |= (uint32_t)(pool_ld(rec + k) >> 32) ^ P.pool_epoch;
-        if (stale != 0u) return false;
-        for (int k = 0; k < kLdsStack; k++)
-            lds_st(&lds_stack[k * kWave + lane], make_uint2((uint32_t)pool_ld(rec + 20 + 2 * k), (uint32_t)pool_ld(rec + 21 + 2 * k)));
-        r.ox = __uint_as_float((uint32_t)pool_ld(rec + 0)); r.oy = __uint_as_float((uint32_t)pool_ld(rec + 1));
-        r.oz = __uint_as_float((uint32_t)pool_ld(rec + 2)); r.dx = __uint_as_float((uint32_t)pool_ld(rec + 3));
-        r.dy = __uint_as_float((uint32_t)pool_ld(rec + 4)); r.dz = __uint_as_float((uint32_t)pool_ld(rec + 5));
-        r.ix = __uint_as_float((uint32_t)pool_ld(rec + 6)); r.iy = __uint_as_float((uint32_t)pool_ld(rec + 7));
-        r.iz = __uint_as_float((uint32_t)pool_ld(rec + 8)); r.tmin = __uint_as_float((uint32_t)pool_ld(rec + 9));
-        r.oct_inv4 = (uint32_t)pool_ld(rec + 10); t = __uint_as_float((uint32_t)pool_ld(rec + 11));
-        prim = (uint32_t)pool_ld(rec + 12); out_index = (uint32_t)pool_ld(rec + 13); steps = trip - (uint32_t)pool_ld(rec + 14);
-        cur = make_uint2((uint32_t)pool_ld(rec + 15), (uint32_t)pool_ld(rec + 16)); sp = (uint32_t)pool_ld(rec + 17);
-        ptri = make_uint2((uint32_t)pool_ld(rec + 18), (uint32_t)pool_ld(rec + 19));
-        lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
-        lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
-        fetched = false;
-        overflow = 0u;
-        // Trust, but check: every index this record can make the walk form stays inside the scene's buffers (the same rule as
-        // for a node buffer handed in over the ABI) - a record that fails is a lost ray and a failed launch, never a stray access.
-        bool sane = sp <= (uint32_t)kLdsStack && out_index < P.out_limit && (prim == TRX_INVALID || prim < P.n_tris) &&
-                    (r.oct_inv4 & 0x7fffffffu) == (r.oct_inv4 & 7u) * 0x01010101u;
-        auto group_ok = [&](uint2 g) -> bool { // a node group {child base, hits | imask} or a triangle group {first triangle, bits}
-            return (g.y & 0xff000000u) ? (g.x <= P.n_nodes && P.n_nodes - g.x >= 8u) : (g.y == 0u || (g.x <= P.n_tris && P.n_tris - g.x >= 24u));
-        };
-        sane = sane && group_ok(cur) && group_ok(ptri);
-        for (uint32_t k = 0; k < (uint32_t)kLdsStack; k++)
-            if (k < sp) sane = sane && group_ok(lds_ld(&lds_stack[k * kWave + lane]));
-        if (!sane) {
-            c_over++;
-            if (P.pool_stats) atomicAdd(&P.pool_stats[3], 1u);
-        } else {
-            has_ray = true;
-            if (P.pool_stats) atomicAdd(&P.pool_stats[1], 1u);
-        }
-        return true;
-    };
-    // idle lanes without a reservation queue up for a ray each (n of them: wave-uniform)
-    auto pool_reserve = [&](unsigned long long who, uint32_t n) {
-        uint32_t h = 0u;
-        if (lane == 0u) h = atomicAdd(&P.pool_ctl->head.v, n);
-        h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
-        if (h + n > P.pool_cap || h + n < h) { // the slots have run out: this wave reserves no more (what it got past the end is void)
-            pool_off = true;
-            return;
-        }
-        if ((who >> lane) & 1ull) my_slot = h + lane_rank(who);
-        if (P.pool_stats && lane == 0u) {
-            atomicAdd(&P.pool_stats[4], 1u);
-            atomicAdd(&P.pool_stats[5], n);
-        }
-    };
-    // has a ray arrived on this lane's slot?
-    auto pool_poll = [&]() {
-        if (my_slot != TRX_INVALID) {
-            TRX_CHK(my_slot, P.pool_cap, 10);
-            const unsigned long long v = pool_ld(P.pool_tags + my_slot);
-            if ((uint32_t)(v >> 32) == P.pool_epoch && (v & kTagReady)) {
-                if (pool_load((uint32_t)v & 0x00ffffffu)) my_slot = TRX_INVALID; // (not whole yet: looked at again next time)
-            }
-        }
-    };
-    // every reservation of this wave is given up; a ray that had just arrived is taken after all
-    auto pool_cancel = [&]() {
-        if (my_slot != TRX_INVALID) {
-            TRX_CHK(my_slot, P.pool_cap, 11);
-            const unsigned long long v = atomicExch(P.pool_tags + my_slot, pack2((uint32_t)kTagVoid, P.pool_epoch));
-            my_slot = TRX_INVALID;
-            if ((uint32_t)(v >> 32) == P.pool_epoch && (v & kTagReady)) {
-                // the ray is this lane's now and nobody else's: its record is read until it is whole (its stores were waited
-                // for before the tag was swapped in; bounded all the same, a ray that never arrives is reported)
-                bool got = false;
-                for (uint32_t spins = 0u; spins < (1u << 16) && !got; spins++) {
-                    got = pool_load((uint32_t)v & 0x00ffffffu);
-                    if (!got) __builtin_amdgcn_s_sleep(8);
-                }
-                if (!got) {
-                    c_over++;
-                    if (P.pool_stats) atomicAdd(&P.pool_stats[6], 1u);
-                }
-            }
-        }
-    };
-    // park this wave's `alive` rays on slots that are on order, if there are that many (all or nothing: the point is one wave fewer)
-    auto pool_park = [&](uint32_t alive) {
-        const uint32_t tail = (uint32_t)__builtin_amdgcn_readlane((int)pool_peek, 0), head = (uint32_t)__builtin_amdgcn_readlane((int)pool_peek, 1);
-        if (head < tail || head - tail < alive || pool_locs + alive > kPoolLocs) return;
-        uint32_t old = tail + 1u;
-        if (lane == 0u) old = atomicCAS(&P.pool_ctl->tail.v, tail, tail + alive);
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) != tail) return; // (another wave got there first: next trip, with a fresh look)
-        const uint32_t j = lane_rank(__ballot(has_ray));
-        uint32_t loc = wave_global * kPoolLocs + pool_locs + j;
-        TRX_CHK(loc, gridDim.x * (blockDim.x / kWave) * kPoolLocs, 13);
-        pool_locs += alive;
-        uint32_t slot_at = tail + j;
-        TRX_CHK(slot_at, P.pool_cap, 14);
-        unsigned long long *const tag = P.pool_tags + slot_at;
-        bool send = has_ray;
-        if (send) { // a slot already given up costs a look, not a record
-            const unsigned long long v = pool_ld(tag);
-            if ((uint32_t)(v >> 32) == P.pool_epoch && (v & kTagVoid)) send = false;
-        }
-        if (send) {
-            unsigned long long *rec = P.pool + (size_t)loc * (kPoolRecWords / 2);
-            const uint32_t w[20] = {__float_as_uint(r.ox), __float_as_uint(r.oy), __float_as_uint(r.oz), __float_as_uint(r.dx),
-                                    __float_as_uint(r.dy), __float_as_uint(r.dz), __float_as_uint(r.ix), __float_as_uint(r.iy),
-                                    __float_as_uint(r.iz), __float_as_uint(r.tmin), r.oct_inv4, __float_as_uint(t), prim, out_index,
-                                    trip - steps, cur.x, cur.y, sp, ptri.x, ptri.y};
-#pragma unroll
-            for (int k = 0; k < 20; k++) pool_st(rec + k, pack2(w[k], P.pool_epoch));
-#pragma unroll
-            for (int k = 0; k < kLdsStack; k++) { // (entries above the ray's top are copied too: harmless)
-                const uint2 e = lds_ld(&lds_stack[k * kWave + lane]);
-                pool_st(rec + 20 + 2 * k, pack2(e.x, P.pool_epoch));
-                pool_st(rec + 21 + 2 * k, pack2(e.y, P.pool_epoch));
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the records are out before a tag says so
-        if (send) {
-            const unsigned long long v = atomicExch(tag, pack2((uint32_t)kTagReady | loc, P.pool_epoch));
-            if (!((uint32_t)(v >> 32) == P.pool_epoch && (v & kTagVoid))) has_ray = false; // (given up meanwhile: the ray stays here)
-        }
-        if (P.pool_stats) {
-            const uint32_t gone = (uint32_t)__popcll(__ballot(send && !has_ray));
-            if (lane == 0u) {
-                atomicAdd(&P.pool_stats[0], gone);
-                atomicAdd(&P.pool_stats[2], alive - gone);
-            }
-        }
-    };
-    // End of a dry wave's trip.
-    auto pool_step = [&]() {
-        const unsigned long long waiting = __ballot(my_slot != TRX_INVALID);
-        if (waiting != 0ull && (trip & 1u) != 0u) pool_poll();
-        uint32_t alive = (uint32_t)__popcll(__ballot(has_ray));
-        pool_small = alive < P.pool_park;
-        if (pool_small) {
-            if (waiting != 0ull) { // a wave this empty stops taking: it is one to be taken from
-                pool_cancel();
-                alive = (uint32_t)__popcll(__ballot(has_ray));
-                pool_small = alive < P.pool_park;
-            }
-            if (pool_small && alive != 0u && !(kThin && alive <= P.thin_max) && __ballot(has_ray && sp > (uint32_t)kLdsStack) == 0ull)
-                pool_park(alive);
-        } else if (!pool_off) {
-            const unsigned long long who = __ballot(!has_ray && my_slot == TRX_INVALID);
-            if ((uint32_t)__popcll(who) >= 16u) pool_reserve(who, (uint32_t)__popcll(who));
-        }
     };
 
     for (;;) {
@@ -1687,10 +1467,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         }
         TRX_STAMP(k_refill);
         if (__ballot(has_ray) == 0ull) {
-            if (kPool && pooling && exhausted) {
-                if (__ballot(my_slot != TRX_INVALID) != 0ull) pool_cancel(); // (leaving: what is on order is given up, or has just come)
-                if (__ballot(has_ray) == 0ull) break;
-            } else
             if (exhausted) {
                 if (kMerge && merge_open && wave_in_block == 0u) {
                     // leaving: close the door, or find that the second wave has just offered its rays
@@ -1768,7 +1544,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             gidx[k] = tri.x + local;
                             ta[k] = tb[k] = tc[k] = unspecified4(); // no lane without a triangle reads them
                             if (have[k]) {
-                                TRX_CHK(gidx[k], P.n_tris, 6);
                                 const float4 *tp = P.tris + (size_t)gidx[k] * 3;
                                 ta[k] = tp[0];
                                 tb[k] = tp[1];
@@ -1827,8 +1602,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             const uint32_t ol = (owner1 - 1u) & 63u; // (owner1 is 1..64; the mask keeps a corrupted table inside this wave's LDS)
                             const uint2 grp = lds_grp[ol];
                             const uint32_t local = select_from_top(grp.y, g - lds_pref[ol]);
-                            uint32_t gidx = grp.x + local;
-                            TRX_CHK(gidx, P.n_tris, 7);
+                            const uint32_t gidx = grp.x + local;
                             if (COUNT && P.touch_tris) P.touch_tris[gidx] = 1;
                             const float4 *tp = P.tris + (size_t)gidx * 3;
                             float4 a = tp[0], b = tp[1], c4 = tp[2];
@@ -1974,8 +1748,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 const bool pow2 = (NODE & 1) ? false : pow2_exact(P, r, act); // (literal-division variants only)
                 uint2 tri = make_uint2(0u, 0u);
                 trip++;
-                if (kPool && pool_small && exhausted && lane < 2u) // (asked now, looked at when the trip ends: off its critical path)
-                    pool_peek = __hip_atomic_load(&P.pool_ctl->tail.v + lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef TRX_DEV_TUNE
                 if (!(P.tune & 0x10000000u)) // (A/B: no priority by ray age)
 #endif
@@ -2045,7 +1817,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         // (tried: when every lane wants the same node - 47 % of the wave-level steps on the bistro-class frame,
                         // 90 % on the kitchen-class one - one copy through the scalar cache instead of 64 through the vector
                         // path: no change in frame time)
-                        TRX_CHK(node_index, P.n_nodes, 2);
                         const uint4 *np = P.nodes + (size_t)node_index * 5;
                         const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
                         stack_push(cur, (cur.y & 0xff000000u) != 0u); // after the loads are on their way
@@ -2153,21 +1924,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     if (MODE == kModeRays && P.any_hit != 0u && prim != TRX_INVALID) done = true;
                     if (done) finish_lane();
                 }
-                uint32_t alive = (uint32_t)__popcll(__ballot(has_ray));
+                const uint32_t alive = (uint32_t)__popcll(__ballot(has_ray));
                 TRX_STAMP(k_pop);
                 if (kMerge && merge_open && exhausted) {
                     merge_step(alive);
                     if (__ballot(has_ray) == 0ull) break;
-                    continue;
-                }
-                if (kPool && pooling && exhausted) {
-                    pool_step();
-                    alive = (uint32_t)__popcll(__ballot(has_ray));
-                    if (alive == 0u) break;
-                    if (kThin && thin_now(alive)) {
-                        go_thin = true;
-                        break;
-                    }
                     continue;
                 }
                 if (alive == 0u || (!exhausted && alive <= keep)) break;
@@ -2189,8 +1950,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 const bool act = has_ray;
                 const bool pow2 = (NODE & 1) ? false : pow2_exact(P, r, act); // (literal-division variants only)
                 trip++;
-                if (kPool && pool_small && exhausted && lane < 2u) // (asked now, looked at when the trip ends: off its critical path)
-                    pool_peek = __hip_atomic_load(&P.pool_ctl->tail.v + lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef TRX_DEV_TUNE
                 if (!(P.tune & 0x10000000u)) // (A/B: no priority by ray age)
 #endif
@@ -2210,8 +1969,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     cur.y &= ~(1u << child_bit);
                     const uint32_t slot = (child_bit - 24u) ^ (r.oct_inv4 & 0xffu);
                     const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot));
-                    uint32_t node_index = child_base + rel;
-                    TRX_CHK(node_index, P.n_nodes, 3);
+                    const uint32_t node_index = child_base + rel;
                     const uint4 *np = P.nodes + (size_t)node_index * 5;
                     fn0 = np[0]; fn1 = np[1]; fn2 = np[2]; fn3 = np[3];
                     {   // (the last 16 bytes as two 8-byte loads: pairs of registers are easier to keep than a fifth quadruple)
@@ -2272,16 +2030,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                     if (__ballot(has_ray) == 0ull) break;
                     continue;
                 }
-                if (kPool && pooling && exhausted) {
-                    pool_step();
-                    const uint32_t now_alive = (uint32_t)__popcll(__ballot(has_ray));
-                    if (now_alive == 0u) break;
-                    if (kThin && thin_now(now_alive)) {
-                        go_thin = true;
-                        break;
-                    }
-                    continue;
-                }
                 if (leave) break;
                 if (kFused && exhausted && (uint32_t)__popcll(__ballot(pend)) >= P.pend_min) break;
                 if (kThin && thin_now(alive)) {
@@ -2335,10 +2083,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
         const unsigned int ticket = atomicAdd(&P.ctr->waves_done, 1u);
         if (ticket == gridDim.x * (blockDim.x / kWave) - 1u) {
             for (int q = 0; q < 8; q++) atomicExch(&P.ctr->heads[q].taken, 0u);
-            if (kPool && pooling) {
-                atomicExch(&P.pool_ctl->tail.v, 0u);
-                atomicExch(&P.pool_ctl->head.v, 0u);
-            }
             // the lists this frame consumed become the next frame's (empty) write lists
             // a frame that filed a new order: the set it read is emptied (it takes the next new order) and the selector flips
             if (lpt_write) {
