@@ -21,7 +21,7 @@ def child(scenes, variant):
     from tray_racing_amd import _lib as L
     from tools.prof_config import hemisphere_rays
     lib = L.load()
-    w, h = 1920, 1080
+    w, h = int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080"))   # (W=3840 H=2160 TLAS=1: configs[4])
     out = {}
     for name in scenes:
         verts, counts = T.gen_scene(name, 0, 1)

@@ -452,7 +452,8 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     uint32_t wpb = (variant >> 16) & 0x7u; // (bit 19: the tile-order feedback does not tune itself off, see below)
     // incoherent single-level passes (AO, explicit rays) run two waves to a workgroup, so that the second can hand its last rays to the first
     // when both are draining (kernels.hip, "drain"); an explicit 1 or 4 here switches that off
-    const bool merge_default = (wpb != 1 && wpb != 2 && wpb != 4) && mode != kModePrimary && mode != kModeFused && !s->tlas && !count;
+    // (two-level scenes: explicit rays only, see kMerge in kernels.hip)
+    const bool merge_default = (wpb != 1 && wpb != 2 && wpb != 4) && mode != kModePrimary && mode != kModeFused && (!s->tlas || mode == kModeRays) && !count;
     if (wpb != 1 && wpb != 2 && wpb != 4) wpb = merge_default ? 2u : kDefaultWavesPerBlock;
     const uint32_t per_cu = (variant >> 8) & 0x1fu;
     int grid = per_cu ? (int)(std::min(per_cu, 32u) * (uint32_t)s->cu_count) : s->grid;
@@ -489,7 +490,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         if (slot.spill) (void)hipFree(slot.spill);
         slot.spill = nullptr;
         slot.spill_waves = 0;
-        HIP_TRY(hipMalloc(&slot.spill, (size_t)grid * kSpillStack * kWave * sizeof(uint2)));
+        HIP_TRY(hipMalloc(&slot.spill, (size_t)grid * kWaveScratch * sizeof(uint2)));
         slot.spill_waves = (uint32_t)grid;
     }
     slot.last_stream = stream;
@@ -556,12 +557,13 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     }
     p.waves_per_block = wpb;
     p.merge = merge_default ? 1u : 0u;
-    // Decode-once node test on wave-uniform node steps (kernels.hip, node_intersect_dec): every single-level primary pass.
+    // Decode-once node test on wave-uniform node steps (kernels.hip, node_intersect_dec): every primary pass (two-level
+    // scenes since round 5: san-miguel-class 4K frame -3.3 %, profiles/r05_ab_5_tlas.log).
     // With the plane-major table of round 3 it paid only where almost every step is uniform (kitchen-class frame -4 %, 90 %
     // of its steps) and was kept to scenes of up to 32 MiB; with the {near, far} pair tables of round 4 the bistro-class
     // frame (47 % uniform steps) gains 2 % and the dense and hairball-class frames, whose steps rarely are uniform, pay
     // 0.3 % for the test that finds that out (profiles/r04_ab_procs_15_decode_once.log).
-    p.uni_decode = (mode == kModePrimary && !s->tlas) ? 1u : 0u;
+    p.uni_decode = mode == kModePrimary ? 1u : 0u;
 #ifdef TRX_DEV_TUNE
     if (p.tune & 0x40000u) p.uni_decode = 1u;
     if (p.tune & 0x80000u) p.uni_decode = 0u;
@@ -879,7 +881,7 @@ uint64_t trx_scene_device_bytes(const trx_scene *s) {
     // launch slots claimed so far: stack spill areas and tile-order lists
     std::lock_guard<std::mutex> lock(const_cast<trx_scene *>(s)->mu);
     for (const Slot &sl : s->slots) {
-        bytes += (uint64_t)sl.spill_waves * kSpillStack * kWave * sizeof(uint2);
+        bytes += (uint64_t)sl.spill_waves * kWaveScratch * sizeof(uint2);
         for (const auto &o : sl.order)
             if (o.lists) bytes += 2ull * (16 * kLptShards + (uint64_t)16 * kLptShards * (o.capacity / 2 + 64)) * sizeof(uint32_t);
         if (sl.ctr) bytes += sizeof(SlotCounters);

@@ -32,6 +32,10 @@ constexpr uint32_t kLptShards = 8; // appenders per tile-cost bucket (16 buckets
 constexpr int kTriBatch = TRX_TRI_BATCH, kTriBatchTlas = TRX_TRI_BATCH_TLAS, kTriBatchPipe = TRX_TRI_BATCH_PIPE;
 constexpr int kLdsStack = TRX_LDS_STACK;        // traversal-stack entries per lane kept in LDS
 constexpr int kSpillStack = 64 - TRX_LDS_STACK; // further entries per lane in HBM (total 64 = oracle's ORC_STACK_SIZE)
+// A wave's private HBM area (TraceParams::spill, in uint2 entries): the stack entries past the LDS part, then the WORLD-SPACE
+// rays of its lanes ([6][64] floats: origin, direction as given) - a two-level walk over instance transforms comes back
+// to them when it leaves a BLAS, and six registers that are read on that path only are six registers the walk does not have
+constexpr int kWaveScratch = kSpillStack * kWave + 3 * kWave;
 // LDS per wave: stack + ray table (2 x float4 per lane) + triangle-phase tables (group, result, prefix, heads)
 constexpr int kLptPend = 32; // tile-list appends a wave parks in LDS before issuing them together
 constexpr int kLdsBytesPerWave = TRX_LDS_STACK * kWave * 8 + kWave * 32 + kWave * 8 + kWave * 8 + kWave * 4 + kWave * 4 + kLptPend * 8 + 6 * 8 * 4; // ... + the decoded child planes of a wave-uniform node step

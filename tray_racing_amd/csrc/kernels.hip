@@ -641,7 +641,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     float *const lds_dec = reinterpret_cast<float *>(lds_pend + kLptPend);                 // [3][8][2] decoded child planes {min, max} of a wave-uniform node step
     float *const lds_dec_neg = reinterpret_cast<float *>(lds_head);                        // [3][8][2] the same as {max, min} (node_intersect_dec); shares lds_head
     // (wave-uniform base, so that it lives in scalar registers: the HBM part of a stack is touched on rare paths only)
-    uint2 *const spill = P.spill + (size_t)wave_global * (kSpillStack * kWave);
+    uint2 *const spill = P.spill + (size_t)wave_global * kWaveScratch;
+    float *const wray = reinterpret_cast<float *>(spill + kSpillStack * kWave); // [6][64]: the lanes' world-space rays (kernels.h)
     const bool tie_first = P.tie_first != 0;
     if (P.wave_times && lane == 0) P.wave_times[kWaveTimeStride * wave_global] = wall_clock64();
     // (counting kernels, never timed: what refill_params() reads back IS this launch's parameter block - a second kernel
@@ -670,7 +671,6 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     // instance transforms (TLAS): the instance being walked / the one the current hit was found in, and the
     // world-space ray (origin, direction as given) to come back to when the BLAS is left
     uint32_t cur_inst = TRX_INVALID, hit_inst = TRX_INVALID;
-    float wox = 0.0f, woy = 0.0f, woz = 0.0f, wdx = 0.0f, wdy = 0.0f, wdz = 0.0f;
     uint2 cur = make_uint2(0u, 0u);
     // pipelined walk: node in flight / fetched for this lane, and the triangle group its last node test left
     bool fetched = false;
@@ -701,7 +701,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     constexpr bool kThin = !TLAS && MODE != kModePrimary && !COUNT;
 #endif
     bool go_thin = false; // wave-uniform
-    constexpr bool kMerge = !TLAS && MODE != kModePrimary && MODE != kModeFused && !COUNT;
+    // (two-level walks: explicit rays only - measured on the 4K two-level scene, profiles/r05_ab_5_tlas.log: rays -4 %, AO pass +2.5 %)
+    constexpr bool kMerge = (!TLAS || MODE == kModeRays) && MODE != kModePrimary && MODE != kModeFused && !COUNT;
     constexpr uint32_t kMergeWords = TLAS ? 31u : 21u, kMergeMax = TLAS ? 32u : 48u, kMergeClosed = 0xffffffffu;
     const bool merging = kMerge && P.merge != 0u && blockDim.x == 2u * kWave;
     bool merge_open = merging; // wave-uniform: this wave has not offered / taken / refused rays yet
@@ -1458,8 +1459,10 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         tlas_sp = TRX_INVALID;
                         bvh_off = P.tlas_start;
                         cur_inst = hit_inst = TRX_INVALID;
-                        wox = r.ox; woy = r.oy; woz = r.oz;
-                        wdx = dx; wdy = dy; wdz = dz;
+                        if (P.inst_xform) { // (what the walk comes back to when it leaves a BLAS: kept in the wave's HBM area)
+                            wray[0 * kWave + lane] = r.ox; wray[1 * kWave + lane] = r.oy; wray[2 * kWave + lane] = r.oz;
+                            wray[3 * kWave + lane] = dx; wray[4 * kWave + lane] = dy; wray[5 * kWave + lane] = dz;
+                        }
                     }
                     has_ray = true;
                 }
@@ -1655,8 +1658,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 m[15] = cur.x; m[16] = cur.y; m[17] = sp; m[18] = ptri.x; m[19] = ptri.y; m[20] = lane;
                 if (TLAS) {
                     m[21] = bvh_off; m[22] = tlas_sp; m[23] = cur_inst; m[24] = hit_inst;
-                    m[25] = __float_as_uint(wox); m[26] = __float_as_uint(woy); m[27] = __float_as_uint(woz);
-                    m[28] = __float_as_uint(wdx); m[29] = __float_as_uint(wdy); m[30] = __float_as_uint(wdz);
+                    for (int c = 0; c < 6; c++) m[25 + c] = __float_as_uint(wray[c * kWave + lane]); // (a ray's world-space copy travels with it)
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1688,8 +1690,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 cur = make_uint2(m[15], m[16]); sp = m[17]; ptri = make_uint2(m[18], m[19]);
                 if (TLAS) {
                     bvh_off = m[21]; tlas_sp = m[22]; cur_inst = m[23]; hit_inst = m[24];
-                    wox = __uint_as_float(m[25]); woy = __uint_as_float(m[26]); woz = __uint_as_float(m[27]);
-                    wdx = __uint_as_float(m[28]); wdy = __uint_as_float(m[29]); wdz = __uint_as_float(m[30]);
+                    for (int c = 0; c < 6; c++) wray[c * kWave + lane] = __uint_as_float(m[25 + c]);
                 }
                 const uint32_t from = m[20];
                 for (uint32_t k = 0; k < sp; k++) lds_st(&lds_stack[k * kWave + lane], merge_stack1[k * kWave + from]);
@@ -1755,9 +1756,11 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 // Coherent primary rays (BLAS only): when every lane that steps visits the SAME node - 47 % of the wave-level
                 // node steps on the bistro-class frame, 90 % on the kitchen-class one - its 48 quantised plane bytes are
                 // converted once, one byte per lane, parked in LDS as floats and read back by address (node_intersect_dec)
-                // (single-level walks: built for the two-level primary kernel as well - absolute node indices, lanes with a
-                // parked triangle group excluded - it spills there and the 4K frame runs 4 % slower, profiles/r04_ab_procs_16)
-                constexpr bool kUni = !TLAS && MODE == kModePrimary && !COUNT;
+                // (two-level walks too since round 5 - absolute node indices, lanes with a parked triangle group excluded: in round 4
+                // the two-level primary kernel spilled with it (4K frame +4 %, profiles/r04_ab_procs_16); with the world-space ray
+                // copies out of the registers (kernels.h, kWaveScratch) it has 121 and the 4K frame runs 3.3 % faster,
+                // profiles/r05_ab_5_tlas.log)
+                constexpr bool kUni = MODE == kModePrimary && !COUNT;
                 bool uni_done = false;
                 if constexpr (kUni) {
                     if (P.uni_decode) {
@@ -1869,6 +1872,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                         // its world-space meaning (the TODO at query_tlas.hlsl:433)
                         const float4 *m = P.inst_xform + (size_t)gidx * 3;
                         const float4 r0 = m[0], r1 = m[1], r2 = m[2];
+                        const float wox = wray[0 * kWave + lane], woy = wray[1 * kWave + lane], woz = wray[2 * kWave + lane];
+                        const float wdx = wray[3 * kWave + lane], wdy = wray[4 * kWave + lane], wdz = wray[5 * kWave + lane];
                         r.ox = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
                         r.oy = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
                         r.oz = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
@@ -1902,8 +1907,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             bvh_off = P.tlas_start;
                             cur_inst = TRX_INVALID;
                             if (P.inst_xform) { // "Reset Ray to untransformed version" (query_tlas.hlsl:484)
-                                r.ox = wox; r.oy = woy; r.oz = woz;
-                                finish_ray_dir(r, wdx, wdy, wdz);
+                                r.ox = wray[0 * kWave + lane]; r.oy = wray[1 * kWave + lane]; r.oz = wray[2 * kWave + lane];
+                                finish_ray_dir(r, wray[3 * kWave + lane], wray[4 * kWave + lane], wray[5 * kWave + lane]);
                                 lds_ray[2u * lane] = make_float4(r.ox, r.oy, r.oz, r.tmin);
                                 lds_ray[2u * lane + 1u] = make_float4(r.dx, r.dy, r.dz, 0.0f);
                             }
