@@ -468,6 +468,14 @@ int trx_set_build_costs(float traversal_cost, float prim_cost);
  * (src/main.rs:113-118).  batch_ratio 0 switches the pass off.  Default 0.02 x 4 iterations.  Applied to
  * triangle builds only: over instance boxes (TLAS) it measured worse and is skipped. */
 int trx_set_build_reinsertion(float batch_ratio, int iterations);
+/* How the candidates of a reinsertion iteration are batched, for subsequent builds (process-wide).  0 (default): the
+ * pipeline's own way - one at a time, each search on the tree the previous move left (trx_flat_build and the presets), or
+ * batches of 128 searched concurrently (trx_flat_build_params).  1: ONE batch per iteration - every candidate searches
+ * the tree the previous iteration left, the paper's formulation - and the searches run as a kernel on the build device
+ * when one is set (trx_set_build_device; one thread per candidate), on the host cores otherwise: the same tree either
+ * way.  An iteration gains less than with small batches (more searches are stale when their moves are applied), so give
+ * the pass more of them (trx_set_build_reinsertion). */
+int trx_set_build_reinsertion_batches(int whole_iterations);
 /* The reference's --preset names (src/main.rs:125-131,563-570: "fastest_build" ... "very_slow_build", "" =
  * defaults) mapped onto this builder's knobs — SAH bins, exact-sweep threshold, reinsertion ratio and
  * iterations, pre-splitting (on from "slow_build"); "medium_build" is the default setting and "" restores it.

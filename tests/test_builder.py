@@ -313,3 +313,26 @@ def test_batched_reinsertion_improves_the_ploc_tree(trx, orc):
         hits[ratio] = flat.tri_source[np.where(got["prim"] != 0xFFFFFFFF, got["prim"], 0)], got["t"].copy()
     assert stats[0.15] < 0.9 * stats[0.0], stats
     assert (hits[0.0][1].view(np.uint32) == hits[0.15][1].view(np.uint32)).all()   # same closest hits through either tree
+
+
+def test_whole_iteration_reinsertion_is_deterministic_and_valid(trx, orc):
+    """trx_set_build_reinsertion_batches(1): every candidate of an iteration searches the tree the previous iteration left
+    (host searches here; the device searches of tests/test_gpu_builder.py must reproduce these bytes).  The same tree on
+    one core and on five, a valid CWBVH, and not the tree of the default batching."""
+    lib = trx.load()
+    verts, counts = trx.gen_scene("bistro", 60000, 1)
+    counts = np.array([verts.shape[0]], dtype=np.uint64)
+    try:
+        assert lib.trx_set_build_reinsertion_batches(1) == 0
+        for build in (lambda t: trx.flat_build_params(verts, counts, trx.build_params(), threads=t),
+                      lambda t: trx.flat_build(verts, counts, preset="medium_build", reinsertion=(0.05, 6), threads=t)):
+            a, b = build(1), build(5)
+            assert (a.nodes == b.nodes).all() and (a.tri_source == b.tri_source).all()
+            assert orc.Scene.from_flat(a).validate() == (0, "")
+        whole = trx.flat_build_params(verts, counts, trx.build_params(), threads=2)
+        assert lib.trx_set_build_reinsertion_batches(0) == 0
+        small = trx.flat_build_params(verts, counts, trx.build_params(), threads=2)
+        assert whole.nodes.shape != small.nodes.shape or not (whole.nodes == small.nodes).all()
+    finally:
+        lib.trx_set_build_reinsertion_batches(0)
+        lib.trx_set_build_preset(b"medium_build")

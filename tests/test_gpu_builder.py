@@ -59,3 +59,49 @@ def test_device_ploc_full_size_bistro_traces_like_the_host_build(trx, orc):
     sc.close()
     want, _ = osc.trace_primary(orc.view_from_bytes(view), w, h, sem=3)
     assert (got["prim"] == want["prim"]).all() and (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("name,n,tlas", [("bistro", 300000, False), ("hairball", 150000, False), ("soup", 60000, False)])
+def test_device_reinsertion_searches_equal_host_searches(trx, orc, name, n, tlas):
+    """Reinsertion with one batch per iteration (trx_set_build_reinsertion_batches): the candidates are chosen and searched
+    on the GPU (csrc/reinsert_gpu.cpp: area keys + radix sort, one thread per search) or on the host cores; the moves are
+    applied on the host in candidate order.  Same flat buffers, byte for byte - for the PLOC pipeline (its BVH2 stage on
+    the device as well) and for the binned-SAH presets.  And, independently of either builder: the device-built tree is a
+    valid CWBVH over the scene's triangles (orc_validate) and a BVH-free brute-force query over the same rays finds the
+    hits the oracle finds through it."""
+    lib = trx.load()
+    verts, _counts = trx.gen_scene(name, n, 1)
+    counts = np.array([n], dtype=np.uint64)
+    try:
+        assert lib.trx_set_build_reinsertion_batches(1) == 0
+        for pipeline in ("ploc", "preset"):
+            assert lib.trx_set_build_preset(b"medium_build") == 0
+            assert lib.trx_set_build_reinsertion(0.05, 6) == 0
+            built = []
+            for device in (-1, 0):
+                assert lib.trx_set_build_device(device) == 0
+                built.append(trx.flat_build_params(verts, counts, trx.build_params()) if pipeline == "ploc"
+                             else trx.flat_build(verts, counts))
+            host, dev = built
+            assert (host.nodes == dev.nodes).all() and (host.tri_source == dev.tri_source).all(), (name, pipeline)
+            osc = orc.Scene.from_flat(dev)
+            assert osc.validate() == (0, "")
+        # the one-batch pass really moved nodes: not the tree of the same pipeline without reinsertion
+        assert lib.trx_set_build_reinsertion(0.0, 0) == 0
+        plain = trx.flat_build(verts, counts)
+        assert plain.nodes.shape != dev.nodes.shape or not (plain.nodes == dev.nodes).all()
+        eye, look, fov = trx.scene_camera(name)
+        w, h = 96, 64
+        view = trx.view_from_camera(eye, look, fov, w, h)
+        ov = orc.view_from_bytes(view)
+        through, _ = osc.trace_primary(ov, w, h, sem=3)
+        brute = osc.brute_primary(ov, w, h, sem=3)
+        assert (through["t"].view(np.uint32) == brute["t"].view(np.uint32)).all()
+        sc = trx.Scene(dev)
+        got, _ = sc.trace_primary(view, w, h, sem=3)
+        sc.close()
+        assert (got["prim"] == through["prim"]).all() and (got["t"].view(np.uint32) == through["t"].view(np.uint32)).all()
+    finally:
+        lib.trx_set_build_device(-1)
+        lib.trx_set_build_reinsertion_batches(0)
+        lib.trx_set_build_preset(b"medium_build")

@@ -1,7 +1,24 @@
-import time, os, sys
+"""Stage times of the builders on the bistro-class scene (TRX_BUILD_VERBOSE=1 prints the laps): the medium_build preset and
+the reference-default PLOC pipeline, host only and with the build device (GPU stages); MODE=whole adds one batch per
+reinsertion iteration.  usage: TRX_BUILD_VERBOSE=1 python tools/build_times.py [iterations]"""
+import os
+import sys
+import time
+
 sys.path.insert(0, os.getcwd())
 import tray_racing_amd as T
-v,c=T.gen_scene("bistro",0,1)
+from tray_racing_amd import _lib as L
+
+lib = L.load()
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+v, c = T.gen_scene("bistro", 0, 1)
 for rep in range(2):
-    for label,fn in (("medium_build", lambda: T.flat_build(v,c,use_tlas=False,preset="medium_build")),("ploc default", lambda: T.flat_build_params(v,c,T.build_params(),use_tlas=False))):
-        t0=time.time(); flat=fn(); print(label,"total %.2f s"%(time.time()-t0), "nodes",flat.n_nodes, flush=True)
+    for label, dev, whole in (("host", -1, 0), ("device + whole iterations", 0, 1)):
+        L.check(lib.trx_set_build_preset(b"medium_build"))
+        L.check(lib.trx_set_build_device(dev))
+        L.check(lib.trx_set_build_reinsertion_batches(whole))
+        if whole:
+            L.check(lib.trx_set_build_reinsertion(0.02, iters))
+        t0 = time.time()
+        flat = T.flat_build_params(v, c, T.build_params(), use_tlas=False)
+        print("ploc default,", label, "total %.2f s" % (time.time() - t0), "nodes", flat.n_nodes, flush=True)

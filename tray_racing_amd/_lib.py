@@ -142,6 +142,7 @@ SIGNATURES = {
     "trx_bvh_build_aabbs": (_i, [_P, _u64, _u32, _i, C.POINTER(_P)]),
     "trx_set_build_costs": (_i, [_f, _f]),
     "trx_set_build_reinsertion": (_i, [_f, _i]),
+    "trx_set_build_reinsertion_batches": (_i, [_i]),
     "trx_set_build_preset": (_i, [C.c_char_p]),
     "trx_set_build_split": (_i, [_f]),
     "trx_set_build_device": (_i, [_i]),

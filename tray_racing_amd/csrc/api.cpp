@@ -56,6 +56,7 @@ struct BuildSettings {
     uint32_t ploc_depth_threshold = 2, ploc_sort_bits = 64;
     int ploc_device = -1;       // >= 0: the PLOC stage of large builds runs on this HIP device (trx_set_build_device)
     bool reinsert_batched = false;
+    bool reinsert_whole = false; // one batch per iteration (trx_set_build_reinsertion_batches)
     float rebraid_area = 1.0f / 4096.0f; // TLAS: open BLAS subtrees whose box exceeds this share of the scene box's area (0 = never)
 };
 BuildSettings g_build;
@@ -80,6 +81,7 @@ BuildParams to_build_params(const BuildSettings &b, uint32_t max_prims, int thre
     bp.ploc_sort_bits = b.ploc_sort_bits;
     bp.ploc_device = b.ploc_device;
     bp.reinsertion_batched = b.reinsert_batched;
+    bp.reinsertion_whole_iterations = b.reinsert_whole;
     return bp;
 }
 
@@ -1926,6 +1928,12 @@ int trx_set_build_reinsertion(float batch_ratio, int iterations) {
     return TRX_OK;
 }
 
+int trx_set_build_reinsertion_batches(int whole_iterations) {
+    std::lock_guard<std::mutex> lock(g_build_mu);
+    g_build.reinsert_whole = whole_iterations != 0;
+    return TRX_OK;
+}
+
 void trx_bvh_destroy(trx_bvh *b) { delete b; }
 uint64_t trx_bvh_node_count(const trx_bvh *b) { return b ? b->bvh.nodes.size() : 0; }
 uint64_t trx_bvh_prim_count(const trx_bvh *b) { return b ? b->bvh.primitive_indices.size() : 0; }
@@ -2029,11 +2037,21 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             counts.push_back(total);
         }
         std::vector<CwbvhNode> nodes;
-        std::vector<uint32_t> blas_offset, blas_tri_start, tri_source;
+        std::vector<uint32_t> blas_offset, blas_tri_start;
         std::vector<Aabb> blas_aabb;
-        std::vector<float> tri_out, box_out;
-        tri_out.reserve(total * 9);
-        tri_source.reserve(total);
+        // The three arrays with one entry per triangle reference go straight into the buffers the caller receives (malloc:
+        // no value-initialisation, no copy at the end - 250 MB each way on a 3.9 M triangle scene, a tenth of a second of
+        // one core); their size is known once the BLASes are built.
+        struct Grow { // entries filled so far / capacity, in triangle references
+            float *tri = nullptr, *box = nullptr;
+            uint32_t *src = nullptr;
+            size_t n = 0, cap = 0;
+            ~Grow() {
+                std::free(tri);
+                std::free(box);
+                std::free(src);
+            }
+        } refs;
         double blas_s = 0.0, tlas_s = 0.0;
         // BLAS builds: large objects one after the other with every thread, the (many) small ones of a
         // TLAS scene concurrently with one thread each; assembly below stays in object order
@@ -2082,28 +2100,35 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             }
             blas_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
+        {
+            size_t all = 0;
+            for (const CwBvh &b : built) all += b.primitive_indices.size();
+            refs.cap = std::max<size_t>(all, 1);
+            refs.tri = (float *)std::malloc(refs.cap * 36);
+            refs.box = (float *)std::malloc(refs.cap * 24);
+            refs.src = (uint32_t *)std::malloc(refs.cap * 4);
+            if (!refs.tri || !refs.box || !refs.src) throw std::bad_alloc();
+        }
         uint64_t first = 0;
         for (size_t bi = 0; bi < counts.size(); bi++) {
             const uint64_t cnt = counts[bi];
             CwBvh &bvh = built[bi];
-            const uint32_t tri_offset = (uint32_t)(tri_out.size() / 9);
+            const uint32_t tri_offset = (uint32_t)refs.n;
             blas_tri_start.push_back(tri_offset);
             // permute triangles into primitive_indices order (mod.rs:38-43); the entries are independent, so a large
             // BLAS is filled by every core
             {
                 const size_t np = bvh.primitive_indices.size();
-                const size_t t0i = tri_out.size(), s0i = tri_source.size(), b0i = box_out.size();
-                tri_out.resize(t0i + np * 9);
-                tri_source.resize(s0i + np);
-                box_out.resize(b0i + np * 6);
+                const size_t r0 = refs.n;
+                refs.n += np;
                 auto fill = [&](size_t k0, size_t k1) {
                     for (size_t k = k0; k < k1; k++) {
                         const uint32_t pi = bvh.primitive_indices[k];
                         const float *v = verts + (first + pi) * 9;
-                        std::memcpy(&tri_out[t0i + k * 9], v, 36);
-                        tri_source[s0i + k] = (uint32_t)(first + pi);
+                        std::memcpy(refs.tri + (r0 + k) * 9, v, 36);
+                        refs.src[r0 + k] = (uint32_t)(first + pi);
                         // the box this entry was built with: the triangle's own, or its clipped part after pre-splitting
-                        float *bx = &box_out[b0i + k * 6];
+                        float *bx = refs.box + (r0 + k) * 6;
                         if (!bvh.primitive_boxes.empty()) {
                             for (int a = 0; a < 3; a++) { bx[a] = bvh.primitive_boxes[k].mn[a]; bx[3 + a] = bvh.primitive_boxes[k].mx[a]; }
                         } else {
@@ -2130,7 +2155,7 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
             nodes.insert(nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
             first += cnt;
         }
-        blas_tri_start.push_back((uint32_t)(tri_out.size() / 9));
+        blas_tri_start.push_back((uint32_t)refs.n);
         std::vector<uint32_t> inst, inst_source, inst_entry;
         std::vector<float> inst_xf;
         uint32_t tlas_start = 0;
@@ -2268,13 +2293,16 @@ static int flat_build_impl(const float *verts, const uint64_t *object_tri_counts
         };
         f->n_nodes = nodes.size();
         f->bvh_bytes = dup(nodes.data(), nodes.size() * sizeof(CwbvhNode));
-        f->n_tris = tri_out.size() / 9;
-        f->tri_verts = (float *)dup(tri_out.data(), tri_out.size() * 4);
+        f->n_tris = refs.n;
+        f->tri_verts = refs.tri; // (handed over: see `refs`)
+        refs.tri = nullptr;
         f->n_instances = (uint32_t)inst.size();
         f->instance_offsets = (uint32_t *)dup(inst.data(), inst.size() * 4);
         f->tlas_start = tlas_start;
-        f->tri_source = (uint32_t *)dup(tri_source.data(), tri_source.size() * 4);
-        f->tri_boxes = (float *)dup(box_out.data(), box_out.size() * 4);
+        f->tri_source = refs.src;
+        f->tri_boxes = refs.box;
+        refs.src = nullptr;
+        refs.box = nullptr;
         f->n_blas = (uint32_t)counts.size();
         f->blas_tri_start = (uint32_t *)dup(blas_tri_start.data(), blas_tri_start.size() * 4);
         f->blas_build_s = blas_s;

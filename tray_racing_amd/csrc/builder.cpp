@@ -1,6 +1,7 @@
 // builder.cpp — CPU construction of the 80-byte CWBVH (see builder.h).
 #include "builder.h"
 #include "ploc_gpu.h"
+#include "reinsert_gpu.h"
 
 #include <algorithm>
 #include <atomic>
@@ -10,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
+#include <new>
 #include <stdexcept>
 #include <thread>
 
@@ -42,9 +45,61 @@ namespace {
 
 constexpr float kInf = std::numeric_limits<float>::infinity();
 
-// the builder's large working arrays (hundreds of megabytes on the 4-5 M triangle scenes)
+// The builder's large working arrays (hundreds of megabytes on the 4-5 M triangle scenes).  Not a std::vector: that
+// value-initialises - one thread writing 300-400 MB of zeroes per array before the cores that fill it get to touch it
+// (a fifth of a reference-default build once the searches run on the GPU).  Memory comes from calloc, i.e. for these
+// sizes as untouched zero pages: reads before writes still see zeroes, and the first touch happens on the core that
+// writes the element.  Elements are trivially copyable records.
 template <class T>
-using BigVec = std::vector<T>;
+class BigVec {
+    T *p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+
+  public:
+    BigVec() = default;
+    explicit BigVec(size_t n) { resize(n); }
+    BigVec(size_t n, const T &v) {
+        resize(n);
+        std::fill(p_, p_ + n, v);
+    }
+    BigVec(const BigVec &) = delete;
+    BigVec &operator=(const BigVec &) = delete;
+    ~BigVec() { std::free(p_); }
+    void resize(size_t n) { // (new elements are zero bytes)
+        if (n > cap_) {
+            T *q = static_cast<T *>(std::calloc(n, sizeof(T)));
+            if (!q) throw std::bad_alloc();
+            if (n_) std::memcpy(static_cast<void *>(q), static_cast<const void *>(p_), n_ * sizeof(T));
+            std::free(p_);
+            p_ = q;
+            cap_ = n;
+        } else if (n > n_) {
+            std::memset(static_cast<void *>(p_ + n_), 0, (n - n_) * sizeof(T));
+        }
+        n_ = n;
+    }
+    template <class It>
+    void assign(It first, It last) {
+        resize((size_t)(last - first));
+        std::copy(first, last, p_);
+    }
+    void clear() { n_ = 0; }
+    void swap(BigVec &o) {
+        std::swap(p_, o.p_);
+        std::swap(n_, o.n_);
+        std::swap(cap_, o.cap_);
+    }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    T *data() { return p_; }
+    const T *data() const { return p_; }
+    T &operator[](size_t i) { return p_[i]; }
+    const T &operator[](size_t i) const { return p_[i]; }
+    T *begin() { return p_; }
+    T *end() { return p_ + n_; }
+    const T *begin() const { return p_; }
+    const T *end() const { return p_ + n_; }
+};
 
 inline Aabb empty_box() {
     return Aabb{{kInf, kInf, kInf}, {-kInf, -kInf, -kInf}};
@@ -500,9 +555,14 @@ struct Reinserter {
     static constexpr uint32_t kNone = 0xffffffffu;
     BigVec<Node2> &nodes;
     BigVec<uint32_t> parent;
-    explicit Reinserter(BigVec<Node2> &n) : nodes(n), parent(n.size(), kNone) {
-        for (uint32_t i = 0; i < nodes.size(); i++)
-            if (nodes[i].count > 1) parent[nodes[i].left] = parent[nodes[i].right] = i;
+    explicit Reinserter(BigVec<Node2> &n) : nodes(n), parent(n.size()) {
+        const size_t total = nodes.size();
+        const int threads = total < ((size_t)1 << 16) ? 1 : std::max(1, std::min(usable_threads(), 32));
+        if (total) parent[0] = kNone; // every other node is some inner node's child
+        on_threads(threads, [&](int t) {
+            for (size_t i = total * (size_t)t / threads; i < total * (size_t)(t + 1) / threads; i++)
+                if (nodes[i].count > 1) parent[nodes[i].left] = parent[nodes[i].right] = (uint32_t)i;
+        });
     }
     bool leaf(uint32_t i) const { return nodes[i].count == 1; }
     uint32_t sibling(uint32_t i) const {
@@ -519,6 +579,7 @@ struct Reinserter {
     // Best place below `top` for a box of area `area`; `gain` is what the tree
     // has saved so far by taking the node out (everything above `top`).
     typedef std::vector<std::pair<float, uint32_t>> Scratch;
+    typedef std::pair<float, uint32_t> Cand; // {area, node}: a candidate of an iteration (select_candidates)
     void search(Scratch &stack, uint32_t top, float gain, const Aabb &box, float area, uint32_t &best_to,
                 float &best_gain) const {
         stack.clear();
@@ -601,6 +662,110 @@ struct Reinserter {
     // previous batch left it, all at once; their moves are then applied in candidate order, skipping a move whose nodes
     // an earlier move of the same batch touched or that would no longer be a legal re-link.  The searches are
     // read-only and the application order is fixed, so the result does not depend on the thread count.
+    // Applies the moves found for candidates [begin, begin + count) in candidate order (see run_batched); returns how many.
+    uint32_t apply_batch(const BigVec<Cand> &cand, size_t begin, size_t count, const uint32_t *found, std::vector<uint32_t> &touched_at,
+                         uint32_t stamp, const uint32_t *ids = nullptr) {
+        uint32_t moved_now = 0;
+        for (size_t k = 0; k < count; k++) {
+            const uint32_t from = ids ? ids[k] : cand[begin + k].second, to = found[k];
+            if (to == kNone) continue;
+            const uint32_t p = parent[from];
+            if (p == 0 || p == kNone || to == p || to == from || parent[to] == kNone) continue;
+            const uint32_t s = sibling(from), g = parent[p], tp = parent[to];
+            if (to == s) continue; // already its sibling: nothing to gain
+            if (touched_at[from] == stamp || touched_at[p] == stamp || touched_at[s] == stamp || touched_at[g] == stamp ||
+                touched_at[to] == stamp || touched_at[tp] == stamp)
+                continue; // an earlier move of this batch re-linked one of them: the search is stale
+            bool inside = false; // `to` must not lie below `from` (an earlier move may have put it there)
+            for (uint32_t a = to; a != kNone; a = parent[a])
+                if (a == from) {
+                    inside = true;
+                    break;
+                }
+            if (inside) continue;
+            move(from, to);
+            touched_at[from] = touched_at[p] = touched_at[s] = touched_at[g] = touched_at[to] = touched_at[tp] = stamp;
+            moved_now++;
+        }
+        return moved_now;
+    }
+
+    // The batched pass with WHOLE-ITERATION batches: every candidate of an iteration searches the tree as the previous
+    // iteration left it (Meister & Bittner's formulation as the paper states it), the searches on `device` (one thread
+    // per candidate, reinsert_gpu.cpp) or, device < 0, on `threads` cores - the same searches, the same found[], the same
+    // tree either way (tests/test_gpu_builder.py).  Moves are applied on the host in candidate order, stale ones skipped.
+    // More of the searches are stale than with batches of 128, so an iteration gains less and the pass runs more of them.
+    uint32_t run_whole_iterations(float batch_ratio, int iterations, int threads, int device, double *device_seconds) {
+        const size_t n = nodes.size();
+        uint32_t moved = 0;
+        if (n < 8 || batch_ratio <= 0.f) return 0;
+        threads = std::max(1, std::min(threads, std::min(usable_threads(), 64)));
+        BigVec<Cand> cand, cand_tmp;
+        std::vector<uint32_t> ids, found;
+        std::vector<uint32_t> touched_at(n, 0u);
+        ReinsertDevice *dev = nullptr;
+        std::string err;
+        if (device >= 0 && !reinsert_dev_open(device, n, &dev, err)) throw std::runtime_error("GPU build stage: " + err);
+        struct Closer {
+            ReinsertDevice *d;
+            ~Closer() { reinsert_dev_close(d); }
+        } closer{dev};
+        const bool verbose = getenv("TRX_BUILD_VERBOSE") != nullptr && n > 100000;
+        auto now = []() { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        double t_select = 0, t_search = 0, t_apply = 0;
+        for (int it = 0; it < iterations; it++) {
+            const auto t0 = now();
+            size_t take;
+            if (dev) {
+                // (the candidates are chosen on the device too: the same nodes in the same order as select_candidates)
+                take = n < 3 ? 0 : std::min(n - 3, (size_t)std::max(1.0, (double)n * batch_ratio));
+            } else {
+                take = select_candidates(cand, cand_tmp, batch_ratio, threads);
+            }
+            ids.resize(take);
+            found.assign(take, kNone);
+            if (!dev)
+                for (size_t k = 0; k < take; k++) ids[k] = cand[k].second;
+            const auto t1 = now();
+            t_select += secs(t0, t1);
+            if (dev) {
+                if (!reinsert_dev_iteration(dev, nodes.data(), parent.data(), (uint32_t)take, ids.data(), found.data(), device_seconds, err))
+                    throw std::runtime_error("GPU build stage: " + err);
+                Scratch scratch; // (a search that outgrew the device's fixed stack: here, same result)
+                for (size_t k = 0; k < take; k++)
+                    if (found[k] == kReinsertOverflow) {
+                        found[k] = kNone;
+                        (void)find(scratch, ids[k], found[k]);
+                    }
+            } else {
+                std::atomic<size_t> next{0};
+                on_threads(threads, [&](int) {
+                    Scratch scratch;
+                    for (size_t k = next.fetch_add(64); k < take; k = next.fetch_add(64))
+                        for (size_t j = k; j < std::min(take, k + 64); j++) {
+                            const uint32_t from = ids[j];
+                            uint32_t to = kNone;
+                            if (parent[from] != 0 && parent[from] != kNone) (void)find(scratch, from, to);
+                            found[j] = to;
+                        }
+                });
+            }
+            const auto t2 = now();
+            t_search += secs(t1, t2);
+            const uint32_t moved_now = apply_batch(cand, 0, take, found.data(), touched_at, (uint32_t)it + 1u, ids.data());
+            t_apply += secs(t2, now());
+            moved += moved_now;
+            if (moved_now == 0) break;
+        }
+        const auto t3 = now();
+        if (moved) relayout(threads);
+        if (verbose)
+            fprintf(stderr, "[trx build] reinsertion: select %.3f s, search (+ copies) %.3f s, apply %.3f s, re-layout %.3f s\n", t_select, t_search,
+                    t_apply, secs(t3, now()));
+        return moved;
+    }
+
     uint32_t run_batched(float batch_ratio, int iterations, int threads) {
         const size_t n = nodes.size();
         uint32_t moved = 0;
@@ -657,27 +822,7 @@ struct Reinserter {
                 search_some(scratch);
                 while (sh.done.load(std::memory_order_acquire) != (uint32_t)pool.size()) std::this_thread::yield();
                 stamp++;
-                for (size_t k = 0; k < sh.count; k++) {
-                    const uint32_t from = cand[begin + k].second, to = found[k];
-                    if (to == kNone) continue;
-                    const uint32_t p = parent[from];
-                    if (p == 0 || p == kNone || to == p || to == from || parent[to] == kNone) continue;
-                    const uint32_t s = sibling(from), g = parent[p], tp = parent[to];
-                    if (to == s) continue; // already its sibling: nothing to gain
-                    if (touched_at[from] == stamp || touched_at[p] == stamp || touched_at[s] == stamp || touched_at[g] == stamp ||
-                        touched_at[to] == stamp || touched_at[tp] == stamp)
-                        continue; // an earlier move of this batch re-linked one of them: the search is stale
-                    bool inside = false; // `to` must not lie below `from` (an earlier move may have put it there)
-                    for (uint32_t a = to; a != kNone; a = parent[a])
-                        if (a == from) {
-                            inside = true;
-                            break;
-                        }
-                    if (inside) continue;
-                    move(from, to);
-                    touched_at[from] = touched_at[p] = touched_at[s] = touched_at[g] = touched_at[to] = touched_at[tp] = stamp;
-                    moved_now++;
-                }
+                moved_now += apply_batch(cand, begin, sh.count, found.data(), touched_at, stamp);
             }
             sh.quit.store(true, std::memory_order_release);
             for (auto &th : pool) th.join();
@@ -715,32 +860,33 @@ struct Reinserter {
         return moved;
     }
 
-    // exact primitive counts of every subtree, children before parents (iterative post-order from the root)
-    void recount() {
-        constexpr uint64_t kSecondVisit = 1ull << 32; // both children are done
-        std::vector<uint64_t> todo;
-        todo.push_back(0u);
-        while (!todo.empty()) {
-            const uint64_t e = todo.back();
-            todo.pop_back();
-            const uint32_t i = (uint32_t)e;
-            if (e & kSecondVisit) {
-                nodes[i].count = nodes[nodes[i].left].count + nodes[nodes[i].right].count;
-            } else if (nodes[i].count > 1) {
-                todo.push_back(kSecondVisit | i);
-                todo.push_back(nodes[i].right);
-                todo.push_back(nodes[i].left);
+    // exact primitive counts of every subtree (the moves left the inner nodes' counts stale): every leaf walks towards the
+    // root, the SECOND walker to reach an inner node sums its children's counts and goes on - each node is written once, by
+    // whichever walker arrives last, from two final values: the same numbers on any number of threads
+    void recount(int threads) {
+        const size_t total = nodes.size();
+        threads = total < ((size_t)1 << 16) ? 1 : std::max(1, std::min(threads, 64));
+        std::unique_ptr<std::atomic<uint8_t>[]> arrived(new std::atomic<uint8_t>[total]);
+        on_threads(threads, [&](int t) {
+            for (size_t i = total * (size_t)t / threads; i < total * (size_t)(t + 1) / threads; i++) arrived[i].store(0, std::memory_order_relaxed);
+        });
+        on_threads(threads, [&](int t) {
+            for (size_t i = total * (size_t)t / threads; i < total * (size_t)(t + 1) / threads; i++) {
+                if (nodes[i].count != 1) continue;
+                for (uint32_t p = parent[i]; p != kNone; p = parent[p]) {
+                    if (arrived[p].fetch_add(1, std::memory_order_acq_rel) == 0) break; // the other child's walker finishes it
+                    nodes[p].count = nodes[nodes[p].left].count + nodes[nodes[p].right].count;
+                }
             }
-        }
+        });
     }
     void relayout(int threads) {
-        recount();
+        recount(threads);
         relayout_dfs(nodes, 0u, threads);
     }
 
     // The `take` candidates of an iteration - the nodes with the largest area, largest first, ties by index - chosen
     // and ordered on `threads` cores: the order is total, so the result is the sequential one whatever the thread count.
-    typedef std::pair<float, uint32_t> Cand;
     static bool larger(const Cand &a, const Cand &b) { return a.first > b.first || (a.first == b.first && a.second < b.second); }
     template <class F>
     static void on_threads(int threads, F f) {
@@ -1237,11 +1383,16 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
     out.total_aabb = b2.nodes[0].box;
     if (params.reinsertion_batch_ratio > 0.f && params.reinsertion_iterations > 0) {
         Reinserter opt(b2.nodes);
-        if (params.reinsertion_batched)
+        if (params.reinsertion_whole_iterations) {
+            double dev_s = 0.0;
+            const int dev = n >= kDevicePlocMinPrims ? params.ploc_device : -1;
+            const uint32_t moved = opt.run_whole_iterations(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads, dev, &dev_s);
+            if (verbose) fprintf(stderr, "[trx build] reinsertion: %u moves, searches on %s (%.4f s of kernels)\n", moved, dev >= 0 ? "the device" : "the host", dev_s);
+        } else if (params.reinsertion_batched)
             opt.run_batched(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads);
         else
             opt.run(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads);
-        lap(params.reinsertion_batched ? "reinsertion (batched)" : "reinsertion");
+        lap(params.reinsertion_whole_iterations ? "reinsertion (whole iterations)" : params.reinsertion_batched ? "reinsertion (batched)" : "reinsertion");
     }
 
     Collapser col(b2.nodes, params, out);

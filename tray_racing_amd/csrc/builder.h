@@ -35,6 +35,10 @@ struct BuildParams {
     // true: batches of 128 candidates search the same tree on every core and their moves are applied in order,
     // stale ones skipped (the parallel formulation of the paper, as obvhs runs it) — the ploc_cwbvh pipeline
     bool reinsertion_batched = false;
+    // true: ONE batch per iteration - every candidate of an iteration searches the tree the previous iteration left (the
+    // paper's own formulation); the searches run on `ploc_device` when that is >= 0 (reinsert_gpu.cpp), else on the host
+    // cores, with the same result.  Takes precedence over reinsertion_batched.
+    bool reinsertion_whole_iterations = false;
     // pre-splitting (obvhs pre_split / --split): up to this fraction of extra triangle references, spent on
     // the triangles whose boxes are emptiest; 0 = off (the reference's default)
     float pre_split_ratio = 0.0f;
