@@ -665,6 +665,34 @@ def main():
             }
             pscene.close()
             del pflat
+            # (i') the same pipeline with its GPU stages (round 5): Morton sort + PLOC rounds, and the reinsertion pass with one
+            #      batch per iteration - candidates chosen (area keys + radix sort) and searched as kernels, one thread per
+            #      search, moves applied on the host - byte-identical to the same pass searched on the host cores
+            #      (tests/test_gpu_builder.py); collapse and encoding on the host
+            try:
+                T.load().trx_set_build_device(local_rank)
+                T.load().trx_set_build_reinsertion_batches(1)
+                T.load().trx_set_build_reinsertion(0.02, 8)   # (the ratio comes from the build parameters: 0.15; 8 iterations)
+                tg0 = time.time()
+                gflat = T.flat_build_params(verts, counts, T.build_params(), use_tlas=False, threads=threads)
+                gbuild = time.time() - tg0
+            finally:
+                T.load().trx_set_build_device(-1)
+                T.load().trx_set_build_reinsertion_batches(0)
+                T.load().trx_set_build_preset(args.preset.encode())
+            gscene = T.Scene(gflat, device=local_rank)
+            gst = gscene.count_primary(view, w, h, sem=args.sem)
+            gp = [gscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
+            legs["ploc_pipeline_gpu_stages"] = {
+                "params": "the same build parameters; reinsertion in 8 whole-iteration batches (ratio 0.15), BVH2 stage and "
+                          "reinsertion searches on the GPU",
+                "build_seconds": round(gbuild, 2), "nodes": int(gflat.n_nodes),
+                "nodes_per_ray": round(gst.n_node / gst.n_rays, 2), "tris_per_ray": round(gst.n_tri / gst.n_rays, 2),
+                "min_ms": round(sum(q[0] for q in gp) / 3, 4), "mean_ms": round(sum(q[1] for q in gp) / 3, 4),
+                "mrays_at_mean": round(n_rays_total / (sum(q[1] for q in gp) / 3) / 1e3, 1),
+            }
+            gscene.close()
+            del gflat
         # (j) the timed region WITHOUT the wake frames: the GPU idles for a second (as it does while a host builds a scene),
         #     then the W warm-up steps and K timed steps run straight away, on clocks that are still coming up - what the
         #     round-3 protocol measured (profiles/r04_clock_ramp.log); one event pair around the K launches, like `value`
@@ -701,7 +729,7 @@ def main():
         t1_rays["origin"] = np.array(eye, dtype=np.float32)
         t1_rays["direction"] = dirs.astype(np.float32)
         t1_rays["tmax"] = 3.4028234663852886e38
-        scene.traverse_threads(t1_rays[:512], threads=16, sem=args.sem)           # (creates the combiner, warms the slots)
+        scene.traverse_threads(t1_rays[:512], threads=16, sem=args.sem)           # (warms the launch slots)
         t1_hits, t1_s, t1_launches = scene.traverse_threads(t1_rays, threads=16, sem=args.sem)
         tb_hits, tb_ms = scene.traverse_batch(t1_rays, sem=args.sem)
         legs["traverse1_threads"] = {
@@ -709,7 +737,7 @@ def main():
             "rays_per_launch": round(n_t1 / max(t1_launches, 1), 1), "us_per_launch": round(t1_s / max(t1_launches, 1) * 1e6, 1),
             "equals_traverse_batch": bool((t1_hits == tb_hits).all()),
             "traverse_batch_kernel_mrays": round(n_t1 / (tb_ms * 1e-3) / 1e6, 1),
-            "note": "one blocking trx_traverse1 call per ray from 16 Python threads; rate = callers in flight / GPU round trip",
+            "note": "one blocking trx_traverse1 call per ray from 16 host threads; rate = callers in flight / GPU round trip",
         }
         # (f) compulsory footprint: distinct nodes / triangles one frame touches
         fn, ft = scene.footprint(view, w, h, sem=args.sem)

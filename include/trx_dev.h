@@ -49,6 +49,12 @@ int trx_debug_tile_profile(trx_scene *scene, const trx_view *view, uint32_t widt
  * shared a launch on average).  Either pointer may be NULL. */
 int trx_debug_traverse1_stats(trx_scene *scene, uint64_t *out_launches, uint64_t *out_rays);
 
+/* Measuring aid: the reference's CPU pixel loop over the literal Traversable::traverse (src/rt_cpu/rt_cpu.rs:35-57) -
+ * `threads` host threads, thread k calls trx_traverse1 for rays k, k + threads, ... - with the loop's wall-clock seconds and
+ * the launches its calls shared. */
+int trx_debug_traverse1_threads(trx_scene *scene, const trx_ray *rays, uint64_t n_rays, uint32_t threads, uint32_t semantics,
+                                trx_rayhit *out, double *out_seconds, uint64_t *out_launches);
+
 /* Kernel variant selection (tuning aid; 0 = default).  Returns the previous
  * value.  Variants compute identical results. */
 uint32_t trx_set_kernel_variant(uint32_t variant);

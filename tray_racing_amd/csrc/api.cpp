@@ -1664,6 +1664,54 @@ int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *ou
     return TRX_OK;
 }
 
+// The reference's CPU pixel loop over the literal Traversable::traverse (src/rt_cpu/rt_cpu.rs:35-57) as a measuring aid:
+// `threads` host threads, thread k calls trx_traverse1 for rays k, k + threads, ...; wall-clock seconds of the loop and the
+// launches its calls shared come back.  (The calls are the public entry point's; only the thread pool lives here, so that a
+// Python caller is not measuring its interpreter lock.)
+int trx_debug_traverse1_threads(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t threads, uint32_t sem, trx_rayhit *out,
+                                double *out_seconds, uint64_t *out_launches) {
+    if (!s || (n && (!rays || !out)) || threads == 0 || threads > 4096) return fail(TRX_ERR_INVALID, "bad argument");
+    uint64_t l0 = 0, l1 = 0;
+    if (n) { // the first call creates the combiner: not part of the loop's time
+        const int rc = trx_traverse1(s, &rays[0], sem, &out[0]);
+        if (rc) return rc;
+    }
+    (void)trx_debug_traverse1_stats(s, &l0, nullptr);
+    std::atomic<int> first_rc{0};
+    std::string first_err;
+    std::mutex err_mu;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    try {
+        for (uint32_t k = 0; k < threads; k++)
+            pool.emplace_back([&, k]() {
+                for (uint64_t i = k; i < n && first_rc.load(std::memory_order_relaxed) == 0; i += threads) {
+                    const int rc = trx_traverse1(s, &rays[i], sem, &out[i]);
+                    if (rc) {
+                        std::lock_guard<std::mutex> g(err_mu);
+                        if (first_rc.load() == 0) {
+                            first_err = g_err;
+                            first_rc.store(rc);
+                        }
+                    }
+                }
+            });
+    } catch (const std::exception &) {
+        first_rc.store(TRX_ERR_OOM);
+        first_err = "could not start the threads";
+    }
+    for (auto &th : pool) th.join();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    (void)trx_debug_traverse1_stats(s, &l1, nullptr);
+    if (first_rc.load()) {
+        g_err = first_err;
+        return first_rc.load();
+    }
+    if (out_seconds) *out_seconds = secs;
+    if (out_launches) *out_launches = l1 - l0;
+    return TRX_OK;
+}
+
 // Launches and rays the single-ray combiner has served so far (development / tests: rays / launches = callers per launch).
 int trx_debug_traverse1_stats(trx_scene *s, uint64_t *out_launches, uint64_t *out_rays) {
     if (!s) return fail(TRX_ERR_INVALID, "null argument");

@@ -667,6 +667,7 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     float t = 0.0f;
     uint32_t prim = TRX_INVALID, out_index = 0, sp = 0, steps = 0;
     uint32_t trip = 0; // traversal-loop trips of this wave (uniform)
+    uint32_t uni_cool = 0; // (uniform) trips for which the decode-once look is skipped
     uint32_t tlas_sp = TRX_INVALID, bvh_off = 0;
     // instance transforms (TLAS): the instance being walked / the one the current hit was found in, and the
     // world-space ray (origin, direction as given) to come back to when the BLAS is left
@@ -1763,6 +1764,15 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                 constexpr bool kUni = MODE == kModePrimary && !COUNT;
                 bool uni_done = false;
                 if constexpr (kUni) {
+#ifndef TRX_UNI_COOL
+#define TRX_UNI_COOL 1
+#endif
+                    // (the look itself is some thirty instructions: after a trip whose lanes wanted different nodes the next
+                    // TRX_UNI_COOL trips do not look - one trip: bistro-class frame -0.5 %, hairball-class -0.8 %, kitchen-class
+                    // -0.2 %; two: -0.1 / -1.2 / +0.5 %, profiles/r05_ab_7_unicool.log)
+                    if (TRX_UNI_COOL && uni_cool != 0u) {
+                        uni_cool--;
+                    } else
                     if (P.uni_decode) {
                         uint32_t node_index = 0u, child_bit = 0u;
                         // (two-level walks: a lane may hold a parked triangle group instead of a node group, and node
@@ -1802,6 +1812,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
                             }
                             __builtin_amdgcn_wave_barrier();
                             uni_done = true;
+                        } else if (TRX_UNI_COOL) {
+                            uni_cool = TRX_UNI_COOL;
                         }
                     }
                 }

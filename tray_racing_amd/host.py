@@ -325,38 +325,15 @@ class Scene:
         return out
 
     def traverse_threads(self, rays, threads=16, sem=L.SEM_HLSL):
-        """The reference's CPU pixel loop over the literal traverse (src/rt_cpu/rt_cpu.rs:35-57): `threads` host threads,
-        thread k calls trx_traverse1 for rays k, k + threads, ... (ctypes drops the GIL around each call).  Returns
-        (RAYHIT_DTYPE array, seconds, launches the calls shared)."""
-        import threading
-        import time
+        """The reference's CPU pixel loop over the literal traverse (src/rt_cpu/rt_cpu.rs:35-57): `threads` host threads
+        (native ones, inside the library: trx_debug_traverse1_threads), thread k calls trx_traverse1 for rays k,
+        k + threads, ...  Returns (RAYHIT_DTYPE array, seconds, launches the calls shared)."""
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
-        n = rays.shape[0]
-        out = np.zeros(n, dtype=RAYHIT_DTYPE)
-        rr = (L.Ray * n).from_buffer(rays)
-        oo = (L.RayHit * n).from_buffer(out)
-        l0, l1 = C.c_uint64(), C.c_uint64()
-        self._lib.trx_debug_traverse1_stats(self._h, C.byref(l0), None)
-        errs = []
-
-        def work(k):
-            fn, h = self._lib.trx_traverse1, self._h
-            for i in range(k, n, threads):
-                rc = fn(h, C.byref(rr[i]), sem, C.byref(oo[i]))
-                if rc:
-                    errs.append(rc)
-                    return
-        ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
-        t0 = time.perf_counter()
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        dt = time.perf_counter() - t0
-        if errs:
-            L.check(errs[0])
-        self._lib.trx_debug_traverse1_stats(self._h, C.byref(l1), None)
-        return out, dt, int(l1.value - l0.value)
+        out = np.zeros(rays.shape[0], dtype=RAYHIT_DTYPE)
+        secs, launches = C.c_double(), C.c_uint64()
+        L.check(self._lib.trx_debug_traverse1_threads(self._h, _ptr(rays), rays.shape[0], threads, sem, _ptr(out),
+                                                      C.byref(secs), C.byref(launches)))
+        return out, secs.value, int(launches.value)
 
     def traverse_batch(self, rays, sem=L.SEM_HLSL):
         """Traversable::traverse for a whole batch in one launch: (RAYHIT_DTYPE array, ms)."""
