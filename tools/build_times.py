@@ -1,6 +1,7 @@
-"""Stage times of the builders on the bistro-class scene (TRX_BUILD_VERBOSE=1 prints the laps): the medium_build preset and
-the reference-default PLOC pipeline, host only and with the build device (GPU stages); MODE=whole adds one batch per
-reinsertion iteration.  usage: TRX_BUILD_VERBOSE=1 python tools/build_times.py [iterations]"""
+"""Stage times of the builders on the bistro-class scene (TRX_BUILD_VERBOSE=1 prints the laps): the medium_build preset
+(binned-SAH BVH2, one candidate at a time) and the reference-default PLOC pipeline on the host cores, and the PLOC
+pipeline with its GPU stages (BVH2 + reinsertion selection and searches as kernels, one batch per iteration).
+usage: TRX_BUILD_VERBOSE=1 python tools/build_times.py [iterations of the GPU pipeline's reinsertion = 8]"""
 import os
 import sys
 import time
@@ -13,6 +14,12 @@ lib = L.load()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 v, c = T.gen_scene("bistro", 0, 1)
 for rep in range(2):
+    L.check(lib.trx_set_build_preset(b"medium_build"))
+    L.check(lib.trx_set_build_device(-1))
+    L.check(lib.trx_set_build_reinsertion_batches(0))
+    t0 = time.time()
+    flat = T.flat_build(v, c, use_tlas=False)
+    print("medium_build, host total %.2f s" % (time.time() - t0), "nodes", flat.n_nodes, flush=True)
     for label, dev, whole in (("host", -1, 0), ("device + whole iterations", 0, 1)):
         L.check(lib.trx_set_build_preset(b"medium_build"))
         L.check(lib.trx_set_build_device(dev))
@@ -22,3 +29,5 @@ for rep in range(2):
         t0 = time.time()
         flat = T.flat_build_params(v, c, T.build_params(), use_tlas=False)
         print("ploc default,", label, "total %.2f s" % (time.time() - t0), "nodes", flat.n_nodes, flush=True)
+L.check(lib.trx_set_build_device(-1))
+L.check(lib.trx_set_build_reinsertion_batches(0))

@@ -145,6 +145,7 @@ struct Bvh2Builder {
 
     static constexpr int kMaxBins = 32;
     static constexpr uint32_t kMaxSweep = 64;
+    static constexpr uint32_t kParallelSplitMin = 1u << 16; // ranges from this size up are split on every core (split_parallel)
     int kBins = 32;          // SAH bins per axis (<= kMaxBins)
     uint32_t kSweepMax = 48; // ranges up to this size get the exact sweep (<= kMaxSweep)
 
@@ -269,8 +270,173 @@ struct Bvh2Builder {
         return mid;
     }
 
-    // Builds one node; returns child tasks through l / r (false for a leaf).
-    bool build_node(const Task &t, Task &l, Task &r) {
+    // split() for a LARGE range on `threads` cores (the top of the tree: eight levels of it touch every primitive, and on
+    // one core they were 60 % of the BVH2 stage).  Same bins, same costs, same split plane - box unions and counts do not
+    // depend on the order they are merged in - and the same arrangement of the primitives inside the two sides as
+    // std::partition leaves (below).  The tree is the serial builder's, node for node and primitive for primitive.
+    BigVec<uint32_t> scratch_idx;
+    uint32_t split_parallel(uint32_t begin, uint32_t end, Aabb &bounds_out, int threads) {
+        const uint32_t n = end - begin;
+        struct Part {
+            Aabb bounds, cb;
+            Aabb bb[3][kMaxBins];
+            uint32_t bc[3][kMaxBins];
+            uint32_t left = 0;
+        };
+        std::vector<Part> part((size_t)threads);
+        auto chunk = [&](int t) { return std::make_pair(begin + (uint32_t)((uint64_t)n * (uint64_t)t / (uint64_t)threads),
+                                                        begin + (uint32_t)((uint64_t)n * (uint64_t)(t + 1) / (uint64_t)threads)); };
+        auto on_all = [&](auto f) {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < threads; t++) pool.emplace_back(f, t);
+            f(0);
+            for (auto &th : pool) th.join();
+        };
+        on_all([&](int t) {
+            Part &p = part[(size_t)t];
+            p.bounds = empty_box();
+            p.cb = empty_box();
+            for (uint32_t i = chunk(t).first; i < chunk(t).second; i++) {
+                const uint32_t q = idx[i];
+                grow(p.bounds, boxes[q]);
+                grow_pt(p.cb, &cen[3 * (size_t)q]);
+            }
+        });
+        Aabb bounds = empty_box(), cb = empty_box();
+        for (const Part &p : part) {
+            grow(bounds, p.bounds);
+            grow(cb, p.cb);
+        }
+        bounds_out = bounds;
+        float lo[3], scale[3];
+        bool live[3];
+        for (int axis = 0; axis < 3; axis++) {
+            lo[axis] = cb.mn[axis];
+            live[axis] = cb.mx[axis] > lo[axis];
+            scale[axis] = live[axis] ? (float)kBins / (cb.mx[axis] - lo[axis]) : 0.f;
+        }
+        on_all([&](int t) {
+            Part &p = part[(size_t)t];
+            for (int axis = 0; axis < 3; axis++)
+                for (int b = 0; b < kBins; b++) {
+                    p.bb[axis][b] = empty_box();
+                    p.bc[axis][b] = 0;
+                }
+            for (uint32_t i = chunk(t).first; i < chunk(t).second; i++) {
+                const uint32_t q = idx[i];
+                for (int axis = 0; axis < 3; axis++) {
+                    if (!live[axis]) continue;
+                    int b = (int)((cen[3 * (size_t)q + axis] - lo[axis]) * scale[axis]);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    grow(p.bb[axis][b], boxes[q]);
+                    p.bc[axis][b]++;
+                }
+            }
+        });
+        float best_cost = kInf;
+        int best_axis = -1, best_bin = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            if (!live[axis]) continue;
+            Aabb bb[kMaxBins];
+            uint32_t bc[kMaxBins];
+            for (int b = 0; b < kBins; b++) {
+                bb[b] = empty_box();
+                bc[b] = 0;
+                for (const Part &p : part) {
+                    grow(bb[b], p.bb[axis][b]);
+                    bc[b] += p.bc[axis][b];
+                }
+            }
+            float right_area[kMaxBins];
+            uint32_t right_cnt[kMaxBins];
+            Aabb acc = empty_box();
+            uint32_t cnt = 0;
+            for (int b = kBins - 1; b > 0; b--) {
+                grow(acc, bb[b]);
+                cnt += bc[b];
+                right_area[b] = half_area(acc);
+                right_cnt[b] = cnt;
+            }
+            acc = empty_box();
+            cnt = 0;
+            for (int b = 0; b < kBins - 1; b++) {
+                grow(acc, bb[b]);
+                cnt += bc[b];
+                if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                float cost = half_area(acc) * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_bin = b;
+                }
+            }
+        }
+        uint32_t mid = begin;
+        if (best_axis >= 0) {
+            const float l0 = lo[best_axis], sc = scale[best_axis];
+            auto goes_left = [&](uint32_t q) {
+                int b = (int)((cen[3 * (size_t)q + best_axis] - l0) * sc);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b <= best_bin;
+            };
+            // The arrangement std::partition leaves (libstdc++'s bidirectional algorithm: the k-th misplaced element from the
+            // left changes places with the k-th misplaced element from the right), produced on every core: a range of two
+            // is split by position, so the ORDER inside a side is part of the tree's primitive order.
+            on_all([&](int t) {
+                uint32_t c = 0;
+                for (uint32_t i = chunk(t).first; i < chunk(t).second; i++) c += goes_left(idx[i]) ? 1u : 0u;
+                part[(size_t)t].left = c;
+            });
+            uint32_t total_left = 0;
+            for (int t = 0; t < threads; t++) total_left += part[(size_t)t].left;
+            mid = begin + total_left;
+            if (mid != begin && mid != end) {
+                // holes: positions below mid that hold a right-side element (rising); strays: positions from mid on that
+                // hold a left-side element (falling).  There are equally many.
+                std::vector<uint32_t> n_hole((size_t)threads, 0u), n_stray((size_t)threads, 0u);
+                on_all([&](int t) {
+                    uint32_t h = 0, g = 0;
+                    for (uint32_t i = chunk(t).first; i < chunk(t).second; i++) {
+                        const bool l = goes_left(idx[i]);
+                        h += (i < mid && !l) ? 1u : 0u;
+                        g += (i >= mid && l) ? 1u : 0u;
+                    }
+                    n_hole[(size_t)t] = h;
+                    n_stray[(size_t)t] = g;
+                });
+                std::vector<uint32_t> hole_at((size_t)threads), stray_at((size_t)threads);
+                uint32_t pairs = 0;
+                for (int t = 0; t < threads; t++) {
+                    hole_at[(size_t)t] = pairs;
+                    pairs += n_hole[(size_t)t];
+                }
+                uint32_t from_right = 0;
+                for (int t = threads - 1; t >= 0; t--) {
+                    stray_at[(size_t)t] = from_right;
+                    from_right += n_stray[(size_t)t];
+                }
+                if (scratch_idx.size() < 2 * (size_t)pairs) scratch_idx.resize(2 * (size_t)pairs);
+                uint32_t *const hole = scratch_idx.data(), *const stray = scratch_idx.data() + pairs;
+                on_all([&](int t) {
+                    uint32_t h = hole_at[(size_t)t];
+                    for (uint32_t i = chunk(t).first; i < chunk(t).second && i < mid; i++)
+                        if (!goes_left(idx[i])) hole[h++] = i;
+                    uint32_t g = stray_at[(size_t)t];
+                    for (uint32_t i = chunk(t).second; i-- > std::max(chunk(t).first, mid);)
+                        if (goes_left(idx[i])) stray[g++] = i;
+                });
+                on_all([&](int t) {
+                    for (uint32_t k = (uint32_t)((uint64_t)pairs * (uint64_t)t / (uint64_t)threads); k < (uint32_t)((uint64_t)pairs * (uint64_t)(t + 1) / (uint64_t)threads); k++)
+                        std::swap(idx[hole[k]], idx[stray[k]]);
+                });
+            }
+        }
+        if (mid == begin || mid == end) return split(begin, end, bounds_out); // (degenerate: the serial path's fall-back)
+        return mid;
+    }
+
+    // Builds one node; returns child tasks through l / r (false for a leaf).  threads > 1: a large range, split on every core.
+    bool build_node(const Task &t, Task &l, Task &r, int threads = 1) {
         Node2 &nd = nodes[t.node];
         uint32_t n = t.end - t.begin;
         nd.count = n;
@@ -281,7 +447,8 @@ struct Bvh2Builder {
             nd.prim = p;
             return false;
         }
-        uint32_t mid = split(t.begin, t.end, nd.box);
+        uint32_t mid = threads > 1 && n >= kParallelSplitMin && n > kSweepMax ? split_parallel(t.begin, t.end, nd.box, threads)
+                                                                               : split(t.begin, t.end, nd.box);
         uint32_t nl = mid - t.begin;
         nd.left = t.node + 1;
         nd.right = t.node + 2 * nl;
@@ -321,7 +488,7 @@ struct Bvh2Builder {
                 continue;
             }
             Task l, r;
-            if (build_node(t, l, r)) {
+            if (build_node(t, l, r, threads)) {
                 pending.push_back(r);
                 pending.push_back(l);
             }
