@@ -890,6 +890,12 @@ def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path, world, streams, batch
     assert ph["collective_world_size"] == world and ph["trace"] > 0 and ph["gather"] > 0 and ph["assemble"] > 0
     assert 0 < ph["trace_ranks_min"] <= ph["trace_ranks_max"] and ph["gather_via"] == (extra[1] if extra else "torch")
     assert ph["gather_to"] == ("root" if "root" in extra else "all")
+    # round 5: a scaling factor is quoted against ONE rank under the same protocol (same streams, same frames per launch, no
+    # gather), the timed region is repeated, and the collective's world is reported at top level
+    assert d["protocol_version"] == 5 and d["rccl_world"] == world
+    assert d["n1_same_protocol_mrays"] > 0 and d["scaling_vs_same_protocol"] == pytest.approx(d["value"] / d["n1_same_protocol_mrays"], rel=1e-2)
+    rep = d["legs"]["timed_region_repeats"]
+    assert rep["n"] >= 7 and rep["ms_per_step_min"] <= rep["ms_per_step_median"] <= rep["ms_per_step_max"]
     g = np.load(dump + ".scene.npz")
     osc = orc.Scene(g["nodes"], g["tri_verts"], g["instance_offsets"], int(g["tlas_start"]))
     want, _ = osc.trace_primary(orc.view_from_bytes(g["view"].tobytes()), int(g["width"]), int(g["height"]), sem=3)
