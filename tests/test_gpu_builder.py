@@ -105,3 +105,46 @@ def test_device_reinsertion_searches_equal_host_searches(trx, orc, name, n, tlas
         lib.trx_set_build_device(-1)
         lib.trx_set_build_reinsertion_batches(0)
         lib.trx_set_build_preset(b"medium_build")
+
+
+@pytest.mark.parametrize("max_prims,cost", [(3, 1.0), (1, 1.0), (2, 0.4), (3, 3.0)])
+def test_device_collapse_and_encoding_equal_the_host_stage(trx, orc, max_prims, cost):
+    """With a build device set, the BVH2 -> CWBVH stage runs as kernels (csrc/collapse_gpu.cpp: cost table level by level,
+    the collapsed tree top-down, subtree sizes, output offsets, encoding) on a tree left in whatever layout the
+    reinsertion pass ended with.  Same nodes and triangle order as the host stage (Collapser in builder.cpp, which
+    re-lays the tree out first) for every leaf size and traversal cost, behind each of the three reinsertion passes; the
+    result validates and traces like the oracle says."""
+    lib = trx.load()
+    try:
+        for name, n in (("bistro", 200000), ("soup", 60000)):
+            verts, _counts = trx.gen_scene(name, n, 1)
+            counts = np.array([n], dtype=np.uint64)
+            for mode in ("one at a time", "batches of 128", "whole iterations"):
+                assert lib.trx_set_build_preset(b"medium_build") == 0
+                assert lib.trx_set_build_reinsertion_batches(1 if mode == "whole iterations" else 0) == 0
+                built = []
+                for device in (-1, 0):
+                    assert lib.trx_set_build_device(device) == 0
+                    if mode == "one at a time":
+                        built.append(trx.flat_build(verts, counts, max_prims_per_leaf=max_prims, traversal_cost=cost))
+                    else:
+                        built.append(trx.flat_build_params(verts, counts, trx.build_params(max_prims_per_leaf=max_prims,
+                                                                                         collapse_traversal_cost=cost)))
+                host, dev = built
+                assert host.nodes.shape == dev.nodes.shape and (host.nodes == dev.nodes).all(), (name, mode)
+                assert (host.tri_source == dev.tri_source).all(), (name, mode)
+            osc = orc.Scene.from_flat(dev)
+            assert osc.validate() == (0, "")
+            eye, look, fov = trx.scene_camera(name)
+            w, h = 96, 64
+            view = trx.view_from_camera(eye, look, fov, w, h)
+            want, _ = osc.trace_primary(orc.view_from_bytes(view), w, h, sem=3)
+            sc = trx.Scene(dev)
+            got, _ = sc.trace_primary(view, w, h, sem=3)
+            sc.close()
+            assert (got["prim"] == want["prim"]).all() and (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+    finally:
+        lib.trx_set_build_device(-1)
+        lib.trx_set_build_reinsertion_batches(0)
+        lib.trx_set_build_costs(1.0, 0.3)
+        lib.trx_set_build_preset(b"medium_build")

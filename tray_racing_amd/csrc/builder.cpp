@@ -1,6 +1,7 @@
 // builder.cpp — CPU construction of the 80-byte CWBVH (see builder.h).
 #include "builder.h"
 #include "ploc_gpu.h"
+#include "collapse_gpu.h"
 #include "reinsert_gpu.h"
 
 #include <algorithm>
@@ -862,7 +863,7 @@ struct Reinserter {
     // per candidate, reinsert_gpu.cpp) or, device < 0, on `threads` cores - the same searches, the same found[], the same
     // tree either way (tests/test_gpu_builder.py).  Moves are applied on the host in candidate order, stale ones skipped.
     // More of the searches are stale than with batches of 128, so an iteration gains less and the pass runs more of them.
-    uint32_t run_whole_iterations(float batch_ratio, int iterations, int threads, int device, double *device_seconds) {
+    uint32_t run_whole_iterations(float batch_ratio, int iterations, int threads, int device, double *device_seconds, bool keep_layout = false) {
         const size_t n = nodes.size();
         uint32_t moved = 0;
         if (n < 8 || batch_ratio <= 0.f) return 0;
@@ -926,14 +927,15 @@ struct Reinserter {
             if (moved_now == 0) break;
         }
         const auto t3 = now();
-        if (moved) relayout(threads);
+        // (the device's collapse stage follows links and counts the primitives itself: no pre-order layout needed)
+        if (moved && !keep_layout) relayout(threads);
         if (verbose)
             fprintf(stderr, "[trx build] reinsertion: select %.3f s, search (+ copies) %.3f s, apply %.3f s, re-layout %.3f s\n", t_select, t_search,
                     t_apply, secs(t3, now()));
         return moved;
     }
 
-    uint32_t run_batched(float batch_ratio, int iterations, int threads) {
+    uint32_t run_batched(float batch_ratio, int iterations, int threads, bool keep_layout = false) {
         const size_t n = nodes.size();
         uint32_t moved = 0;
         if (n < 8 || batch_ratio <= 0.f) return 0;
@@ -997,17 +999,25 @@ struct Reinserter {
             moved += moved_now;
             if (moved_now == 0) break;
         }
-        if (moved) relayout(threads);
+        if (moved && !keep_layout) relayout(threads);
         return moved;
     }
 
-    uint32_t run(float batch_ratio, int iterations, int threads) {
+    uint32_t run(float batch_ratio, int iterations, int threads, bool keep_layout = false) {
         const size_t n = nodes.size();
         uint32_t moved = 0;
         if (n < 8 || batch_ratio <= 0.f) return 0;
         BigVec<Cand> cand, cand_tmp;
+        const bool verbose = getenv("TRX_BUILD_VERBOSE") != nullptr && n > 100000;
+        auto now = []() { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        double t_select = 0, t_search = 0;
+        size_t searched = 0;
         for (int it = 0; it < iterations; it++) {
+            const auto t0 = now();
             const size_t take = select_candidates(cand, cand_tmp, batch_ratio, std::min(threads, usable_threads()));
+            const auto t1 = now();
+            t_select += secs(t0, t1);
             // one at a time, each search on the tree as the previous move left it (sequential: the searches
             // cost little next to the memory passes around them, and stale searches lose tree quality)
             uint32_t moved_now = 0;
@@ -1020,10 +1030,16 @@ struct Reinserter {
                     moved_now++;
                 }
             }
+            searched += take;
+            t_search += secs(t1, now());
             moved += moved_now;
             if (moved_now == 0) break;
         }
-        if (moved) relayout(threads);
+        const auto t3 = now();
+        if (moved && !keep_layout) relayout(threads);
+        if (verbose)
+            fprintf(stderr, "[trx build] reinsertion: select %.3f s, %zu searches + %u moves %.3f s, re-layout %.3f s\n", t_select, searched, moved,
+                    t_search, secs(t3, now()));
         return moved;
     }
 
@@ -1550,18 +1566,32 @@ void build_from_boxes(const Aabb *boxes, const float *centroids, uint64_t n, con
     out.total_aabb = b2.nodes[0].box;
     if (params.reinsertion_batch_ratio > 0.f && params.reinsertion_iterations > 0) {
         Reinserter opt(b2.nodes);
+        const int dev = n >= kDevicePlocMinPrims ? params.ploc_device : -1; // (>= 0: the collapse runs there and needs no pre-order layout)
         if (params.reinsertion_whole_iterations) {
             double dev_s = 0.0;
-            const int dev = n >= kDevicePlocMinPrims ? params.ploc_device : -1;
-            const uint32_t moved = opt.run_whole_iterations(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads, dev, &dev_s);
+            const uint32_t moved = opt.run_whole_iterations(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads, dev, &dev_s, dev >= 0);
             if (verbose) fprintf(stderr, "[trx build] reinsertion: %u moves, searches on %s (%.4f s of kernels)\n", moved, dev >= 0 ? "the device" : "the host", dev_s);
         } else if (params.reinsertion_batched)
-            opt.run_batched(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads);
+            opt.run_batched(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads, dev >= 0);
         else
-            opt.run(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads);
+            opt.run(params.reinsertion_batch_ratio, params.reinsertion_iterations, threads, dev >= 0);
         lap(params.reinsertion_whole_iterations ? "reinsertion (whole iterations)" : params.reinsertion_batched ? "reinsertion (batched)" : "reinsertion");
     }
 
+    if (params.ploc_device >= 0 && n >= kDevicePlocMinPrims) {
+        // cost table, emission order and node encoding as kernels; the bytes are the ones the host stage below writes
+        std::string err;
+        double dev_s = 0.0;
+        float root_cost = 0.f;
+        if (!collapse_encode_device(params.ploc_device, b2.nodes.data(), b2.nodes.size(), params.max_prims_per_leaf, params.traversal_cost,
+                                    params.prim_cost, out.nodes, out.primitive_indices, &root_cost, &dev_s, err))
+            throw std::runtime_error("GPU build stage: " + err);
+        out.sah_cost = root_cost / std::max(half_area(b2.nodes[0].box), 1e-30f);
+        if (verbose) fprintf(stderr, "[trx build] collapse + encode on device %d: %.4f s of kernels, sah8=%.3f\n", params.ploc_device, dev_s, out.sah_cost);
+        lap("collapse (device)");
+        out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return;
+    }
     Collapser col(b2.nodes, params, out);
     col.compute_costs(threads);
     lap("collapse dp");

@@ -131,25 +131,44 @@ def flat_build(verts, object_counts=None, use_tlas=False, max_prims_per_leaf=3, 
     return _take_flat(lib, fp)
 
 
+class _FlatOwner:
+    """Keeps a trx_flat alive while numpy views of its buffers exist (trx_flat_destroy when the last one goes)."""
+
+    def __init__(self, lib, fp):
+        self.lib, self.fp = lib, fp
+
+    def __del__(self):
+        try:
+            self.lib.trx_flat_destroy(self.fp)
+        except Exception:   # interpreter shutdown
+            pass
+
+
+def _view(owner, address, dtype, count, shape):
+    """A numpy array over `count` items of the library's memory at `address` (no copy: a 3.9 M triangle scene has
+    280 MB of them); the array holds `owner`."""
+    dtype = np.dtype(dtype)
+    if count == 0 or not address:
+        return np.zeros(shape, dtype=dtype)
+    raw = (C.c_uint8 * (count * dtype.itemsize)).from_address(address)
+    raw._trx_owner = owner
+    return np.frombuffer(raw, dtype=dtype).reshape(shape)
+
+
 def _take_flat(lib, fp):
     f = fp.contents
-    try:
-        nodes = np.frombuffer((C.c_uint8 * (f.n_nodes * 80)).from_address(f.bvh_bytes), dtype=np.uint32).copy()
-        tris = np.ctypeslib.as_array(f.tri_verts, shape=(max(f.n_tris, 1), 9))[: f.n_tris].copy()
-        inst = np.ctypeslib.as_array(f.instance_offsets, shape=(max(f.n_instances, 1),))[: f.n_instances].copy()
-        src = np.ctypeslib.as_array(f.tri_source, shape=(max(f.n_tris, 1),))[: f.n_tris].copy()
-        bts = np.ctypeslib.as_array(f.blas_tri_start, shape=(f.n_blas + 1,)).copy()
-        boxes = np.ctypeslib.as_array(f.tri_boxes, shape=(max(f.n_tris, 1), 6))[: f.n_tris].copy()
-        isrc = np.ctypeslib.as_array(f.instance_source, shape=(max(f.n_instances, 1),))[: f.n_instances].copy()
-        ixf = None
-        if f.instance_transforms:
-            ixf = np.ctypeslib.as_array(f.instance_transforms, shape=(max(f.n_instances, 1), 16))[: f.n_instances].copy()
-        ient = None
-        if f.instance_entry_nodes:
-            ient = np.ctypeslib.as_array(f.instance_entry_nodes, shape=(max(f.n_instances, 1),))[: f.n_instances].copy()
-        return FlatScene(nodes, tris, inst, f.tlas_start, src, bts, f.blas_build_s, f.tlas_build_s, boxes, isrc, ixf, ient)
-    finally:
-        lib.trx_flat_destroy(fp)
+    owner = _FlatOwner(lib, fp)
+    addr = lambda p: C.cast(p, C.c_void_p).value
+    nodes = _view(owner, f.bvh_bytes, np.uint32, f.n_nodes * 20, (f.n_nodes, 20))
+    tris = _view(owner, addr(f.tri_verts), np.float32, f.n_tris * 9, (f.n_tris, 9))
+    inst = _view(owner, addr(f.instance_offsets), np.uint32, f.n_instances, (f.n_instances,))
+    src = _view(owner, addr(f.tri_source), np.uint32, f.n_tris, (f.n_tris,))
+    bts = _view(owner, addr(f.blas_tri_start), np.uint32, f.n_blas + 1, (f.n_blas + 1,))
+    boxes = _view(owner, addr(f.tri_boxes), np.float32, f.n_tris * 6, (f.n_tris, 6))
+    isrc = _view(owner, addr(f.instance_source), np.uint32, f.n_instances, (f.n_instances,))
+    ixf = _view(owner, addr(f.instance_transforms), np.float32, f.n_instances * 16, (f.n_instances, 16)) if f.instance_transforms else None
+    ient = _view(owner, addr(f.instance_entry_nodes), np.uint32, f.n_instances, (f.n_instances,)) if f.instance_entry_nodes else None
+    return FlatScene(nodes, tris, inst, f.tlas_start, src, bts, f.blas_build_s, f.tlas_build_s, boxes, isrc, ixf, ient)
 
 
 def flat_build_instanced(verts, object_counts, instance_object, object_to_world=None, max_prims_per_leaf=3, threads=0):
