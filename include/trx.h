@@ -553,11 +553,14 @@ typedef struct trx_build_params {
     float collapse_traversal_cost;      /* --collapse-traversal-cost */
 } trx_build_params;
 void trx_build_params_default(trx_build_params *params); /* the reference's command-line defaults */
-/* Where the BVH2 stage of trx_flat_build_params (Morton sort + PLOC merge rounds) runs for subsequent builds
- * (process-wide): device >= 0 = on that HIP device, as kernels (objects of at least 32,768 primitives; the many small
- * BLASes of a TLAS scene stay on the host cores), -1 = on the host cores (default).  The device stage returns the very
- * tree the host stage returns (same operations in the same order); reinsertion, collapse and encoding follow on the
- * host either way.  A device failure fails the build (TRX_ERR_NO_DEVICE / TRX_ERR_OOM): nothing falls back silently. */
+/* Which stages of subsequent builds run on a HIP device, as kernels (process-wide): device >= 0 = that device, -1 = the
+ * host cores only (default).  Objects of at least 32,768 primitives take the device stages; the many small BLASes of a
+ * TLAS scene stay on the host cores.  Stages: the BVH2 stage of trx_flat_build_params (Morton sort + PLOC merge rounds);
+ * candidate selection and searches of the whole-iteration reinsertion pass (trx_set_build_reinsertion_batches(1); its
+ * moves are applied on the host, in candidate order); and, for every builder, the BVH2 -> CWBVH stage (cost table,
+ * collapse, slot assignment, node encoding, primitive order).  Each device stage returns the very bytes its host twin
+ * returns (same operations in the same order), so a build is the same build wherever it ran.  A device failure fails
+ * the build (TRX_ERR_NO_DEVICE / TRX_ERR_OOM): nothing falls back silently. */
 int trx_set_build_device(int device);
 /* TLAS of trx_flat_build / trx_flat_build_params (process-wide): a BLAS whose box exceeds `area_fraction` of the scene
  * box's surface area is referenced through the subtrees under its root instead of as a whole, largest first, as long as
