@@ -934,7 +934,7 @@ def main():
             "protocol_version": 5,
             "rccl_world": rccl_world,
             "n1_same_protocol_mrays": round(n1_same, 2) if n1_same else None,
-            "scaling_vs_same_protocol": round(value / n1_same, 3) if n1_same else None,
+            "scaling_vs_same_protocol": round(value / n1_same, 4) if n1_same else None,
             "kernel_ms_mean": round(kernel_ms, 4),
             "kernel_ms_min": round(min(launch_ms), 4),
             "kernel_ms_min_source": ("per-launch hipEvent pairs of an untimed REPLAY of the same frames right after the timed "

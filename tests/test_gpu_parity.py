@@ -893,7 +893,7 @@ def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path, world, streams, batch
     # round 5: a scaling factor is quoted against ONE rank under the same protocol (same streams, same frames per launch, no
     # gather), the timed region is repeated, and the collective's world is reported at top level
     assert d["protocol_version"] == 5 and d["rccl_world"] == world
-    assert d["n1_same_protocol_mrays"] > 0 and d["scaling_vs_same_protocol"] == pytest.approx(d["value"] / d["n1_same_protocol_mrays"], rel=1e-2)
+    assert d["n1_same_protocol_mrays"] > 0 and d["scaling_vs_same_protocol"] == pytest.approx(d["value"] / d["n1_same_protocol_mrays"], rel=1e-2, abs=1e-4)
     rep = d["legs"]["timed_region_repeats"]
     assert rep["n"] >= 7 and rep["ms_per_step_min"] <= rep["ms_per_step_median"] <= rep["ms_per_step_max"]
     g = np.load(dump + ".scene.npz")
