@@ -11,8 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <thread>
@@ -123,6 +125,56 @@ inline float half_area(const Aabb &b) {
     return dx * dy + dy * dz + dz * dx;
 }
 
+// A few dozen short parallel phases in a row (the top of the BVH2 build: five per split) cost more in thread creation than
+// in work when every phase starts its own threads; this keeps the threads and hands them one phase after the other.
+// Workers spin briefly, then yield, between phases; the pool lives only as long as the phases do.
+struct PhasePool {
+    const int n;
+    std::vector<std::thread> workers;
+    std::atomic<uint64_t> generation{0};
+    std::atomic<int> done{0};
+    std::function<void(int)> phase;
+    bool stop = false;
+
+    explicit PhasePool(int threads) : n(std::max(1, threads)) {
+        for (int t = 1; t < n; t++)
+            workers.emplace_back([this, t]() {
+                uint64_t seen = 0;
+                for (;;) {
+                    uint64_t g;
+                    for (unsigned spins = 0; (g = generation.load(std::memory_order_acquire)) == seen; spins++) {
+                        if (spins < 4000) __builtin_ia32_pause();
+                        else std::this_thread::yield();
+                    }
+                    seen = g;
+                    if (stop) return;
+                    phase(t);
+                    done.fetch_add(1, std::memory_order_acq_rel);
+                }
+            });
+    }
+    // f(t) for t = 0 .. n-1, t = 0 on the calling thread; returns when all have returned
+    template <class F>
+    void run(F f) {
+        if (n == 1) {
+            f(0);
+            return;
+        }
+        phase = f;
+        done.store(0, std::memory_order_relaxed);
+        generation.fetch_add(1, std::memory_order_release);
+        f(0);
+        while (done.load(std::memory_order_acquire) != n - 1) __builtin_ia32_pause();
+    }
+    ~PhasePool() {
+        stop = true;
+        generation.fetch_add(1, std::memory_order_release);
+        for (auto &th : workers) th.join();
+    }
+    PhasePool(const PhasePool &) = delete;
+    PhasePool &operator=(const PhasePool &) = delete;
+};
+
 // ---- BVH2 ------------------------------------------------------------------
 // Nodes are laid out in DFS pre-order: a subtree over n primitives owns exactly
 // 2n-1 consecutive nodes, so the layout is independent of the thread schedule.
@@ -146,7 +198,7 @@ struct Bvh2Builder {
 
     static constexpr int kMaxBins = 32;
     static constexpr uint32_t kMaxSweep = 64;
-    static constexpr uint32_t kParallelSplitMin = 1u << 16; // ranges from this size up are split on every core (split_parallel)
+    static constexpr uint32_t kParallelSplitMin = 1u << 15; // ranges from this size up are split on every core (split_parallel)
     int kBins = 32;          // SAH bins per axis (<= kMaxBins)
     uint32_t kSweepMax = 48; // ranges up to this size get the exact sweep (<= kMaxSweep)
 
@@ -276,6 +328,7 @@ struct Bvh2Builder {
     // depend on the order they are merged in - and the same arrangement of the primitives inside the two sides as
     // std::partition leaves (below).  The tree is the serial builder's, node for node and primitive for primitive.
     BigVec<uint32_t> scratch_idx;
+    PhasePool *top_pool = nullptr; // threads of the parallel splits (run())
     uint32_t split_parallel(uint32_t begin, uint32_t end, Aabb &bounds_out, int threads) {
         const uint32_t n = end - begin;
         struct Part {
@@ -287,12 +340,7 @@ struct Bvh2Builder {
         std::vector<Part> part((size_t)threads);
         auto chunk = [&](int t) { return std::make_pair(begin + (uint32_t)((uint64_t)n * (uint64_t)t / (uint64_t)threads),
                                                         begin + (uint32_t)((uint64_t)n * (uint64_t)(t + 1) / (uint64_t)threads)); };
-        auto on_all = [&](auto f) {
-            std::vector<std::thread> pool;
-            for (int t = 1; t < threads; t++) pool.emplace_back(f, t);
-            f(0);
-            for (auto &th : pool) th.join();
-        };
+        auto on_all = [&](auto f) { top_pool->run(f); };
         on_all([&](int t) {
             Part &p = part[(size_t)t];
             p.bounds = empty_box();
@@ -477,40 +525,70 @@ struct Bvh2Builder {
         nodes.resize(2 * (size_t)n - 1);
         idx.resize(n);
         for (uint32_t i = 0; i < n; i++) idx[i] = i;
-        // Serial top: split every range larger than the grain, then hand the
-        // remaining subtrees to the thread pool.
-        uint32_t grain = std::max<uint32_t>(4096, n / (uint32_t)(threads * 16));
-        std::vector<Task> pending{Task{0, 0, n}}, leaves;
-        while (!pending.empty()) {
-            Task t = pending.back();
-            pending.pop_back();
-            if (t.end - t.begin <= grain || threads == 1) {
-                leaves.push_back(t);
-                continue;
+        // Top: ranges of at least kParallelSplitMin primitives are split one after the other, each on every core; what is
+        // left goes to a shared queue, where a worker either splits a range once more (still larger than the grain: its
+        // halves go back to the queue) or builds the whole subtree - nothing is ever split by one core while the others wait.
+        const uint32_t grain = std::max<uint32_t>(4096, n / (uint32_t)(threads * 16));
+        std::vector<Task> pending{Task{0, 0, n}}, queue;
+        const auto t_top = std::chrono::steady_clock::now();
+        {
+            PhasePool pool(threads);
+            top_pool = &pool;
+            while (!pending.empty()) {
+                Task t = pending.back();
+                pending.pop_back();
+                if (t.end - t.begin < kParallelSplitMin || t.end - t.begin <= grain || threads == 1) {
+                    queue.push_back(t);
+                    continue;
+                }
+                Task l, r;
+                if (build_node(t, l, r, threads)) {
+                    pending.push_back(r);
+                    pending.push_back(l);
+                }
             }
-            Task l, r;
-            if (build_node(t, l, r, threads)) {
-                pending.push_back(r);
-                pending.push_back(l);
-            }
+            top_pool = nullptr;
         }
-        std::sort(leaves.begin(), leaves.end(),
-                  [](const Task &a, const Task &b) { return a.end - a.begin > b.end - b.begin; });
-        std::atomic<size_t> next{0};
+        if (getenv("TRX_BUILD_VERBOSE") && n > 100000) fprintf(stderr, "[trx build] bvh2 top: %.3f s, %zu ranges\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_top).count(), queue.size());
+        std::sort(queue.begin(), queue.end(), [](const Task &a, const Task &b) { return a.end - a.begin < b.end - b.begin; }); // largest last = first out
+        if (threads <= 1) {
+            for (size_t i = queue.size(); i-- > 0;) build_subtree(queue[i]);
+            return;
+        }
+        std::mutex mu;
+        std::atomic<size_t> outstanding{queue.size()}; // ranges in the queue or in a worker's hands
         auto worker = [&]() {
             for (;;) {
-                size_t i = next.fetch_add(1);
-                if (i >= leaves.size()) break;
-                build_subtree(leaves[i]);
+                Task t;
+                {
+                    std::unique_lock<std::mutex> lock(mu);
+                    if (queue.empty()) {
+                        lock.unlock();
+                        if (outstanding.load(std::memory_order_acquire) == 0) return;
+                        std::this_thread::yield();
+                        continue;
+                    }
+                    t = queue.back();
+                    queue.pop_back();
+                }
+                Task l, r;
+                if (t.end - t.begin > grain) {
+                    if (build_node(t, l, r)) {
+                        std::lock_guard<std::mutex> lock(mu);
+                        queue.push_back(r);
+                        queue.push_back(l);
+                        outstanding.fetch_add(1, std::memory_order_acq_rel); // one taken, two added
+                        continue;
+                    }
+                } else {
+                    build_subtree(t);
+                }
+                outstanding.fetch_sub(1, std::memory_order_acq_rel);
             }
         };
-        if (threads <= 1) {
-            worker();
-        } else {
-            std::vector<std::thread> pool;
-            for (int i = 0; i < threads; i++) pool.emplace_back(worker);
-            for (auto &th : pool) th.join();
-        }
+        std::vector<std::thread> pool;
+        for (int i = 0; i < threads; i++) pool.emplace_back(worker);
+        for (auto &th : pool) th.join();
     }
 };
 
