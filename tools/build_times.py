@@ -1,6 +1,7 @@
 """Stage times of the builders on the bistro-class scene (TRX_BUILD_VERBOSE=1 prints the laps): the medium_build preset
-(binned-SAH BVH2, one candidate at a time) and the reference-default PLOC pipeline on the host cores, and the PLOC
-pipeline with its GPU stages (BVH2 + reinsertion selection and searches as kernels, one batch per iteration).
+(binned-SAH BVH2, one candidate at a time; on the host cores, and with its collapse stage on the GPU), the
+reference-default PLOC pipeline on the host cores, and the PLOC pipeline with its GPU stages (BVH2, reinsertion
+selection and searches, collapse + encoding as kernels, one batch per iteration).
 usage: TRX_BUILD_VERBOSE=1 python tools/build_times.py [iterations of the GPU pipeline's reinsertion = 8]"""
 import os
 import sys
@@ -20,6 +21,10 @@ for rep in range(2):
     t0 = time.time()
     flat = T.flat_build(v, c, use_tlas=False)
     print("medium_build, host total %.2f s" % (time.time() - t0), "nodes", flat.n_nodes, flush=True)
+    L.check(lib.trx_set_build_device(0))   # the same tree; collapse + encoding as kernels, no re-layout before them
+    t0 = time.time()
+    flat = T.flat_build(v, c, use_tlas=False)
+    print("medium_build, collapse stage on the device total %.2f s" % (time.time() - t0), "nodes", flat.n_nodes, flush=True)
     for label, dev, whole in (("host", -1, 0), ("device + whole iterations", 0, 1)):
         L.check(lib.trx_set_build_preset(b"medium_build"))
         L.check(lib.trx_set_build_device(dev))

@@ -1160,22 +1160,63 @@ struct Reinserter {
         const size_t n = nodes.size();
         threads = std::max(1, std::min(threads, 64));
         if (n < (size_t)1 << 16) threads = 1;
-        // every node but the root and its children, in index order
+        // every node but the root and its children is eligible
         std::vector<size_t> first(threads + 1, 0);
         auto range = [&](int t) { return std::make_pair(1 + (n - 1) * (size_t)t / threads, 1 + (n - 1) * (size_t)(t + 1) / threads); };
-        on_threads(threads, [&](int t) {
+        size_t take;
+        if (threads == 1) {
             size_t c = 0;
-            for (size_t i = range(t).first; i < range(t).second; i++) c += parent[i] != 0;
-            first[t + 1] = c;
-        });
-        for (int t = 0; t < threads; t++) first[t + 1] += first[t];
-        cand.resize(first[threads]);
-        on_threads(threads, [&](int t) {
-            size_t w = first[t];
-            for (size_t i = range(t).first; i < range(t).second; i++)
+            for (size_t i = 1; i < n; i++) c += parent[i] != 0;
+            cand.resize(c);
+            size_t w = 0;
+            for (size_t i = 1; i < n; i++)
                 if (parent[i] != 0) cand[w++] = Cand(half_area(nodes[i].box), (uint32_t)i);
-        });
-        const size_t take = std::min(cand.size(), (size_t)std::max(1.0, (double)n * batch_ratio));
+            take = std::min(cand.size(), (size_t)std::max(1.0, (double)n * batch_ratio));
+        } else {
+            // On every core: a histogram of the areas' upper sixteen bits (an area is a non-negative float: its bits order
+            // like its value) finds the bin the take-th largest falls into; only the nodes from that bin up are gathered,
+            // and the serial selection below works on a few per cent of the array instead of all of it.
+            constexpr size_t kHist = (size_t)1 << 16;
+            std::vector<uint32_t> hist((size_t)threads * kHist, 0u);
+            on_threads(threads, [&](int t) {
+                uint32_t *h = &hist[(size_t)t * kHist];
+                size_t c = 0;
+                for (size_t i = range(t).first; i < range(t).second; i++) {
+                    if (parent[i] == 0) continue;
+                    const float a = half_area(nodes[i].box);
+                    uint32_t bits;
+                    std::memcpy(&bits, &a, 4);
+                    h[bits >> 16]++;
+                    c++;
+                }
+                first[t + 1] = c;
+            });
+            size_t eligible = 0;
+            for (int t = 0; t < threads; t++) eligible += first[t + 1];
+            take = std::min(eligible, (size_t)std::max(1.0, (double)n * batch_ratio));
+            size_t above = 0, bin = kHist; // `above` nodes lie in bins >= bin
+            while (bin > 0 && above < take) {
+                bin--;
+                for (int t = 0; t < threads; t++) above += hist[(size_t)t * kHist + bin];
+            }
+            for (int t = 0; t < threads; t++) {
+                size_t c = 0;
+                for (size_t b = bin; b < kHist; b++) c += hist[(size_t)t * kHist + b];
+                first[t + 1] = first[t] + c;
+            }
+            first[0] = 0;
+            cand.resize(first[threads]);
+            on_threads(threads, [&](int t) {
+                size_t w = first[t];
+                for (size_t i = range(t).first; i < range(t).second; i++) {
+                    if (parent[i] == 0) continue;
+                    const float a = half_area(nodes[i].box);
+                    uint32_t bits;
+                    std::memcpy(&bits, &a, 4);
+                    if ((bits >> 16) >= bin) cand[w++] = Cand(a, (uint32_t)i);
+                }
+            });
+        }
         if (take < cand.size()) std::nth_element(cand.begin(), cand.begin() + take, cand.end(), larger);
         if (threads == 1 || take < (size_t)1 << 16) {
             std::sort(cand.begin(), cand.begin() + take, larger);
