@@ -488,261 +488,265 @@ def main():
     out = None
     legs = {}
     if rank == 0 and world == 1 and args.sim_shards == 1 and not args.no_legs:
-        s0 = streams[0]
-        # (a) the reference's protocol: 3 passes x [3 discarded + 20 frames], hipEvent pair per frame, min and mean
-        passes = [scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
-        legs["reference_protocol"] = {
-            "passes": 3, "discarded_frames": 3, "frames": 20,
-            "min_ms": round(sum(p[0] for p in passes) / 3, 4), "mean_ms": round(sum(p[1] for p in passes) / 3, 4),
-            "mrays_at_min": round(n_rays_total / (sum(p[0] for p in passes) / 3) / 1e3, 1),
-        }
-        # (b) tile-order feedback off: what the first frame of a geometry (or a caller that never repeats one) gets
-        lib.trx_set_kernel_variant(VARIANT_COLD)
-        cmin, cmean = scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20)
-        lib.trx_set_kernel_variant(0)
-        legs["cold_order_ms"] = {"min": round(cmin, 4), "mean": round(cmean, 4)}
-        # (c) the literal HLSL arithmetic (per-node IEEE divides, tt <= t)
-        hmin, hmean = scene.bench_primary(view, w, h, sem=0, warmup=3, frames=20)
-        legs["sem_hlsl_ms"] = {"min": round(hmin, 4), "mean": round(hmean, 4)}
-        # (c') every frame runs as the first frame of its image geometry (natural order while its tiles are measured; the
-        #      probe pass that once predicted an order here was measured and removed)
-        lib.trx_set_kernel_variant(VARIANT_CUT)
-        fmin, fmean = scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20)
-        lib.trx_set_kernel_variant(0)
-        legs["first_frame_ms"] = {"min": round(fmin, 4), "mean": round(fmean, 4)}
-        # (c") the AO pass over this frame's primary hits (the reference's second ray per pixel, rt_gpu_software.hlsl:105-128):
-        #      one cosine-weighted ray per primary hit, a new noise seed every pass; default stream, hipEvents per launch
-        d_prim = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
-        d_ao = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
-        scene.trace_primary_dev(view, w, h, d_prim.data_ptr(), sem=args.sem)
-        torch.cuda.synchronize()
-        n_ao = int(((d_prim & 0xffffffff) != 0x7f800000).sum().item())   # low word = t bits; +inf = miss
-        ao_ev = []
-        for k in range(3 + 12):
-            a, b = ev(), ev()
-            a.record()
-            scene.trace_ao_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=k, ao_eps=0.01)
-            b.record()
-            ao_ev.append((a, b))
-        torch.cuda.synchronize()
-        at = [a.elapsed_time(b) for a, b in ao_ev][3:]
-        legs["ao_pass_ms"] = {"rays": n_ao, "frames": len(at), "min": round(min(at), 4), "mean": round(sum(at) / len(at), 4),
-                              "mrays_at_mean": round(n_ao / (sum(at) / len(at)) / 1e3, 1)}
-
-        def timed(fn, reps=12, skip=3):
-            """hipEvent time of fn(i) on the default stream, one call in flight: (min, mean) over `reps` after `skip`."""
-            ts = []
-            for i in range(reps + skip):
+        # (a leg that fails - a scene that does not fit, a build stage that errors - must not take the headline with it)
+        try:
+            s0 = streams[0]
+            # (a) the reference's protocol: 3 passes x [3 discarded + 20 frames], hipEvent pair per frame, min and mean
+            passes = [scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
+            legs["reference_protocol"] = {
+                "passes": 3, "discarded_frames": 3, "frames": 20,
+                "min_ms": round(sum(p[0] for p in passes) / 3, 4), "mean_ms": round(sum(p[1] for p in passes) / 3, 4),
+                "mrays_at_min": round(n_rays_total / (sum(p[0] for p in passes) / 3) / 1e3, 1),
+            }
+            # (b) tile-order feedback off: what the first frame of a geometry (or a caller that never repeats one) gets
+            lib.trx_set_kernel_variant(VARIANT_COLD)
+            cmin, cmean = scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20)
+            lib.trx_set_kernel_variant(0)
+            legs["cold_order_ms"] = {"min": round(cmin, 4), "mean": round(cmean, 4)}
+            # (c) the literal HLSL arithmetic (per-node IEEE divides, tt <= t)
+            hmin, hmean = scene.bench_primary(view, w, h, sem=0, warmup=3, frames=20)
+            legs["sem_hlsl_ms"] = {"min": round(hmin, 4), "mean": round(hmean, 4)}
+            # (c') every frame runs as the first frame of its image geometry (natural order while its tiles are measured; the
+            #      probe pass that once predicted an order here was measured and removed)
+            lib.trx_set_kernel_variant(VARIANT_CUT)
+            fmin, fmean = scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20)
+            lib.trx_set_kernel_variant(0)
+            legs["first_frame_ms"] = {"min": round(fmin, 4), "mean": round(fmean, 4)}
+            # (c") the AO pass over this frame's primary hits (the reference's second ray per pixel, rt_gpu_software.hlsl:105-128):
+            #      one cosine-weighted ray per primary hit, a new noise seed every pass; default stream, hipEvents per launch
+            d_prim = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
+            d_ao = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
+            scene.trace_primary_dev(view, w, h, d_prim.data_ptr(), sem=args.sem)
+            torch.cuda.synchronize()
+            n_ao = int(((d_prim & 0xffffffff) != 0x7f800000).sum().item())   # low word = t bits; +inf = miss
+            ao_ev = []
+            for k in range(3 + 12):
                 a, b = ev(), ev()
                 a.record()
-                fn(i)
+                scene.trace_ao_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=k, ao_eps=0.01)
                 b.record()
-                torch.cuda.synchronize()
-                if i >= skip:
-                    ts.append(a.elapsed_time(b))
-            return min(ts), sum(ts) / len(ts)
-        # (c"') BASELINE.json's "4 spp" = AO frames with seeds 0..3 (src/rt_cpu/rt_cpu.rs:95-97): ONE launch
-        #       (trx_trace_ao_batch_dev) - the four passes share one drain
-        d_ao4 = torch.empty(4 * n_rays_total, dtype=torch.int64, device="cuda")
-        a4 = timed(lambda i: scene.trace_ao_batch_dev(view, w, h, d_prim.data_ptr(), d_ao4.data_ptr(), n_rays_total, 4,
-                                                      sem=args.sem, frame0=4 * i, ao_eps=0.01))
-        legs["ao_4spp_ms"] = {"rays": 4 * n_ao, "launches": 1, "min": round(a4[0], 4), "mean": round(a4[1], 4),
-                              "mrays_at_mean": round(4 * n_ao / a4[1] / 1e3, 1)}
-        # (c"") the reference-style frame, device-resident: primary + AO as two launches back to back on one stream, and as
-        #       ONE launch (trx_trace_frame_dev: the reference's single dispatch, a lane whose primary ray hits goes on as
-        #       the pixel's AO ray) - same records either way
-        f2 = timed(lambda i: (scene.trace_primary_dev(view, w, h, d_prim.data_ptr(), sem=args.sem),
-                              scene.trace_ao_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=i % 4, ao_eps=0.01)))
-        f1 = timed(lambda i: scene.trace_frame_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=i % 4, ao_eps=0.01))
-        legs["frame_primary_ao_ms"] = {"two_launches": {"min": round(f2[0], 4), "mean": round(f2[1], 4)},
-                                       "one_launch": {"min": round(f1[0], 4), "mean": round(f1[1], 4)}}
-        del d_prim, d_ao, d_ao4
-        # (c5) BASELINE.json configs[3] itself: the hairball-class stand-in, primary frame, one AO pass, and the 4 spp in one launch
-        if args.scene == "bistro" and args.tris == 0:
-            hv, hc = T.gen_scene("hairball", 0, 1)
-            hflat = T.flat_build(hv, hc, use_tlas=False, threads=threads, preset=args.preset)
-            hscene = T.Scene(hflat, device=local_rank)
-            he, hl, hf = T.scene_camera("hairball")
-            hview = T.view_from_camera(he, hl, hf, w, h)
-            hp = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
-            ha = torch.empty(4 * n_rays_total, dtype=torch.int64, device="cuda")
-            hprim = [hscene.bench_primary(hview, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(2)]
-            hscene.trace_primary_dev(hview, w, h, hp.data_ptr(), sem=args.sem)
+                ao_ev.append((a, b))
             torch.cuda.synchronize()
-            h_ao = int(((hp & 0xffffffff) != 0x7f800000).sum().item())
-            h1 = timed(lambda i: hscene.trace_ao_dev(hview, w, h, hp.data_ptr(), ha.data_ptr(), sem=args.sem, frame=i % 4, ao_eps=0.01))
-            h4 = timed(lambda i: hscene.trace_ao_batch_dev(hview, w, h, hp.data_ptr(), ha.data_ptr(), n_rays_total, 4, sem=args.sem,
-                                                           frame0=4 * i, ao_eps=0.01))
-            legs["hairball_4spp"] = {
-                "scene": "hairball", "tris": int(hflat.n_tris), "ao_rays_per_frame": h_ao,
-                "primary_ms": round(sum(q[1] for q in hprim) / 2, 4),
-                "ao_pass_ms": {"min": round(h1[0], 4), "mean": round(h1[1], 4), "mrays_at_mean": round(h_ao / h1[1] / 1e3, 1)},
-                "ao_4spp_one_launch_ms": {"min": round(h4[0], 4), "mean": round(h4[1], 4),
-                                          "mrays_at_mean": round(4 * h_ao / h4[1] / 1e3, 1)},
-            }
-            hscene.close()
-            del hv, hc, hflat, hp, ha
-        # (d) frames overlapped on 4 streams (independent frames; the tail of one overlaps the next)
-        ps = [torch.cuda.Stream() for _ in range(4)]
-        pbuf = [torch.empty(n_rays_total, dtype=torch.int64, device="cuda") for _ in ps]
+            at = [a.elapsed_time(b) for a, b in ao_ev][3:]
+            legs["ao_pass_ms"] = {"rays": n_ao, "frames": len(at), "min": round(min(at), 4), "mean": round(sum(at) / len(at), 4),
+                                  "mrays_at_mean": round(n_ao / (sum(at) / len(at)) / 1e3, 1)}
 
-        def pipelined(n):
-            for k in range(n):
-                with torch.cuda.stream(ps[k % 4]):
-                    scene.trace_primary_dev(view, w, h, pbuf[k % 4].data_ptr(), sem=args.sem, stream=ps[k % 4].cuda_stream)
-        pipelined(16)
-        torch.cuda.synchronize()
-        tp = time.perf_counter()
-        pipelined(200)
-        torch.cuda.synchronize()
-        legs["pipelined_mrays"] = round(n_rays_total * 200 / (time.perf_counter() - tp) / 1e6, 1)
-        legs["pipelined_frames_in_flight"] = 4
-        # (e) measured HBM ceiling: device-to-device copy of 2 GiB (1 GiB read + 1 GiB written per pass)
-        n64 = (1 << 30) // 8
-        src = torch.empty(n64, dtype=torch.int64, device="cuda").fill_(1)
-        dst = torch.empty_like(src)
-        for _ in range(3):
-            dst.copy_(src)
-        e0, e1 = ev(), ev()
-        e0.record()
-        for _ in range(10):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        legs["hbm_copy_gbs"] = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-        del src, dst
-        # (h) a camera that moves: every frame a new view (the eye and its target advance 5 cm along the street per frame),
-        #     the tile order learnt from the PREVIOUS view; what a renderer with temporal coherence gets, between the
-        #     static-camera figure and the cold one
-        mv = []
-        mbuf = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
-        for f in range(48):
-            off = 0.05 * f
-            v = T.view_from_camera((eye[0] + off, eye[1], eye[2]), (look[0] + off, look[1], look[2]), fov, w, h)
-            a, b = ev(), ev()
-            a.record()
-            scene.trace_primary_dev(v, w, h, mbuf.data_ptr(), sem=args.sem)
-            b.record()
-            mv.append((a, b))
-        torch.cuda.synchronize()
-        mt = [a.elapsed_time(b) for a, b in mv][8:]
-        legs["moving_camera_ms"] = {"step_m": 0.05, "frames": len(mt), "min": round(min(mt), 4), "mean": round(sum(mt) / len(mt), 4)}
-        del mbuf
-        # (g) second headline row: the denser bistro-class stand-in built to the reference's PROFILE_RT legend
-        #     (about 30 node visits / 15 triangle tests per primary ray, rt_gpu_software.hlsl:95,102), same protocol
-        if args.scene == "bistro" and args.tris == 0:
-            dv, dc = T.gen_scene("bistro_dense", 0, 1)
-            dflat = T.flat_build(dv, dc, use_tlas=False, threads=threads, preset=args.preset)
-            dscene = T.Scene(dflat, device=local_rank)
-            dst = dscene.count_primary(view, w, h, sem=args.sem)
-            dp = [dscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
-            legs["dense_scene"] = {
-                "scene": "bistro_dense", "tris": int(dflat.n_tris), "nodes_per_ray": round(dst.n_node / dst.n_rays, 2),
-                "tris_per_ray": round(dst.n_tri / dst.n_rays, 2),
-                "min_ms": round(sum(p[0] for p in dp) / 3, 4), "mean_ms": round(sum(p[1] for p in dp) / 3, 4),
-                "mrays_at_mean": round(n_rays_total / (sum(p[1] for p in dp) / 3) / 1e3, 1),
-            }
-            dscene.close()
-            del dv, dc, dflat
-        # (i) the same frame over a tree from the ploc_cwbvh pipeline with the reference's command-line defaults for
-        #     BvhBuildParams (src/main.rs:85-124,571-585: search distance 14, depth threshold 2, 64-bit codes, reinsertion
-        #     0.15, 3 primitives per leaf) - obvhs' own values for the preset name are not in the reference tree, so the
-        #     headline runs this library's medium_build; this leg says what the other builder's tree costs to traverse
-        if args.scene == "bistro" and args.tris == 0:
-            tp0 = time.time()
-            pflat = T.flat_build_params(verts, counts, T.build_params(), use_tlas=False, threads=threads)
-            pbuild = time.time() - tp0
-            pscene = T.Scene(pflat, device=local_rank)
-            pst = pscene.count_primary(view, w, h, sem=args.sem)
-            pp = [pscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
-            legs["ploc_pipeline"] = {
-                "params": "reference command-line defaults (ploc_search_distance 14, search_depth_threshold 2, "
-                          "sort_precision 64, reinsertion_batch_ratio 0.15, max_prims_per_leaf 3)",
-                "build_seconds": round(pbuild, 2), "nodes": int(pflat.n_nodes),
-                "nodes_per_ray": round(pst.n_node / pst.n_rays, 2), "tris_per_ray": round(pst.n_tri / pst.n_rays, 2),
-                "min_ms": round(sum(q[0] for q in pp) / 3, 4), "mean_ms": round(sum(q[1] for q in pp) / 3, 4),
-                "mrays_at_mean": round(n_rays_total / (sum(q[1] for q in pp) / 3) / 1e3, 1),
-            }
-            pscene.close()
-            del pflat
-            # (i') the same pipeline with its GPU stages (round 5): Morton sort + PLOC rounds, and the reinsertion pass with one
-            #      batch per iteration - candidates chosen (area keys + radix sort) and searched as kernels, one thread per
-            #      search, moves applied on the host - byte-identical to the same pass searched on the host cores
-            #      (tests/test_gpu_builder.py); collapse and encoding on the host
-            try:
-                T.load().trx_set_build_device(local_rank)
-                T.load().trx_set_build_reinsertion_batches(1)
-                T.load().trx_set_build_reinsertion(0.02, 8)   # (the ratio comes from the build parameters: 0.15; 8 iterations)
-                tg0 = time.time()
-                gflat = T.flat_build_params(verts, counts, T.build_params(), use_tlas=False, threads=threads)
-                gbuild = time.time() - tg0
-            finally:
-                T.load().trx_set_build_device(-1)
-                T.load().trx_set_build_reinsertion_batches(0)
-                T.load().trx_set_build_preset(args.preset.encode())
-            gscene = T.Scene(gflat, device=local_rank)
-            gst = gscene.count_primary(view, w, h, sem=args.sem)
-            gp = [gscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
-            legs["ploc_pipeline_gpu_stages"] = {
-                "params": "the same build parameters; reinsertion in 8 whole-iteration batches (ratio 0.15), BVH2 stage and "
-                          "reinsertion searches on the GPU",
-                "build_seconds": round(gbuild, 2), "nodes": int(gflat.n_nodes),
-                "nodes_per_ray": round(gst.n_node / gst.n_rays, 2), "tris_per_ray": round(gst.n_tri / gst.n_rays, 2),
-                "min_ms": round(sum(q[0] for q in gp) / 3, 4), "mean_ms": round(sum(q[1] for q in gp) / 3, 4),
-                "mrays_at_mean": round(n_rays_total / (sum(q[1] for q in gp) / 3) / 1e3, 1),
-            }
-            gscene.close()
-            del gflat
-        # (j) the timed region WITHOUT the wake frames: the GPU idles for a second (as it does while a host builds a scene),
-        #     then the W warm-up steps and K timed steps run straight away, on clocks that are still coming up - what the
-        #     round-3 protocol measured (profiles/r04_clock_ramp.log); one event pair around the K launches, like `value`
-        if one_pair:
+            def timed(fn, reps=12, skip=3):
+                """hipEvent time of fn(i) on the default stream, one call in flight: (min, mean) over `reps` after `skip`."""
+                ts = []
+                for i in range(reps + skip):
+                    a, b = ev(), ev()
+                    a.record()
+                    fn(i)
+                    b.record()
+                    torch.cuda.synchronize()
+                    if i >= skip:
+                        ts.append(a.elapsed_time(b))
+                return min(ts), sum(ts) / len(ts)
+            # (c"') BASELINE.json's "4 spp" = AO frames with seeds 0..3 (src/rt_cpu/rt_cpu.rs:95-97): ONE launch
+            #       (trx_trace_ao_batch_dev) - the four passes share one drain
+            d_ao4 = torch.empty(4 * n_rays_total, dtype=torch.int64, device="cuda")
+            a4 = timed(lambda i: scene.trace_ao_batch_dev(view, w, h, d_prim.data_ptr(), d_ao4.data_ptr(), n_rays_total, 4,
+                                                          sem=args.sem, frame0=4 * i, ao_eps=0.01))
+            legs["ao_4spp_ms"] = {"rays": 4 * n_ao, "launches": 1, "min": round(a4[0], 4), "mean": round(a4[1], 4),
+                                  "mrays_at_mean": round(4 * n_ao / a4[1] / 1e3, 1)}
+            # (c"") the reference-style frame, device-resident: primary + AO as two launches back to back on one stream, and as
+            #       ONE launch (trx_trace_frame_dev: the reference's single dispatch, a lane whose primary ray hits goes on as
+            #       the pixel's AO ray) - same records either way
+            f2 = timed(lambda i: (scene.trace_primary_dev(view, w, h, d_prim.data_ptr(), sem=args.sem),
+                                  scene.trace_ao_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=i % 4, ao_eps=0.01)))
+            f1 = timed(lambda i: scene.trace_frame_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=i % 4, ao_eps=0.01))
+            legs["frame_primary_ao_ms"] = {"two_launches": {"min": round(f2[0], 4), "mean": round(f2[1], 4)},
+                                           "one_launch": {"min": round(f1[0], 4), "mean": round(f1[1], 4)}}
+            del d_prim, d_ao, d_ao4
+            # (c5) BASELINE.json configs[3] itself: the hairball-class stand-in, primary frame, one AO pass, and the 4 spp in one launch
+            if args.scene == "bistro" and args.tris == 0:
+                hv, hc = T.gen_scene("hairball", 0, 1)
+                hflat = T.flat_build(hv, hc, use_tlas=False, threads=threads, preset=args.preset)
+                hscene = T.Scene(hflat, device=local_rank)
+                he, hl, hf = T.scene_camera("hairball")
+                hview = T.view_from_camera(he, hl, hf, w, h)
+                hp = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
+                ha = torch.empty(4 * n_rays_total, dtype=torch.int64, device="cuda")
+                hprim = [hscene.bench_primary(hview, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(2)]
+                hscene.trace_primary_dev(hview, w, h, hp.data_ptr(), sem=args.sem)
+                torch.cuda.synchronize()
+                h_ao = int(((hp & 0xffffffff) != 0x7f800000).sum().item())
+                h1 = timed(lambda i: hscene.trace_ao_dev(hview, w, h, hp.data_ptr(), ha.data_ptr(), sem=args.sem, frame=i % 4, ao_eps=0.01))
+                h4 = timed(lambda i: hscene.trace_ao_batch_dev(hview, w, h, hp.data_ptr(), ha.data_ptr(), n_rays_total, 4, sem=args.sem,
+                                                               frame0=4 * i, ao_eps=0.01))
+                legs["hairball_4spp"] = {
+                    "scene": "hairball", "tris": int(hflat.n_tris), "ao_rays_per_frame": h_ao,
+                    "primary_ms": round(sum(q[1] for q in hprim) / 2, 4),
+                    "ao_pass_ms": {"min": round(h1[0], 4), "mean": round(h1[1], 4), "mrays_at_mean": round(h_ao / h1[1] / 1e3, 1)},
+                    "ao_4spp_one_launch_ms": {"min": round(h4[0], 4), "mean": round(h4[1], 4),
+                                              "mrays_at_mean": round(4 * h_ao / h4[1] / 1e3, 1)},
+                }
+                hscene.close()
+                del hv, hc, hflat, hp, ha
+            # (d) frames overlapped on 4 streams (independent frames; the tail of one overlaps the next)
+            ps = [torch.cuda.Stream() for _ in range(4)]
+            pbuf = [torch.empty(n_rays_total, dtype=torch.int64, device="cuda") for _ in ps]
+
+            def pipelined(n):
+                for k in range(n):
+                    with torch.cuda.stream(ps[k % 4]):
+                        scene.trace_primary_dev(view, w, h, pbuf[k % 4].data_ptr(), sem=args.sem, stream=ps[k % 4].cuda_stream)
+            pipelined(16)
             torch.cuda.synchronize()
-            time.sleep(1.0)
-            run_frames(args.warmup, None)
-            n0, n1 = ev(), ev()
-            n0.record(streams[0])
-            run_frames(args.steps, None)
-            n1.record(streams[0])
+            tp = time.perf_counter()
+            pipelined(200)
             torch.cuda.synchronize()
-            nw_ms = n0.elapsed_time(n1) / args.steps
-            legs["no_wake"] = {"idle_s": 1.0, "warmup": args.warmup, "steps": args.steps, "kernel_ms_mean": round(nw_ms, 4),
-                               "mrays": round(n_rays_total / (nw_ms * 1e-3) / 1e6, 1)}
-        # (k) Traversable::traverse called the way the reference's CPU loop calls it (src/rt_cpu/rt_cpu.rs:35-57): 16 host
-        #     threads, ONE ray per call, every call blocking for its RayHit.  Concurrent callers share launches (the
-        #     per-scene combiner behind trx_traverse1); a caller still waits one GPU round trip per ray, so this is a latency
-        #     figure - threads / round trip - next to which trx_traverse_batch (the same rays in one call) is the throughput one
-        rng = np.random.default_rng(11)
-        n_t1 = 16 * 1500
-        px = rng.integers(0, n_rays_total, n_t1)
-        fx = (px % w + 0.5) / w * 2.0 - 1.0
-        fy = 1.0 - (px // w + 0.5) / h * 2.0
-        fwd = np.array(look, dtype=np.float64) - np.array(eye, dtype=np.float64)
-        fwd /= np.linalg.norm(fwd)
-        right = np.cross(fwd, [0.0, 1.0, 0.0])
-        right /= np.linalg.norm(right)
-        up = np.cross(right, fwd)
-        th = np.tan(np.radians(fov) / 2.0)
-        dirs = fwd[None, :] + (fx * th * w / h)[:, None] * right[None, :] + (fy * th)[:, None] * up[None, :]
-        dirs /= np.linalg.norm(dirs, axis=1)[:, None]
-        t1_rays = np.zeros(n_t1, dtype=T.RAY_DTYPE)
-        t1_rays["origin"] = np.array(eye, dtype=np.float32)
-        t1_rays["direction"] = dirs.astype(np.float32)
-        t1_rays["tmax"] = 3.4028234663852886e38
-        scene.traverse_threads(t1_rays[:512], threads=16, sem=args.sem)           # (warms the launch slots)
-        t1_hits, t1_s, t1_launches = scene.traverse_threads(t1_rays, threads=16, sem=args.sem)
-        tb_hits, tb_ms = scene.traverse_batch(t1_rays, sem=args.sem)
-        legs["traverse1_threads"] = {
-            "threads": 16, "rays": n_t1, "mrays": round(n_t1 / t1_s / 1e6, 4), "launches": t1_launches,
-            "rays_per_launch": round(n_t1 / max(t1_launches, 1), 1), "us_per_launch": round(t1_s / max(t1_launches, 1) * 1e6, 1),
-            "equals_traverse_batch": bool((t1_hits == tb_hits).all()),
-            "traverse_batch_kernel_mrays": round(n_t1 / (tb_ms * 1e-3) / 1e6, 1),
-            "note": "one blocking trx_traverse1 call per ray from 16 host threads; rate = callers in flight / GPU round trip",
-        }
-        # (f) compulsory footprint: distinct nodes / triangles one frame touches
-        fn, ft = scene.footprint(view, w, h, sem=args.sem)
-        legs["footprint"] = {"nodes": fn, "tris": ft, "bytes": NODE_BYTES * fn + TRI_BYTES * ft + HIT_BYTES * n_rays_total}
-        del s0
+            legs["pipelined_mrays"] = round(n_rays_total * 200 / (time.perf_counter() - tp) / 1e6, 1)
+            legs["pipelined_frames_in_flight"] = 4
+            # (e) measured HBM ceiling: device-to-device copy of 2 GiB (1 GiB read + 1 GiB written per pass)
+            n64 = (1 << 30) // 8
+            src = torch.empty(n64, dtype=torch.int64, device="cuda").fill_(1)
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            legs["hbm_copy_gbs"] = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del src, dst
+            # (h) a camera that moves: every frame a new view (the eye and its target advance 5 cm along the street per frame),
+            #     the tile order learnt from the PREVIOUS view; what a renderer with temporal coherence gets, between the
+            #     static-camera figure and the cold one
+            mv = []
+            mbuf = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
+            for f in range(48):
+                off = 0.05 * f
+                v = T.view_from_camera((eye[0] + off, eye[1], eye[2]), (look[0] + off, look[1], look[2]), fov, w, h)
+                a, b = ev(), ev()
+                a.record()
+                scene.trace_primary_dev(v, w, h, mbuf.data_ptr(), sem=args.sem)
+                b.record()
+                mv.append((a, b))
+            torch.cuda.synchronize()
+            mt = [a.elapsed_time(b) for a, b in mv][8:]
+            legs["moving_camera_ms"] = {"step_m": 0.05, "frames": len(mt), "min": round(min(mt), 4), "mean": round(sum(mt) / len(mt), 4)}
+            del mbuf
+            # (g) second headline row: the denser bistro-class stand-in built to the reference's PROFILE_RT legend
+            #     (about 30 node visits / 15 triangle tests per primary ray, rt_gpu_software.hlsl:95,102), same protocol
+            if args.scene == "bistro" and args.tris == 0:
+                dv, dc = T.gen_scene("bistro_dense", 0, 1)
+                dflat = T.flat_build(dv, dc, use_tlas=False, threads=threads, preset=args.preset)
+                dscene = T.Scene(dflat, device=local_rank)
+                dst = dscene.count_primary(view, w, h, sem=args.sem)
+                dp = [dscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
+                legs["dense_scene"] = {
+                    "scene": "bistro_dense", "tris": int(dflat.n_tris), "nodes_per_ray": round(dst.n_node / dst.n_rays, 2),
+                    "tris_per_ray": round(dst.n_tri / dst.n_rays, 2),
+                    "min_ms": round(sum(p[0] for p in dp) / 3, 4), "mean_ms": round(sum(p[1] for p in dp) / 3, 4),
+                    "mrays_at_mean": round(n_rays_total / (sum(p[1] for p in dp) / 3) / 1e3, 1),
+                }
+                dscene.close()
+                del dv, dc, dflat
+            # (i) the same frame over a tree from the ploc_cwbvh pipeline with the reference's command-line defaults for
+            #     BvhBuildParams (src/main.rs:85-124,571-585: search distance 14, depth threshold 2, 64-bit codes, reinsertion
+            #     0.15, 3 primitives per leaf) - obvhs' own values for the preset name are not in the reference tree, so the
+            #     headline runs this library's medium_build; this leg says what the other builder's tree costs to traverse
+            if args.scene == "bistro" and args.tris == 0:
+                tp0 = time.time()
+                pflat = T.flat_build_params(verts, counts, T.build_params(), use_tlas=False, threads=threads)
+                pbuild = time.time() - tp0
+                pscene = T.Scene(pflat, device=local_rank)
+                pst = pscene.count_primary(view, w, h, sem=args.sem)
+                pp = [pscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
+                legs["ploc_pipeline"] = {
+                    "params": "reference command-line defaults (ploc_search_distance 14, search_depth_threshold 2, "
+                              "sort_precision 64, reinsertion_batch_ratio 0.15, max_prims_per_leaf 3)",
+                    "build_seconds": round(pbuild, 2), "nodes": int(pflat.n_nodes),
+                    "nodes_per_ray": round(pst.n_node / pst.n_rays, 2), "tris_per_ray": round(pst.n_tri / pst.n_rays, 2),
+                    "min_ms": round(sum(q[0] for q in pp) / 3, 4), "mean_ms": round(sum(q[1] for q in pp) / 3, 4),
+                    "mrays_at_mean": round(n_rays_total / (sum(q[1] for q in pp) / 3) / 1e3, 1),
+                }
+                pscene.close()
+                del pflat
+                # (i') the same pipeline with its GPU stages (round 5): Morton sort + PLOC rounds, and the reinsertion pass with one
+                #      batch per iteration - candidates chosen (area keys + radix sort) and searched as kernels, one thread per
+                #      search, moves applied on the host - and the BVH2 -> CWBVH collapse + node encoding as kernels; every stage
+                #      byte-identical to its host twin (tests/test_gpu_builder.py)
+                try:
+                    T.load().trx_set_build_device(local_rank)
+                    T.load().trx_set_build_reinsertion_batches(1)
+                    T.load().trx_set_build_reinsertion(0.02, 8)   # (the ratio comes from the build parameters: 0.15; 8 iterations)
+                    tg0 = time.time()
+                    gflat = T.flat_build_params(verts, counts, T.build_params(), use_tlas=False, threads=threads)
+                    gbuild = time.time() - tg0
+                finally:
+                    T.load().trx_set_build_device(-1)
+                    T.load().trx_set_build_reinsertion_batches(0)
+                    T.load().trx_set_build_preset(args.preset.encode())
+                gscene = T.Scene(gflat, device=local_rank)
+                gst = gscene.count_primary(view, w, h, sem=args.sem)
+                gp = [gscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
+                legs["ploc_pipeline_gpu_stages"] = {
+                    "params": "the same build parameters; reinsertion in 8 whole-iteration batches (ratio 0.15); BVH2 stage, "
+                              "reinsertion searches and collapse + encoding on the GPU",
+                    "build_seconds": round(gbuild, 2), "nodes": int(gflat.n_nodes),
+                    "nodes_per_ray": round(gst.n_node / gst.n_rays, 2), "tris_per_ray": round(gst.n_tri / gst.n_rays, 2),
+                    "min_ms": round(sum(q[0] for q in gp) / 3, 4), "mean_ms": round(sum(q[1] for q in gp) / 3, 4),
+                    "mrays_at_mean": round(n_rays_total / (sum(q[1] for q in gp) / 3) / 1e3, 1),
+                }
+                gscene.close()
+                del gflat
+            # (j) the timed region WITHOUT the wake frames: the GPU idles for a second (as it does while a host builds a scene),
+            #     then the W warm-up steps and K timed steps run straight away, on clocks that are still coming up - what the
+            #     round-3 protocol measured (profiles/r04_clock_ramp.log); one event pair around the K launches, like `value`
+            if one_pair:
+                torch.cuda.synchronize()
+                time.sleep(1.0)
+                run_frames(args.warmup, None)
+                n0, n1 = ev(), ev()
+                n0.record(streams[0])
+                run_frames(args.steps, None)
+                n1.record(streams[0])
+                torch.cuda.synchronize()
+                nw_ms = n0.elapsed_time(n1) / args.steps
+                legs["no_wake"] = {"idle_s": 1.0, "warmup": args.warmup, "steps": args.steps, "kernel_ms_mean": round(nw_ms, 4),
+                                   "mrays": round(n_rays_total / (nw_ms * 1e-3) / 1e6, 1)}
+            # (k) Traversable::traverse called the way the reference's CPU loop calls it (src/rt_cpu/rt_cpu.rs:35-57): 16 host
+            #     threads, ONE ray per call, every call blocking for its RayHit.  Concurrent callers share launches (the
+            #     per-scene combiner behind trx_traverse1); a caller still waits one GPU round trip per ray, so this is a latency
+            #     figure - threads / round trip - next to which trx_traverse_batch (the same rays in one call) is the throughput one
+            rng = np.random.default_rng(11)
+            n_t1 = 16 * 1500
+            px = rng.integers(0, n_rays_total, n_t1)
+            fx = (px % w + 0.5) / w * 2.0 - 1.0
+            fy = 1.0 - (px // w + 0.5) / h * 2.0
+            fwd = np.array(look, dtype=np.float64) - np.array(eye, dtype=np.float64)
+            fwd /= np.linalg.norm(fwd)
+            right = np.cross(fwd, [0.0, 1.0, 0.0])
+            right /= np.linalg.norm(right)
+            up = np.cross(right, fwd)
+            th = np.tan(np.radians(fov) / 2.0)
+            dirs = fwd[None, :] + (fx * th * w / h)[:, None] * right[None, :] + (fy * th)[:, None] * up[None, :]
+            dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+            t1_rays = np.zeros(n_t1, dtype=T.RAY_DTYPE)
+            t1_rays["origin"] = np.array(eye, dtype=np.float32)
+            t1_rays["direction"] = dirs.astype(np.float32)
+            t1_rays["tmax"] = 3.4028234663852886e38
+            scene.traverse_threads(t1_rays[:512], threads=16, sem=args.sem)           # (warms the launch slots)
+            t1_hits, t1_s, t1_launches = scene.traverse_threads(t1_rays, threads=16, sem=args.sem)
+            tb_hits, tb_ms = scene.traverse_batch(t1_rays, sem=args.sem)
+            legs["traverse1_threads"] = {
+                "threads": 16, "rays": n_t1, "mrays": round(n_t1 / t1_s / 1e6, 4), "launches": t1_launches,
+                "rays_per_launch": round(n_t1 / max(t1_launches, 1), 1), "us_per_launch": round(t1_s / max(t1_launches, 1) * 1e6, 1),
+                "equals_traverse_batch": bool((t1_hits == tb_hits).all()),
+                "traverse_batch_kernel_mrays": round(n_t1 / (tb_ms * 1e-3) / 1e6, 1),
+                "note": "one blocking trx_traverse1 call per ray from 16 host threads; rate = callers in flight / GPU round trip",
+            }
+            # (f) compulsory footprint: distinct nodes / triangles one frame touches
+            fn, ft = scene.footprint(view, w, h, sem=args.sem)
+            legs["footprint"] = {"nodes": fn, "tris": ft, "bytes": NODE_BYTES * fn + TRI_BYTES * ft + HIT_BYTES * n_rays_total}
+            del s0
+        except Exception as e:  # noqa: BLE001
+            legs["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
 
     pmc, pmc_src, pmc_ms = None, None, None
     if rank == 0 and world == 1 and args.sim_shards == 1:
