@@ -1,6 +1,8 @@
 """The BVH2 stage of the ploc_cwbvh build on the GPU (csrc/ploc_gpu.cpp: Morton codes, radix sort, PLOC merge rounds as
 kernels) must return the very tree the host stage returns: same operations in the same order, so the flat buffers that
 come out of reinsertion / collapse / encoding are byte-identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -63,10 +65,13 @@ def test_device_ploc_full_size_bistro_traces_like_the_host_build(trx, orc):
 
 @pytest.mark.parametrize("name,n,tlas", [("bistro", 300000, False), ("hairball", 150000, False), ("soup", 60000, False)])
 def test_device_reinsertion_searches_equal_host_searches(trx, orc, name, n, tlas):
-    """Reinsertion with one batch per iteration (trx_set_build_reinsertion_batches): the candidates are chosen and searched
-    on the GPU (csrc/reinsert_gpu.cpp: area keys + radix sort, one thread per search) or on the host cores; the moves are
-    applied on the host in candidate order.  Same flat buffers, byte for byte - for the PLOC pipeline (its BVH2 stage on
-    the device as well) and for the binned-SAH presets.  And, independently of either builder: the device-built tree is a
+    """Reinsertion with one batch per iteration (trx_set_build_reinsertion_batches) on the host cores - searches on every
+    core, moves applied in candidate order - or entirely on the GPU with the tree resident there (csrc/reinsert_gpu.cpp:
+    area keys + radix sort, one thread per search, the moves the sequential pass would apply found as a fixed point of
+    atomic-min claims, checked for the one rule that needs the order, applied at once, boxes recomputed level by level).
+    Same flat buffers, byte for byte - for the PLOC pipeline (its BVH2 stage on the device as well) and for the binned-SAH
+    presets; also when some iterations are handed to the host in the middle of the pass (TRX_BUILD_HOST_APPLY), which is
+    what happens when the device finds a move only the sequential pass can judge.  And, independently of either builder: the device-built tree is a
     valid CWBVH over the scene's triangles (orc_validate) and a BVH-free brute-force query over the same rays finds the
     hits the oracle finds through it."""
     lib = trx.load()
@@ -84,6 +89,12 @@ def test_device_reinsertion_searches_equal_host_searches(trx, orc, name, n, tlas
                              else trx.flat_build(verts, counts))
             host, dev = built
             assert (host.nodes == dev.nodes).all() and (host.tri_source == dev.tri_source).all(), (name, pipeline)
+            os.environ["TRX_BUILD_HOST_APPLY"] = "0x2a"   # iterations 1, 3 and 5 go to the host and come back
+            try:
+                mixed = trx.flat_build_params(verts, counts, trx.build_params()) if pipeline == "ploc" else trx.flat_build(verts, counts)
+            finally:
+                del os.environ["TRX_BUILD_HOST_APPLY"]
+            assert (host.nodes == mixed.nodes).all() and (host.tri_source == mixed.tri_source).all(), (name, pipeline, "hand-over")
             osc = orc.Scene.from_flat(dev)
             assert osc.validate() == (0, "")
         # the one-batch pass really moved nodes: not the tree of the same pipeline without reinsertion

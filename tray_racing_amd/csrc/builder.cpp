@@ -960,6 +960,10 @@ struct Reinserter {
         auto now = []() { return std::chrono::steady_clock::now(); };
         auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
         double t_select = 0, t_search = 0, t_apply = 0;
+        int on_host = 0; // iterations of a device pass that the host had to apply
+        uint32_t max_rounds = 0;
+        const unsigned long long host_apply_mask = getenv("TRX_BUILD_HOST_APPLY") ? std::strtoull(getenv("TRX_BUILD_HOST_APPLY"), nullptr, 0) : 0ull;
+        if (dev && !reinsert_dev_upload(dev, nodes.data(), parent.data(), err)) throw std::runtime_error("GPU build stage: " + err);
         for (int it = 0; it < iterations; it++) {
             const auto t0 = now();
             size_t take;
@@ -975,15 +979,36 @@ struct Reinserter {
                 for (size_t k = 0; k < take; k++) ids[k] = cand[k].second;
             const auto t1 = now();
             t_select += secs(t0, t1);
+            uint32_t moved_now = 0;
             if (dev) {
-                if (!reinsert_dev_iteration(dev, nodes.data(), parent.data(), (uint32_t)take, ids.data(), found.data(), device_seconds, err))
+                // The tree stays on the device from the first iteration to the last: selection, searches, the choice of
+                // the moves that apply_batch would apply, the re-linking and the boxes are kernels (reinsert_gpu.cpp).
+                // An iteration the device cannot settle - a search that outgrew its fixed stack, or a move whose target
+                // has come to lie below the node it moves, which only the sequential pass resolves - comes here whole.
+                bool to_host = false;
+                uint32_t rounds = 0;
+                // (TRX_BUILD_HOST_APPLY = bit mask of iterations handed to the host whatever the device finds: how the tests
+                // reach the hand-over, which real trees almost never take)
+                const bool force = host_apply_mask & (1ull << std::min(it, 63));
+                if (!reinsert_dev_iteration_resident(dev, (uint32_t)take, ids.data(), found.data(), &moved_now, &to_host, device_seconds, err, force,
+                                                     &rounds))
                     throw std::runtime_error("GPU build stage: " + err);
-                Scratch scratch; // (a search that outgrew the device's fixed stack: here, same result)
-                for (size_t k = 0; k < take; k++)
-                    if (found[k] == kReinsertOverflow) {
-                        found[k] = kNone;
-                        (void)find(scratch, ids[k], found[k]);
-                    }
+                max_rounds = std::max(max_rounds, rounds);
+                const auto t2 = now();
+                t_search += secs(t1, t2);
+                if (to_host) {
+                    on_host++;
+                    if (!reinsert_dev_download(dev, nodes.data(), parent.data(), err)) throw std::runtime_error("GPU build stage: " + err);
+                    Scratch scratch;
+                    for (size_t k = 0; k < take; k++)
+                        if (found[k] == kReinsertOverflow) {
+                            found[k] = kNone;
+                            (void)find(scratch, ids[k], found[k]);
+                        }
+                    moved_now = apply_batch(cand, 0, take, found.data(), touched_at, (uint32_t)it + 1u, ids.data());
+                    if (!reinsert_dev_upload(dev, nodes.data(), parent.data(), err)) throw std::runtime_error("GPU build stage: " + err);
+                    t_apply += secs(t2, now());
+                }
             } else {
                 std::atomic<size_t> next{0};
                 on_threads(threads, [&](int) {
@@ -996,13 +1021,19 @@ struct Reinserter {
                             found[j] = to;
                         }
                 });
+                const auto t2 = now();
+                t_search += secs(t1, t2);
+                moved_now = apply_batch(cand, 0, take, found.data(), touched_at, (uint32_t)it + 1u, ids.data());
+                t_apply += secs(t2, now());
             }
-            const auto t2 = now();
-            t_search += secs(t1, t2);
-            const uint32_t moved_now = apply_batch(cand, 0, take, found.data(), touched_at, (uint32_t)it + 1u, ids.data());
-            t_apply += secs(t2, now());
             moved += moved_now;
             if (moved_now == 0) break;
+        }
+        if (dev) {
+            const auto t2 = now();
+            if (!reinsert_dev_download(dev, nodes.data(), parent.data(), err)) throw std::runtime_error("GPU build stage: " + err);
+            t_search += secs(t2, now());
+            if (verbose) fprintf(stderr, "[trx build] reinsertion: tree resident on the device, %d iteration(s) applied by the host, at most %u rounds to settle an iteration's moves\n", on_host, max_rounds);
         }
         const auto t3 = now();
         // (the device's collapse stage follows links and counts the primitives itself: no pre-order layout needed)
