@@ -669,7 +669,7 @@ def main():
                 del pflat
                 # (i') the same pipeline with its GPU stages (round 5): Morton sort + PLOC rounds, and the reinsertion pass with one
                 #      batch per iteration - candidates chosen (area keys + radix sort) and searched as kernels, one thread per
-                #      search, moves applied on the host - and the BVH2 -> CWBVH collapse + node encoding as kernels; every stage
+                #      search, the moves chosen and applied there too - and the BVH2 -> CWBVH collapse + node encoding as kernels; every stage
                 #      byte-identical to its host twin (tests/test_gpu_builder.py)
                 try:
                     T.load().trx_set_build_device(local_rank)
@@ -687,7 +687,7 @@ def main():
                 gp = [gscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
                 legs["ploc_pipeline_gpu_stages"] = {
                     "params": "the same build parameters; reinsertion in 8 whole-iteration batches (ratio 0.15); BVH2 stage, "
-                              "reinsertion searches and collapse + encoding on the GPU",
+                              "reinsertion (searches and moves) and collapse + encoding on the GPU",
                     "build_seconds": round(gbuild, 2), "nodes": int(gflat.n_nodes),
                     "nodes_per_ray": round(gst.n_node / gst.n_rays, 2), "tris_per_ray": round(gst.n_tri / gst.n_rays, 2),
                     "min_ms": round(sum(q[0] for q in gp) / 3, 4), "mean_ms": round(sum(q[1] for q in gp) / 3, 4),

@@ -556,8 +556,8 @@ void trx_build_params_default(trx_build_params *params); /* the reference's comm
 /* Which stages of subsequent builds run on a HIP device, as kernels (process-wide): device >= 0 = that device, -1 = the
  * host cores only (default).  Objects of at least 32,768 primitives take the device stages; the many small BLASes of a
  * TLAS scene stay on the host cores.  Stages: the BVH2 stage of trx_flat_build_params (Morton sort + PLOC merge rounds);
- * candidate selection and searches of the whole-iteration reinsertion pass (trx_set_build_reinsertion_batches(1); its
- * moves are applied on the host, in candidate order); and, for every builder, the BVH2 -> CWBVH stage (cost table,
+ * the whole-iteration reinsertion pass (trx_set_build_reinsertion_batches(1)) with the tree resident on the device -
+ * candidate selection, searches, the choice and application of the moves, the boxes; and, for every builder, the BVH2 -> CWBVH stage (cost table,
  * collapse, slot assignment, node encoding, primitive order).  Each device stage returns the very bytes its host twin
  * returns (same operations in the same order), so a build is the same build wherever it ran.  A device failure fails
  * the build (TRX_ERR_NO_DEVICE / TRX_ERR_OOM): nothing falls back silently. */

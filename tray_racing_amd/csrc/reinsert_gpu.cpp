@@ -1,11 +1,11 @@
-// reinsert_gpu.cpp — the searches of the BVH2 reinsertion pass (Meister & Bittner 2018, "Parallel Reinsertion for
+// reinsert_gpu.cpp — the BVH2 reinsertion pass with one batch per iteration (Meister & Bittner 2018, "Parallel Reinsertion for
 // Bounding Volume Hierarchy Optimization"; the pass obvhs runs after PLOC, knob reinsertion_batch_ratio behind the
 // reference's -r, src/main.rs:113-118) on the GPU: one thread per candidate, every candidate of a batch against the same
 // tree.  A search is a branch-and-bound walk of a few hundred dependent node reads - latency on a CPU core (2-3 s of a
 // reference-default build of a 3.9 M triangle scene on 16 cores), throughput here.  Same search order, same tie rule, same
 // binary32 operations without contraction as Reinserter::find in builder.cpp, so found[] is the host's found[], candidate
-// for candidate (tests/test_gpu_builder.py); the moves are then applied on the host, in candidate order, as they are
-// after host searches.
+// for candidate (tests/test_gpu_builder.py).  The moves are applied here too (further down): the tree stays on the device
+// from the first iteration to the last.
 #include "reinsert_gpu.h"
 
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-// reinsert_gpu.h — the searches of the BVH2 reinsertion pass on a HIP device (reinsert_gpu.cpp), called by builder.cpp.
+// reinsert_gpu.h — the whole-iteration BVH2 reinsertion pass on a HIP device (reinsert_gpu.cpp), called by builder.cpp.
 #pragma once
 #include <cstdint>
 #include <string>
