@@ -928,13 +928,17 @@ struct Reinserter {
                     inside = true;
                     break;
                 }
-            if (inside) continue;
+            if (inside) {
+                below_skips++;
+                continue;
+            }
             move(from, to);
             touched_at[from] = touched_at[p] = touched_at[s] = touched_at[g] = touched_at[to] = touched_at[tp] = stamp;
             moved_now++;
         }
         return moved_now;
     }
+    uint64_t below_skips = 0; // moves apply_batch dropped because their target had come to lie below the node they move
 
     // The batched pass with WHOLE-ITERATION batches: every candidate of an iteration searches the tree as the previous
     // iteration left it (Meister & Bittner's formulation as the paper states it), the searches on `device` (one thread
@@ -1039,8 +1043,8 @@ struct Reinserter {
         // (the device's collapse stage follows links and counts the primitives itself: no pre-order layout needed)
         if (moved && !keep_layout) relayout(threads);
         if (verbose)
-            fprintf(stderr, "[trx build] reinsertion: select %.3f s, search (+ copies) %.3f s, apply %.3f s, re-layout %.3f s\n", t_select, t_search,
-                    t_apply, secs(t3, now()));
+            fprintf(stderr, "[trx build] reinsertion: select %.3f s, search (+ copies) %.3f s, apply %.3f s, re-layout %.3f s; %llu move(s) dropped for a target below the moved node\n",
+                    t_select, t_search, t_apply, secs(t3, now()), (unsigned long long)below_skips);
         return moved;
     }
 
