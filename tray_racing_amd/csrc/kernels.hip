@@ -324,8 +324,11 @@ __device__ __forceinline__ bool intersect_tri(const Ray &r, const float4 a, cons
     const uint32_t hit = __float_as_uint(u) | __float_as_uint(v) | __float_as_uint(w);
     if (inv_det != 0.0f && (hit & 0x80000000u) == 0) {
         const float tt = dot3(ngx, ngy, ngz, cx, cy, cz) * inv_det;
-        const bool closer = tie_first ? (tt < t) : (tt <= t);
-        if (tt >= r.tmin && closer) {
+        // (tie_first ? tt < t : tt <= t, written so that the wave-uniform flag is a scalar mask operation: as a select
+        // between the two comparisons it compiles to five vector instructions per test)
+        const bool lt = tt < t, eq = tt == t;
+        const bool closer = lt | (eq & !tie_first); // (bitwise: no short-circuit branches)
+        if ((tt >= r.tmin) & closer) {
             t = tt;
             return true;
         }
