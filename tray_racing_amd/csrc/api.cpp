@@ -556,6 +556,12 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         // tuning: variant bits 29..31 = per-lane rounds one cooperative round is worth (0 = default 2; 7 = always cooperative)
         const uint32_t r = (variant >> 29) & 0x7u;
         p.tri_coop_ratio = r == 0u ? 2u : r == 7u ? 0u : r;
+        // cooperative rounds are chosen when rounds(largest per-lane count) > ratio x windows, and there is at least one
+        // window: a wave whose largest count is at most ratio x kTriBatch can never choose them, so it need not run the two
+        // wave scans that decide (twelve DPP instructions a trip; a largest count of exactly two is the common case on
+        // coherent rays).  Same decisions, fewer scans.
+        if (c == 0u && p.tri_coop_ratio != 0u)
+            p.tri_compact_min = std::max(p.tri_compact_min, p.tri_coop_ratio * (uint32_t)(s->tlas ? kTriBatchTlas : kTriBatch) + 1u);
     }
     p.waves_per_block = wpb;
     p.merge = merge_default ? 1u : 0u;
