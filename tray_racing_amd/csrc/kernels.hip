@@ -72,6 +72,10 @@
 namespace trx {
 namespace {
 
+// __ballot() takes an int: a bool that lives as a lane mask is first turned into 0 / 1 per lane and compared again (two
+// vector instructions where the mask was already there); the builtin takes the bool
+__device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 constexpr bool kTune = TRX_K_TUNE, kTailDiag = TRX_K_TAIL, kStamps = TRX_K_STAMPS;
 
 #define TRX_F32_MAX 3.402823466e+38f
