@@ -1038,7 +1038,9 @@ def test_literal_division_shortcut_is_exact_at_its_edges(trx, orc):
     """TRX_SEM_HLSL divides per node like the shader (query.hlsl:237-243); the kernel computes e / d as e * (1/d) where
     that is the same float (e a power of two, nothing leaves the normal range) and divides otherwise.  Rays whose
     direction components are denormal, enormous, zero, or just inside the allowed range, and a scene so small that its
-    exponent bytes fall below 21, take the other path - every hit equals the oracle's, which always divides."""
+    exponent bytes fall below 21, take the other path - every hit equals the oracle's, which always divides.  Likewise
+    (p - o) / d, computed from the ray's 1/d by one correction step where ray and scene admit it (round 5; all 2^46
+    pairs of significands checked against `/` by tools/ubench/div_exhaustive.hip, profiles/r05_div_exhaustive.log)."""
     w, h = 64, 64
     flat, _view, osc, _ov = make_scene(trx, orc, "cornell", 0, w, h)
     rays = random_rays(trx, flat, 4096, 77)
@@ -1050,18 +1052,68 @@ def test_literal_division_shortcut_is_exact_at_its_edges(trx, orc):
         d[i, rng.integers(0, 3)] = edge[rng.integers(0, edge.size)]
         if i % 3 == 0:
             d[i, rng.integers(0, 3)] = edge[rng.integers(0, edge.size)]
+    # ... and the edges of the other shortcut, (p - o) / d from the ray's reciprocal by one correction step (kernels.hip
+    # div_by_rcp; admitted per RAY: |d| in [2^-30, 2^20], every origin component 0 or in [2^-36, 2^59]; per SCENE: every
+    # node origin component +0 or in that range; a ray outside sends every node step of its wave through `/`):
+    # directions on and just outside 2^-30, origins on and outside both ends, zero origins of either sign, origins that
+    # coincide with a node's quantisation origin (p - o = +0) or sit one ulp beside it
+    two30 = np.float32(2.0 ** -30)
+    edge_d = np.array([two30, -two30, np.nextafter(two30, np.float32(0)), -np.nextafter(two30, np.float32(0)),
+                       np.nextafter(two30, np.float32(1)), np.float32(2.0 ** -31), np.float32(-2.0 ** -29)], dtype=np.float32)
+    lo36, hi59 = np.float32(2.0 ** -36), np.float32(2.0 ** 59)
+    edge_o = np.array([0.0, -0.0, lo36, -lo36, np.nextafter(lo36, np.float32(0)), -np.nextafter(lo36, np.float32(0)), 1e-13, 1e-30, 1e-39,
+                       hi59, -hi59, np.nextafter(hi59, np.float32(np.inf)), 1e18, -1.2e18, 3e19], dtype=np.float64).astype(np.float32)
+    node_p = flat.nodes[:, 0:3].copy().view(np.float32)
+    o = rays["origin"]
+    for i in range(2048, 4096):
+        k = i % 8
+        if k < 2:
+            d[i, rng.integers(0, 3)] = edge_d[rng.integers(0, edge_d.size)]
+        elif k < 5:
+            ax = rng.integers(0, 3)
+            pv = node_p[rng.integers(0, node_p.shape[0]), ax]
+            o[i, ax] = (pv, np.nextafter(pv, np.float32(np.inf)), np.nextafter(pv, np.float32(-np.inf)))[k - 2]
+            if i % 16 >= 8:
+                o[i, (ax + 1) % 3] = node_p[rng.integers(0, node_p.shape[0]), (ax + 1) % 3]
+        elif k < 7:
+            o[i, rng.integers(0, 3)] = edge_o[rng.integers(0, edge_o.size)]
+        # (k == 7: as drawn)
     rays["direction"] = d
+    rays["origin"] = o
     sc = trx.Scene(flat)
     try:
         for sem in (0, 2, 4, 6):                   # every semantics word whose node test divides
             got, _ = sc.trace_rays(rays, sem=sem)
             want, _ = osc.trace_rays(rays, sem=sem)
             assert_hits_equal(got, want, "edge directions, sem %d" % sem)
+        # whole waves inside the range (no lane sends a step through `/`): rays as drawn, far from any edge
+        plain = random_rays(trx, flat, 4096, 78, zero_dirs=False)
+        for sem in (0, 4):
+            got, _ = sc.trace_rays(plain, sem=sem)
+            want, _ = osc.trace_rays(plain, sem=sem)
+            assert_hits_equal(got, want, "plain rays, sem %d" % sem)
+    finally:
+        sc.close()
+    # a tree some of whose node origins are -0, tiny or enormous (the boxes move with them - for the oracle too): the
+    # scene's flag allows the power-of-two shortcut only, every (p - o) / d is divided
+    import copy
+    odd = copy.copy(flat)
+    odd.nodes = flat.nodes.copy()
+    pf = odd.nodes[:, 0:3].view(np.float32)
+    pf[7::23, 0] = np.float32(-0.0)
+    pf[11::29, 1] = np.float32(1e-13)
+    pf[13::31, 2] = np.float32(-3e18)
+    oosc = orc.Scene.from_flat(odd)
+    sc = trx.Scene(odd)
+    try:
+        for sem in (0, 4):
+            got, _ = sc.trace_rays(plain, sem=sem)
+            want, _ = oosc.trace_rays(plain, sem=sem)
+            assert_hits_equal(got, want, "odd node origins, sem %d" % sem)
     finally:
         sc.close()
     # the same tree with every exponent byte lowered by 40 (boxes 2^-40 of their size, some bytes below 21): the shortcut
     # is off for the whole scene, and whatever the collapsed boxes let through is what the oracle lets through
-    import copy
     low = copy.copy(flat)
     low.nodes = flat.nodes.copy()
     eb = low.nodes.view(np.uint8).reshape(-1, 80)[:, 12:15]

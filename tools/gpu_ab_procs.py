@@ -22,6 +22,7 @@ def child(scenes, variant):
     from tools.prof_config import hemisphere_rays
     lib = L.load()
     w, h = int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080"))   # (W=3840 H=2160 TLAS=1: configs[4])
+    SEM = int(os.environ.get("SEM", "3"))   # (SEM=0: the shader's literal arithmetic, TRX_SEM_HLSL)
     out = {}
     for name in scenes:
         verts, counts = T.gen_scene(name, 0, 1)
@@ -31,7 +32,7 @@ def child(scenes, variant):
         sc = T.Scene(flat)
         prim = torch.zeros(w * h, dtype=torch.int64, device="cuda")
         ao = torch.zeros(w * h, dtype=torch.int64, device="cuda")
-        sc.trace_primary_dev(view, w, h, prim.data_ptr(), sem=3)
+        sc.trace_primary_dev(view, w, h, prim.data_ptr(), sem=SEM)
         torch.cuda.synchronize()
         rays = hemisphere_rays(flat, None, eye, 1 << 20, 7)
         d_rays = torch.from_numpy(rays.view("u1").copy()).cuda()
@@ -52,20 +53,20 @@ def child(scenes, variant):
                 ts.append(e0.elapsed_time(e1) / per)
             return min(ts), statistics.median(ts)
 
-        a_min, a_med = batches(lambda i: sc.trace_ao_dev(view, w, h, prim.data_ptr(), ao.data_ptr(), sem=3, frame=i, ao_eps=0.01))
-        r_min, r_med = batches(lambda i: sc.trace_rays_dev(d_rays.data_ptr(), len(rays), hits.data_ptr(), sem=3))
-        p_min, p_med = batches(lambda i: sc.trace_primary_dev(view, w, h, prim.data_ptr(), sem=3), warm=140)
+        a_min, a_med = batches(lambda i: sc.trace_ao_dev(view, w, h, prim.data_ptr(), ao.data_ptr(), sem=SEM, frame=i, ao_eps=0.01))
+        r_min, r_med = batches(lambda i: sc.trace_rays_dev(d_rays.data_ptr(), len(rays), hits.data_ptr(), sem=SEM))
+        p_min, p_med = batches(lambda i: sc.trace_primary_dev(view, w, h, prim.data_ptr(), sem=SEM), warm=140)
         out[name] = {"ao": a_med, "ao_min": a_min, "rays": r_med, "rays_min": r_min, "primary": p_med, "primary_min": p_min}
         if hasattr(lib, "trx_trace_frame_dev"):   # the reference-style frame: two launches / one launch; 4 spp in one launch
             prim1 = torch.zeros(w * h, dtype=torch.int64, device="cuda")
             ao4 = torch.zeros(4 * w * h, dtype=torch.int64, device="cuda")
 
             def two(i):
-                sc.trace_primary_dev(view, w, h, prim.data_ptr(), sem=3)
-                sc.trace_ao_dev(view, w, h, prim.data_ptr(), ao.data_ptr(), sem=3, frame=i, ao_eps=0.01)
+                sc.trace_primary_dev(view, w, h, prim.data_ptr(), sem=SEM)
+                sc.trace_ao_dev(view, w, h, prim.data_ptr(), ao.data_ptr(), sem=SEM, frame=i, ao_eps=0.01)
             out[name]["frame2"] = batches(two)[1]
-            out[name]["frame1"] = batches(lambda i: sc.trace_frame_dev(view, w, h, prim1.data_ptr(), ao.data_ptr(), sem=3, frame=i, ao_eps=0.01))[1]
-            out[name]["ao4"] = batches(lambda i: sc.trace_ao_batch_dev(view, w, h, prim.data_ptr(), ao4.data_ptr(), w * h, 4, sem=3, frame0=4 * i, ao_eps=0.01), per=4)[1]
+            out[name]["frame1"] = batches(lambda i: sc.trace_frame_dev(view, w, h, prim1.data_ptr(), ao.data_ptr(), sem=SEM, frame=i, ao_eps=0.01))[1]
+            out[name]["ao4"] = batches(lambda i: sc.trace_ao_batch_dev(view, w, h, prim.data_ptr(), ao4.data_ptr(), w * h, 4, sem=SEM, frame0=4 * i, ao_eps=0.01), per=4)[1]
         lib.trx_set_kernel_variant(0)
         sc.close()
     print("AB_CHILD " + json.dumps(out), flush=True)

@@ -249,7 +249,7 @@ struct trx_scene {
     uint32_t n_inst = 0, tlas_start = 0;
     bool tlas = false;
     float scene_diag = 0.f; // diagonal of the root node's box (camera-cut detection scales with it)
-    bool exp_exact = false; // every node exponent byte is 0 or >= 21 (TraceParams::exp_exact)
+    uint32_t exp_exact = 0u; // 1: every node exponent byte is 0 or >= 21; 2: and every node origin admits div_by_rcp (TraceParams::exp_exact)
     int grid = 0;      // default number of persistent waves
     int cu_count = 0;
     unsigned long long *d_wave_times = nullptr; // diagnostics only (trx_debug_wave_timeline)
@@ -503,7 +503,7 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.inst_entry = s->d_inst_entry;
     p.inst_xform = s->d_inst_xform;
     p.tlas_start = s->tlas_start;
-    p.exp_exact = s->exp_exact ? 1u : 0u;
+    p.exp_exact = s->exp_exact;
     p.ctr = slot.ctr;
     p.spill = slot.spill;
     p.tie_first = (sem & TRX_SEM_TIE_FIRST) ? 1u : 0u;
@@ -848,7 +848,18 @@ int trx_scene_create(const void *bvh_bytes, uint64_t n_nodes, const void *tri_by
         const CwbvhNode *nodes = (const CwbvhNode *)bvh_bytes;
         for (uint64_t i = 0; i < n_nodes && ok; i++)
             for (int k = 0; k < 3; k++) ok = ok && (nodes[i].e[k] == 0 || nodes[i].e[k] >= 21);
-        s->exp_exact = ok;
+        // ... and may it compute (p - o) / d from the ray's 1/d by one correction step (kernels.hip, div_by_rcp)?  Every
+        // component of every node's p is +0 or 2^-36 <= |p| <= 2^59 (no -0, no NaN, nothing tiny or enormous): with the
+        // ray's own flag (origin components 0 or in the same range) p - o is then +0 or 2^-59 <= |p - o| <= 2^60
+        bool org = ok;
+        for (uint64_t i = 0; i < n_nodes && org; i++)
+            for (int k = 0; k < 3; k++) {
+                uint32_t bits;
+                std::memcpy(&bits, &nodes[i].p[k], 4);
+                const float a = std::fabs(nodes[i].p[k]);
+                org = org && (bits == 0u || (a >= 0x1p-36f && a <= 0x1p59f));
+            }
+        s->exp_exact = ok ? (org ? 2u : 1u) : 0u;
     }
     if (s->grid <= 0) return cleanup(fail(TRX_ERR_NO_DEVICE, "could not size the persistent grid"));
     *out = s;

@@ -140,7 +140,7 @@ struct TraceParams {
     uint32_t merge;                  // 2 waves per workgroup, incoherent BLAS pass: the second wave may hand its last rays to the first (kernels.hip, drain)
     unsigned long long *wave_times;  // diagnostics: [8*wave] start, [8*wave+1] end (wall_clock64), [+2..7] phase cycles in TRX_STAMPS builds; or null
     FbState *fb;          // image passes with tile-order feedback: the schedule tuner's state (null = feedback always on)
-    uint32_t exp_exact;   // every exponent byte of the scene's nodes is 0 or >= 21: e / d may be computed as e * (1/d) exactly (kernels.hip, pow2)
+    uint32_t exp_exact;   // >= 1: every exponent byte of the scene's nodes is 0 or >= 21: e / d may be computed as e * (1/d) exactly; 2: and every node origin is +0 or within 2^-36 .. 2^59: (p - o) / d from 1/d by one correction step (kernels.hip, TRX_NODE_FRAME)
     uint32_t no_order;    // ignore the order on file (this frame files a new one): first frame of an image geometry
     uint32_t new_view;    // camera cut: the schedule tuner starts over
     uint32_t uni_decode;  // coherent primary walk: decode the child planes of a node step once per wave when every lane visits the same node

@@ -131,6 +131,28 @@ __device__ __forceinline__ float ubyte(uint32_t x, int j) { return (float)((x >>
 // the normal range - which pow2_exact() below guarantees from the ray (every |d| normal and <= 2^20) and the
 // scene (every exponent byte 0 or >= 21); overflow to infinity happens to both sides at the same threshold.
 // Three of the six IEEE divisions of a node step become multiplications by the ray's 1/d.
+//   The other three, b = (p - o) / d, have a numerator that is no power of two.  With y = RN(1 / d) - the ray's r.ix, an IEEE
+// division at ray set-up - the correctly rounded quotient takes ONE correction step (Markstein): q0 = RN(a y),
+// rem = a - d q0 (exact in one fma), q = RN(q0 + rem y) = RN(a / d), as long as no intermediate leaves the normal range
+// (div_by_rcp: three instructions where the compiler's `/` is eleven).  Whether the identity holds depends on the two
+// significands only - scaling by powers of two commutes with every step - and tools/ubench/div_exhaustive.hip checks
+// all 2^46 pairs of them on the GPU against `/` (profiles/r05_div_exhaustive.log: 0 mismatches in 7.04e13), plus 2^36
+// random pairs over the admitted exponents and zero numerators.  Admitted: 2^-30 <= |d| <= 2^20 and a = +0 or
+// 2^-60 <= |a| <= 2^60 - every product, remainder and quotient then stays between 2^-127+24 and 2^127; a = +0 comes out
+// as the zero of the right sign (worked through in DESIGN.md section 3), a = -0 would not.  Nothing of that is looked
+// at per node step: the RAY carries a flag (finish_ray_dir: every origin component 0 or 2^-36 <= |o| <= 2^59) and the
+// SCENE one (api.cpp, exp_exact = 2: every component of every node's p is +0 or 2^-36 <= |p| <= 2^59), and the
+// difference of two such floats is +0 or a multiple of 2^-59 no larger than 2^60.  shortcut = 2: both shortcuts for
+// this step (every lane that takes it), 1: the power-of-two one only, 0: the shader's six divisions.
+#ifndef TRX_DIV_BY_RCP
+#define TRX_DIV_BY_RCP 1
+#endif
+// RN(a / d) from y = RN(1 / d): see above for when
+__device__ __forceinline__ float div_by_rcp(float a, float d, float y) {
+    const float q0 = a * y;
+    const float rem = __builtin_fmaf(-d, q0, a);
+    return __builtin_fmaf(rem, y, q0);
+}
 #define TRX_NODE_FRAME(r, n0, pow2)                                                                         \
     const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);         \
     const uint32_t e_imask = n0.w;                                                                          \
@@ -149,9 +171,15 @@ __device__ __forceinline__ float ubyte(uint32_t x, int j) { return (float)((x >>
         ax = ex * r.ix;                                                                                     \
         ay = ey * r.iy;                                                                                     \
         az = ez * r.iz;                                                                                     \
-        bx = (px - r.ox) / r.dx;                                                                            \
-        by = (py - r.oy) / r.dy;                                                                            \
-        bz = (pz - r.oz) / r.dz;                                                                            \
+        if (TRX_DIV_BY_RCP && pow2 > 1) {                                                                   \
+            bx = div_by_rcp(px - r.ox, r.dx, r.ix);                                                         \
+            by = div_by_rcp(py - r.oy, r.dy, r.iy);                                                         \
+            bz = div_by_rcp(pz - r.oz, r.dz, r.iz);                                                         \
+        } else {                                                                                            \
+            bx = (px - r.ox) / r.dx;                                                                        \
+            by = (py - r.oy) / r.dy;                                                                        \
+            bz = (pz - r.oz) / r.dz;                                                                        \
+        }                                                                                                   \
     } else {                                                                                                \
         ax = ex / r.dx;                                                                                     \
         ay = ey / r.dy;                                                                                     \
@@ -164,7 +192,7 @@ __device__ __forceinline__ float ubyte(uint32_t x, int j) { return (float)((x >>
 template <int NODE>
 __device__ __forceinline__ uint32_t node_intersect(const Ray &r, float max_distance, const uint4 n0,
                                                    const uint4 n1, const uint4 n2, const uint4 n3,
-                                                   const uint4 n4, const bool pow2) {
+                                                   const uint4 n4, const int pow2) {
     TRX_NODE_FRAME(r, n0, pow2)
     const bool nx = r.dx < 0.0f, ny = r.dy < 0.0f, nz = r.dz < 0.0f;
     uint32_t hit_mask = 0;
@@ -211,7 +239,7 @@ __device__ __forceinline__ uint32_t node_intersect(const Ray &r, float max_dista
 // two register moves each: 37 moves in a 178-instruction test.)  Same values, same operations, same mask.
 template <int NODE>
 __device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_distance, const uint4 n0, const uint4 n1,
-                                                       const float *dec_pos, const float *dec_neg, const bool pow2) {
+                                                       const float *dec_pos, const float *dec_neg, const int pow2) {
     TRX_NODE_FRAME(r, n0, pow2)
     const float4 *const qx = reinterpret_cast<const float4 *>(r.dx < 0.0f ? dec_neg : dec_pos);
     const float4 *const qy = reinterpret_cast<const float4 *>((r.dy < 0.0f ? dec_neg : dec_pos) + 16);
@@ -253,7 +281,7 @@ __device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_d
 // C child_meta bytes.
 template <int NODE, int C>
 __device__ __forceinline__ uint32_t node_children_intersect(const Ray &r, float max_distance, const uint4 n0, uint32_t meta,
-                                                            const uint32_t q[6], const bool pow2) {
+                                                            const uint32_t q[6], const int pow2) {
     TRX_NODE_FRAME(r, n0, pow2)
     const uint32_t is_inner4 = (meta & (meta << 1)) & 0x10101010u;
     const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
@@ -341,6 +369,8 @@ __device__ __forceinline__ bool intersect_tri(const Ray &r, const float4 a, cons
 }
 
 
+// (LITERAL: a node test that divides - the flags are only looked at there)
+template <bool LITERAL>
 __device__ __forceinline__ void finish_ray_dir(Ray &r, float dx, float dy, float dz) {
     r.dx = dx == 0.0f ? TRX_F32_EPSILON : dx;
     r.dy = dy == 0.0f ? TRX_F32_EPSILON : dy;
@@ -350,16 +380,26 @@ __device__ __forceinline__ void finish_ray_dir(Ray &r, float dx, float dy, float
     r.iz = 1.0f / r.dz;
     r.oct_inv4 = (r.dx < 0.0f ? 0u : 0x04040404u) | (r.dy < 0.0f ? 0u : 0x02020202u) |
                  (r.dz < 0.0f ? 0u : 0x01010101u);
-    // bit 31 (masked out wherever oct_inv4 is used): this ray's direction does NOT allow e / d = e * (1/d) exactly
-    const float lo = 1.17549435e-38f, hi = 1048576.0f; // 2^-126 (smallest normal), 2^20; a NaN fails both
+    if (!LITERAL) return;
+    // bits 31 and 30 (masked out wherever oct_inv4 is used) switch the literal-division shortcuts of TRX_NODE_FRAME off:
+    // bit 31 - a direction component outside 2^-30 .. 2^20 (or NaN): this ray divides six times per node like the shader's
+    // text (e / d = e * (1/d) needs |d| normal and <= 2^20; the lower bound is the tighter one of div_by_rcp);
+    // bit 30 - an origin component that is neither 0 nor within 2^-36 .. 2^59: (p - o) / d is divided
+    const float lo = 0x1p-30f, hi = 1048576.0f; // a NaN fails both
     const bool exact = fabsf(r.dx) >= lo && fabsf(r.dx) <= hi && fabsf(r.dy) >= lo && fabsf(r.dy) <= hi &&
                        fabsf(r.dz) >= lo && fabsf(r.dz) <= hi;
     if (!exact) r.oct_inv4 |= 0x80000000u;
+    const float olo = 0x1p-36f, ohi = 0x1p59f;
+    const bool org = (r.ox == 0.0f || (fabsf(r.ox) >= olo && fabsf(r.ox) <= ohi)) && (r.oy == 0.0f || (fabsf(r.oy) >= olo && fabsf(r.oy) <= ohi)) &&
+                     (r.oz == 0.0f || (fabsf(r.oz) >= olo && fabsf(r.oz) <= ohi));
+    if (!org) r.oct_inv4 |= 0x40000000u;
 }
 
-// Wave-uniform: may this node step of the literal-division variants multiply by 1/d (node_intersect, pow2)?
-__device__ __forceinline__ bool pow2_exact(const TraceParams &P, const Ray &r, bool act) {
-    return P.exp_exact != 0u && __ballot(act && (r.oct_inv4 >> 31) != 0u) == 0ull;
+// Wave-uniform: which shortcuts may this node step of the literal-division variants take (TRX_NODE_FRAME: 0, 1 or 2)?
+__device__ __forceinline__ int pow2_exact(const TraceParams &P, const Ray &r, bool act) {
+    if (P.exp_exact == 0u) return 0;
+    if (__ballot(act && (r.oct_inv4 >> 30) != 0u) == 0ull) return (int)P.exp_exact;
+    return __ballot(act && (r.oct_inv4 >> 31) != 0u) == 0ull ? 1 : 0;
 }
 
 __device__ __forceinline__ void mat4_mul(const float *m, float v0, float v1, float v2, float v3, float &r0,
