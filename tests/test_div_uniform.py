@@ -1,5 +1,5 @@
 """The division the kernels' refill uses for launch-uniform divisors (kernels.hip div_uniform, reciprocals from
-api.cpp enqueue): q = mulhi(x, floor(2^32 / d)), one correction step - restated in numpy and checked against integer
+api_launch.cpp enqueue): q = mulhi(x, floor(2^32 / d)), one correction step - restated in numpy and checked against integer
 division over the divisors a launch can have (image widths, tile counts, frames per launch) and over random ones."""
 import numpy as np
 

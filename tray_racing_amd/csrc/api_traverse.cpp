@@ -1,0 +1,238 @@
+// api_traverse.cpp - Traversable::traverse (traversable/src/lib.rs:13-28) for one ray and for batches.
+#include "api_internal.h"
+
+static void futex_wait(std::atomic<uint32_t> *a, uint32_t while_value) {
+    static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(a), FUTEX_WAIT_PRIVATE, while_value, nullptr, nullptr, 0);
+}
+static void futex_wake_all(std::atomic<uint32_t> *a) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(a), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+static int64_t now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
+extern "C" {
+
+// {t, global triangle} (+ the TLAS primitive it was found in) as obvhs' RayHit: (geometry_id, primitive_id local to
+// that geometry) like src/cwbvh.rs:151-160 when the geometry ranges are known, RayHit::none() for a miss.
+static void to_rayhit(const trx_scene *s, const trx_hit h, uint32_t inst, trx_rayhit *out) {
+    out->t = h.t;
+    out->instance_id = 0xFFFFFFFFu;
+    if (h.prim == 0xFFFFFFFFu) { // RayHit::none()
+        out->primitive_id = out->geometry_id = 0xFFFFFFFFu;
+        return;
+    }
+    out->primitive_id = h.prim;
+    out->geometry_id = 0;
+    if (s->blas_tri_start.size() > 1) {
+        auto it = std::upper_bound(s->blas_tri_start.begin(), s->blas_tri_start.end(), h.prim);
+        uint32_t g = (uint32_t)(it - s->blas_tri_start.begin()) - 1;
+        out->geometry_id = g;
+        out->primitive_id = h.prim - s->blas_tri_start[g];
+        out->instance_id = g;
+    }
+    if (s->tlas) out->instance_id = inst; // the TLAS primitive the hit was found in
+}
+
+int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *out) {
+    if (!s || !ray || !out) return fail(TRX_ERR_INVALID, "null argument");
+    if (sem & ~7u) return fail(TRX_ERR_INVALID, "unknown semantics bits 0x%x", sem);
+    HIP_TRY(hipSetDevice(s->device));
+    std::call_once(s->comb_once, [s]() { s->comb = new (std::nothrow) RayCombiner(s->device); });
+    RayCombiner *c = s->comb;
+    if (!c || !c->ok) return fail(TRX_ERR_OOM, "single-ray combiner: %s", c ? c->init_err.c_str() : "allocation failed");
+    struct Inside { // (counted while inside: a caller spins for its batch only while the callers fit the host's cores)
+        std::atomic<int> &n;
+        explicit Inside(std::atomic<int> &a) : n(a) { n.fetch_add(1, std::memory_order_relaxed); }
+        ~Inside() { n.fetch_sub(1, std::memory_order_relaxed); }
+    } inside(c->inside);
+    std::unique_lock<std::mutex> lock(c->mu);
+    bool leader = false;
+    int bi = -1;
+    for (;;) {
+        if (c->open >= 0) {
+            if (c->batch[c->open].sem == sem) {
+                bi = c->open;
+                break;
+            }
+            c->cv.wait(lock); // an open batch of another semantics closes within kMaxWait: wait for it rather than mix
+            continue;
+        }
+        for (int i = 0; i < (int)RayCombiner::kBatches && bi < 0; i++)
+            if (c->batch[i].state == RayCombiner::Batch::kFree) bi = i;
+        if (bi >= 0) {
+            RayCombiner::Batch &nb = c->batch[bi];
+            nb.state = RayCombiner::Batch::kOpen;
+            nb.sem = sem;
+            nb.n = 0;
+            nb.read.store(0, std::memory_order_relaxed);
+            nb.rc = 0;
+            c->open = bi;
+            leader = true;
+            break;
+        }
+        c->cv.wait(lock); // every batch is in flight or being read: one frees up when its last reader leaves
+    }
+    RayCombiner::Batch &b = c->batch[bi];
+    const uint32_t idx = b.n++;
+    b.rays[RayCombiner::slot(idx)] = *ray;
+    const uint32_t epoch = b.done_epoch.load(std::memory_order_relaxed);
+    if (b.n == RayCombiner::kCap) c->open = -1; // full: closed to later arrivals (its leader notices)
+    if (leader) {
+        // Wait for company.  Everyone who can still join is inside this function and not attached to another batch: once
+        // they are all here (and nobody new has turned up for kQuiet), go; kMaxWait bounds the wait either way.
+        const int64_t t0 = now_ns();
+        int64_t t_last = t0;
+        uint32_t seen = b.n;
+        while (c->open == bi) {
+            lock.unlock();
+            if (c->inside.load(std::memory_order_relaxed) > c->cores) std::this_thread::yield(); // (callers that have no core yet)
+            else for (int k = 0; k < 16; k++) cpu_relax();
+            lock.lock();
+            const int64_t t = now_ns();
+            if (b.n != seen) {
+                seen = b.n;
+                t_last = t;
+            }
+            uint32_t elsewhere = 0;
+            for (int j = 0; j < (int)RayCombiner::kBatches; j++)
+                if (j != bi && c->batch[j].state != RayCombiner::Batch::kFree)
+                    elsewhere += c->batch[j].n - std::min(c->batch[j].n, c->batch[j].read.load(std::memory_order_relaxed));
+            const int expected = c->inside.load(std::memory_order_relaxed) - (int)elsewhere;
+            if (((int)b.n >= expected && t - t_last > RayCombiner::kQuietNs) || t - t0 > RayCombiner::kMaxWaitNs) break;
+        }
+        if (c->open == bi) c->open = -1;
+        const uint32_t n = b.n;
+        b.state = RayCombiner::Batch::kFlying;
+        c->launches++;
+        c->rays += n;
+        lock.unlock();
+        c->cv.notify_all(); // (callers waiting for an open batch of their own semantics)
+        *b.over = 0u;
+        int rc = trace_rays_impl(s, b.rays, RayCombiner::slots_used(n), sem, b.hits, b.stream, false, nullptr, false,
+                                 s->tlas ? b.inst : nullptr, b.over, n <= RayCombiner::kSpread);
+        if (!rc && hipStreamSynchronize(b.stream) != hipSuccess) rc = fail(TRX_ERR_NO_DEVICE, "sync failed");
+        if (!rc && *reinterpret_cast<volatile uint32_t *>(b.over) != 0u)
+            rc = fail(TRX_ERR_STACK_OVERFLOW, "a ray overflowed the %d-entry traversal stack (or the step cap)", kLdsStack + kSpillStack);
+        b.rc = rc;
+        if (rc) b.err = err_string();
+        b.done_epoch.fetch_add(1, std::memory_order_release);
+        if (n > 1) futex_wake_all(&b.done_epoch);
+    } else {
+        // a follower spins on the batch's epoch for about a round trip (when it has a core to spin on), then sleeps on it
+        lock.unlock();
+        if (c->inside.load(std::memory_order_relaxed) <= c->cores) {
+            const int64_t t0 = now_ns();
+            while (b.done_epoch.load(std::memory_order_acquire) == epoch && now_ns() - t0 < 300000)
+                for (int k = 0; k < 16; k++) cpu_relax();
+        }
+        while (b.done_epoch.load(std::memory_order_acquire) == epoch) futex_wait(&b.done_epoch, epoch);
+    }
+    // (no lock: the batch's records stay put until its last reader has left)
+    const int rc = b.rc;
+    if (rc && !leader) err_string() = b.err;
+    const uint32_t at = RayCombiner::slot(idx);
+    const trx_hit h = b.hits[at];
+    const uint32_t inst = s->tlas ? b.inst[at] : 0xFFFFFFFFu;
+    if (idx < RayCombiner::kSpread) b.rays[at] = RayCombiner::null_ray(); // (the slot goes back to being padding)
+    const uint32_t n_final = b.n;
+    if (b.read.fetch_add(1, std::memory_order_acq_rel) + 1 == n_final) { // last reader out: the batch can be opened again
+        lock.lock();
+        b.state = RayCombiner::Batch::kFree;
+        lock.unlock();
+        c->cv.notify_all();
+    }
+    if (rc) return rc;
+    to_rayhit(s, h, inst, out);
+    return TRX_OK;
+}
+
+// The reference's CPU pixel loop over the literal Traversable::traverse (src/rt_cpu/rt_cpu.rs:35-57) as a measuring aid:
+// `threads` host threads, thread k calls trx_traverse1 for rays k, k + threads, ...; wall-clock seconds of the loop and the
+// launches its calls shared come back.  (The calls are the public entry point's; only the thread pool lives here, so that a
+// Python caller is not measuring its interpreter lock.)
+int trx_debug_traverse1_threads(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t threads, uint32_t sem, trx_rayhit *out,
+                                double *out_seconds, uint64_t *out_launches) {
+    if (!s || (n && (!rays || !out)) || threads == 0 || threads > 4096) return fail(TRX_ERR_INVALID, "bad argument");
+    uint64_t l0 = 0, l1 = 0;
+    if (n) { // the first call creates the combiner: not part of the loop's time
+        const int rc = trx_traverse1(s, &rays[0], sem, &out[0]);
+        if (rc) return rc;
+    }
+    (void)trx_debug_traverse1_stats(s, &l0, nullptr);
+    std::atomic<int> first_rc{0};
+    std::string first_err;
+    std::mutex err_mu;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    try {
+        for (uint32_t k = 0; k < threads; k++)
+            pool.emplace_back([&, k]() {
+                for (uint64_t i = k; i < n && first_rc.load(std::memory_order_relaxed) == 0; i += threads) {
+                    const int rc = trx_traverse1(s, &rays[i], sem, &out[i]);
+                    if (rc) {
+                        std::lock_guard<std::mutex> g(err_mu);
+                        if (first_rc.load() == 0) {
+                            first_err = err_string();
+                            first_rc.store(rc);
+                        }
+                    }
+                }
+            });
+    } catch (const std::exception &) {
+        first_rc.store(TRX_ERR_OOM);
+        first_err = "could not start the threads";
+    }
+    for (auto &th : pool) th.join();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    (void)trx_debug_traverse1_stats(s, &l1, nullptr);
+    if (first_rc.load()) {
+        err_string() = first_err;
+        return first_rc.load();
+    }
+    if (out_seconds) *out_seconds = secs;
+    if (out_launches) *out_launches = l1 - l0;
+    return TRX_OK;
+}
+
+// Launches and rays the single-ray combiner has served so far (development / tests: rays / launches = callers per launch).
+int trx_debug_traverse1_stats(trx_scene *s, uint64_t *out_launches, uint64_t *out_rays) {
+    if (!s) return fail(TRX_ERR_INVALID, "null argument");
+    uint64_t l = 0, r = 0;
+    if (s->comb) {
+        std::lock_guard<std::mutex> lock(s->comb->mu);
+        l = s->comb->launches;
+        r = s->comb->rays;
+    }
+    if (out_launches) *out_launches = l;
+    if (out_rays) *out_rays = r;
+    return TRX_OK;
+}
+
+// Traversable::traverse for a batch: one launch, then the same {t, prim} -> RayHit mapping as trx_traverse1.
+int trx_traverse_batch(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t sem, trx_rayhit *out, float *out_ms) {
+    if (!s || (n && (!rays || !out))) return fail(TRX_ERR_INVALID, "null argument");
+    if (n == 0) return TRX_OK;
+    std::vector<trx_hit> hits;
+    std::vector<uint32_t> inst;
+    try {
+        hits.resize(n);
+        if (s->tlas) inst.resize(n);
+    } catch (const std::exception &) {
+        return fail(TRX_ERR_OOM, "host allocation failed");
+    }
+    int rc = trx_trace_rays_inst(s, rays, n, sem, hits.data(), s->tlas ? inst.data() : nullptr, out_ms);
+    if (rc) return rc;
+    for (uint64_t i = 0; i < n; i++) to_rayhit(s, hits[i], s->tlas ? inst[i] : 0xFFFFFFFFu, &out[i]);
+    return TRX_OK;
+}
+
+} // extern "C"

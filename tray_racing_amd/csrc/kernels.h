@@ -1,4 +1,4 @@
-// kernels.h — launch interface between the C-ABI layer (api.cpp) and the
+// kernels.h — launch interface between the C-ABI layer (api_launch.cpp) and the
 // gfx950 kernels (kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -141,7 +141,7 @@ __device__ __forceinline__ float ubyte(uint32_t x, int j) { return (float)((x >>
 // 2^-60 <= |a| <= 2^60 - every product, remainder and quotient then stays between 2^-127+24 and 2^127; a = +0 comes out
 // as the zero of the right sign (worked through in DESIGN.md section 3), a = -0 would not.  Nothing of that is looked
 // at per node step: the RAY carries a flag (finish_ray_dir: every origin component 0 or 2^-36 <= |o| <= 2^59) and the
-// SCENE one (api.cpp, exp_exact = 2: every component of every node's p is +0 or 2^-36 <= |p| <= 2^59), and the
+// SCENE one (trx_scene_create in api.cpp, exp_exact = 2: every component of every node's p is +0 or 2^-36 <= |p| <= 2^59), and the
 // difference of two such floats is +0 or a multiple of 2^-59 no larger than 2^60.  shortcut = 2: both shortcuts for
 // this step (every lane that takes it), 1: the power-of-two one only, 0: the shader's six divisions.
 #ifndef TRX_DIV_BY_RCP
@@ -707,7 +707,7 @@ hipError_t launch_node(const TraceParams &p, int node, int grid, hipStream_t str
 template <int MODE>
 hipError_t launch_mode(const TraceParams &p, bool tlas, int node, bool count, bool pipe, int grid, hipStream_t stream) {
     // (the one-launch frame exists for single-level scenes: the two-level walk has no registers to spare for the in-place
-    // hand-over - it spills - so trx_trace_frame_dev runs a two-level frame as two launches, api.cpp)
+    // hand-over - it spills - so trx_trace_frame_dev runs a two-level frame as two launches, api_trace.cpp)
     if constexpr (MODE == kModeFused) {
         if (tlas) return hipErrorInvalidValue;
     } else
