@@ -531,6 +531,48 @@ def main():
             legs["ao_pass_ms"] = {"rays": n_ao, "frames": len(at), "min": round(min(at), 4), "mean": round(sum(at) / len(at), 4),
                                   "mrays_at_mean": round(n_ao / (sum(at) / len(at)) / 1e3, 1)}
 
+            def fetch_vs_random(sc, n_node, n_tri, ms):
+                """north_star's "node-fetch loop against a MEASURED roofline" for an incoherent pass: what the pass asks for
+                per second (counted node steps x 80 B + triangle tests x 48 B over its kernel time) against what this GPU
+                serves when every lane of the same grid fetches UNIFORMLY RANDOM nodes and triangle records of the same
+                scene in the same proportion and does nothing else (trx_debug_fetch_rate).  Not an upper bound: a walk's
+                upper tree levels stay in L1 / L2 and a leaf's triangles share lines, the probe's fetches do neither - a
+                ratio above 1 says the pass runs beyond the no-locality rate of the memory system, i.e. on its caches."""
+                nps, tps = sc.fetch_rate(tris_per_node=n_tri / max(n_node, 1))
+                rnd = NODE_BYTES * nps + TRI_BYTES * tps
+                ach = (NODE_BYTES * n_node + TRI_BYTES * n_tri) / (ms * 1e-3)
+                return {"requested_gbs": round(ach / 1e9, 1), "random_fetch_gbs": round(rnd / 1e9, 1), "ratio": round(ach / rnd, 3),
+                        "nodes_per_s_g": round(n_node / (ms * 1e-3) / 1e9, 2), "tris_per_s_g": round(n_tri / (ms * 1e-3) / 1e9, 2),
+                        "random_nodes_per_s_g": round(nps / 1e9, 2), "random_tris_per_s_g": round(tps / 1e9, 2)}
+            ao_st = scene.count_ao(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=0, ao_eps=0.01)
+            legs["ao_pass_ms"]["fetch_vs_random"] = fetch_vs_random(scene, int(ao_st.n_node), int(ao_st.n_tri), min(at))
+            # random rays: origins spread over the scene's box, uniformly random directions - incoherent by construction
+            rng_r = np.random.default_rng(5)
+            tv = flat.tri_verts.reshape(-1, 3)
+            blo, bhi = tv.min(axis=0), tv.max(axis=0)
+            rr = np.zeros(n_rays_total, dtype=T.RAY_DTYPE)
+            rr["origin"] = (blo + (bhi - blo) * rng_r.random((n_rays_total, 3))).astype(np.float32)
+            rd = rng_r.normal(size=(n_rays_total, 3))
+            rr["direction"] = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+            rr["tmax"] = 3.4028234663852886e38
+            d_rr = torch.from_numpy(rr.view(np.uint8).reshape(-1)).cuda()
+            rr_ev = []
+            for k in range(3 + 12):
+                a, b = ev(), ev()
+                a.record()
+                scene.trace_rays_dev(d_rr.data_ptr(), n_rays_total, d_ao.data_ptr(), sem=args.sem)
+                b.record()
+                rr_ev.append((a, b))
+            torch.cuda.synchronize()
+            rt = [a.elapsed_time(b) for a, b in rr_ev][3:]
+            rr_st = scene.count_rays(d_rr.data_ptr(), n_rays_total, d_ao.data_ptr(), sem=args.sem)
+            legs["random_rays_ms"] = {"rays": n_rays_total, "min": round(min(rt), 4), "mean": round(sum(rt) / len(rt), 4),
+                                      "mrays_at_mean": round(n_rays_total / (sum(rt) / len(rt)) / 1e3, 1),
+                                      "nodes_per_ray": round(int(rr_st.n_node) / n_rays_total, 2),
+                                      "tris_per_ray": round(int(rr_st.n_tri) / n_rays_total, 2),
+                                      "fetch_vs_random": fetch_vs_random(scene, int(rr_st.n_node), int(rr_st.n_tri), min(rt))}
+            del d_rr, rr, rd, tv
+
             def timed(fn, reps=12, skip=3):
                 """hipEvent time of fn(i) on the default stream, one call in flight: (min, mean) over `reps` after `skip`."""
                 ts = []
@@ -575,8 +617,10 @@ def main():
                 h1 = timed(lambda i: hscene.trace_ao_dev(hview, w, h, hp.data_ptr(), ha.data_ptr(), sem=args.sem, frame=i % 4, ao_eps=0.01))
                 h4 = timed(lambda i: hscene.trace_ao_batch_dev(hview, w, h, hp.data_ptr(), ha.data_ptr(), n_rays_total, 4, sem=args.sem,
                                                                frame0=4 * i, ao_eps=0.01))
+                h_st = hscene.count_ao(hview, w, h, hp.data_ptr(), ha.data_ptr(), sem=args.sem, frame=0, ao_eps=0.01)
                 legs["hairball_4spp"] = {
                     "scene": "hairball", "tris": int(hflat.n_tris), "ao_rays_per_frame": h_ao,
+                    "ao_pass_fetch_vs_random": fetch_vs_random(hscene, int(h_st.n_node), int(h_st.n_tri), h1[0]),
                     "primary_ms": round(sum(q[1] for q in hprim) / 2, 4),
                     "ao_pass_ms": {"min": round(h1[0], 4), "mean": round(h1[1], 4), "mrays_at_mean": round(h_ao / h1[1] / 1e3, 1)},
                     "ao_4spp_one_launch_ms": {"min": round(h4[0], 4), "mean": round(h4[1], 4),

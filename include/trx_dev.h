@@ -55,6 +55,13 @@ int trx_debug_traverse1_stats(trx_scene *scene, uint64_t *out_launches, uint64_t
 int trx_debug_traverse1_threads(trx_scene *scene, const trx_ray *rays, uint64_t n_rays, uint32_t threads, uint32_t semantics,
                                 trx_rayhit *out, double *out_seconds, uint64_t *out_launches);
 
+/* Measuring aid: the no-locality rate of the node-fetch loop on THIS scene's buffers (bench.py's `fetch_vs_random`).  The tracer's
+ * persistent grid at the tracer's occupancy, every lane fetching one uniformly random 80-byte node per step and, on average,
+ * tris_per_node_x256 / 256 random 48-byte triangle records beside it, the next index a hash of what arrived (one step in
+ * flight per wave, like a traversing wave) - and nothing else.  Returns nodes and triangle records fetched per second. */
+int trx_debug_fetch_rate(trx_scene *scene, uint32_t steps, uint32_t tris_per_node_x256, double *out_nodes_per_s,
+                         double *out_tris_per_s);
+
 /* Kernel variant selection (tuning aid; 0 = default).  Returns the previous
  * value.  Variants compute identical results. */
 uint32_t trx_set_kernel_variant(uint32_t variant);

@@ -1128,3 +1128,25 @@ def test_literal_division_shortcut_is_exact_at_its_edges(trx, orc):
             assert_hits_equal(got, want, "lowered exponents, sem %d" % sem)
     finally:
         sc.close()
+
+
+def test_fetch_probe_measures_a_rate_and_honours_the_mix(trx, orc):
+    """trx_debug_fetch_rate (bench.py's `fetch_vs_random`): random nodes of the scene's own buffers per second, with the
+    asked-for number of triangle records beside them; traces after it are untouched by it."""
+    w, h = 64, 48
+    flat, view, osc, ov = make_scene(trx, orc, "bistro", 60000, w, h)
+    sc = trx.Scene(flat)
+    try:
+        n0, t0 = sc.fetch_rate(0.0, steps=64)
+        n1, t1 = sc.fetch_rate(0.5, steps=64)
+        n2, t2 = sc.fetch_rate(1.5, steps=64)
+        assert n0 > 1e8 and t0 == 0.0
+        assert abs(t1 / n1 - 0.5) < 1e-9 and abs(t2 / n2 - 1.5) < 1e-9
+        assert n0 >= 0.8 * n1 and n1 >= 0.8 * n2      # more bytes per step, no more steps per second
+        got = sc.trace_primary(view, w, h, sem=3)[0]
+        want = osc.trace_primary(ov, w, h, sem=3)[0]
+        assert_hits_equal(got, want, "primary frame after the probe")
+    finally:
+        sc.close()
+    with pytest.raises(Exception):
+        trx.Scene(flat).fetch_rate(99.0)

@@ -5,6 +5,7 @@
 //   api_trace.cpp    the trace / count / bench / diagnostic entry points (device-resident and host-buffer forms)
 //   api_traverse.cpp Traversable::traverse for one ray (concurrent callers share launches) and for batches
 //   api_build.cpp    builders, flat-buffer assembly (cwbvh_gpu_runner's host half), scene generators and loaders
+//   probe.cpp        trx_debug_fetch_rate: the measured ceiling of the node-fetch loop on a scene's buffers
 #ifndef TRX_API_INTERNAL_H
 #define TRX_API_INTERNAL_H
 #include <hip/hip_runtime.h>

@@ -362,6 +362,26 @@ class Scene:
         L.check(self._lib.trx_traverse_batch(self._h, _ptr(rays), rays.shape[0], sem, _ptr(out), C.byref(ms)))
         return out, ms.value
 
+    def count_ao(self, view, width, height, d_primary, d_ao, sem=L.SEM_HLSL, frame=0, ao_eps=0.01, shard=(0, 1)):
+        """Node steps / triangle tests of one AO pass over device-resident primary hits (counting kernel)."""
+        st = L.Stats()
+        L.check(self._lib.trx_count_ao(self._h, C.byref(view), width, height, L.Shard(*shard), sem, frame, ao_eps,
+                                       C.c_void_p(d_primary), C.c_void_p(d_ao), C.byref(st)))
+        return st
+
+    def count_rays(self, d_rays, n, d_hits, sem=L.SEM_HLSL):
+        """Node steps / triangle tests of one explicit-ray batch (counting kernel)."""
+        st = L.Stats()
+        L.check(self._lib.trx_count_rays(self._h, C.c_void_p(d_rays), n, sem, C.c_void_p(d_hits), C.byref(st)))
+        return st
+
+    def fetch_rate(self, tris_per_node=0.0, steps=400):
+        """Measured ceiling of the node-fetch loop on this scene's buffers (trx_debug_fetch_rate): random 80-byte nodes
+        and, tris_per_node per node on average, random 48-byte triangle records per second, nothing else running."""
+        nps, tps = C.c_double(), C.c_double()
+        L.check(self._lib.trx_debug_fetch_rate(self._h, steps, int(round(tris_per_node * 256)), C.byref(nps), C.byref(tps)))
+        return nps.value, tps.value
+
     def count_primary(self, view, width, height, sem=L.SEM_HLSL, shard=(0, 1)):
         st = L.Stats()
         L.check(self._lib.trx_count_primary(self._h, C.byref(view), width, height, L.Shard(*shard), sem, None,
