@@ -287,7 +287,11 @@ int trx_debug_tri_histogram(trx_scene *s, const trx_view *view, uint32_t w, uint
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipEventRecord(s->ev0, nullptr));
     SlotCounters *ctr = nullptr;
-    rc = enqueue(s, p, kModePrimary, sem, true, nullptr, &ctr);
+    bool count = true;
+#ifdef TRX_DEV_TUNE
+    if (getenv("TRX_HIST_NORMAL")) count = false; // (development builds: the histograms a NORMAL frame files under a tune word)
+#endif
+    rc = enqueue(s, p, kModePrimary, sem, count, nullptr, &ctr);
     if (rc) return rc;
     return finish_count(s, ctr, nullptr, out_hist);
 }

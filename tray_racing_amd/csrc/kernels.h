@@ -38,7 +38,7 @@ constexpr int kSpillStack = 64 - TRX_LDS_STACK; // further entries per lane in H
 constexpr int kWaveScratch = kSpillStack * kWave + 3 * kWave;
 // LDS per wave: stack + ray table (2 x float4 per lane) + triangle-phase tables (group, result, prefix, heads)
 constexpr int kLptPend = 32; // tile-list appends a wave parks in LDS before issuing them together
-constexpr int kLdsBytesPerWave = TRX_LDS_STACK * kWave * 8 + kWave * 32 + kWave * 8 + kWave * 8 + kWave * 4 + kWave * 4 + kLptPend * 8 + 6 * 8 * 4; // ... + the decoded child planes of a wave-uniform node step
+constexpr int kLdsBytesPerWave = TRX_LDS_STACK * kWave * 8 + kWave * 32 + kWave * 8 + kWave * 8 + kWave * 4 + kWave * 4 + kLptPend * 8 + 6 * 8 * 4 + 64; // ... + the decoded child planes of a wave-uniform node step + the packet test's ray bounds (16 waves per CU = 160 KB exactly)
 constexpr int kWaveTimeStride = 8; // diagnostics record per wave: start, end, then (TRX_STAMPS builds) phase cycles
 constexpr uint32_t kMaxSteps = 1u << 22; // per-ray iteration cap: every wave reaches an exit
 

@@ -144,6 +144,10 @@ __device__ __forceinline__ float ubyte(uint32_t x, int j) { return (float)((x >>
 // SCENE one (trx_scene_create in api.cpp, exp_exact = 2: every component of every node's p is +0 or 2^-36 <= |p| <= 2^59), and the
 // difference of two such floats is +0 or a multiple of 2^-59 no larger than 2^60.  shortcut = 2: both shortcuts for
 // this step (every lane that takes it), 1: the power-of-two one only, 0: the shader's six divisions.
+// packet culling of wave-uniform node steps (trace_walk_plain.inc): on / off
+#ifndef TRX_PACKET_CULL
+#define TRX_PACKET_CULL 1
+#endif
 #ifndef TRX_DIV_BY_RCP
 #define TRX_DIV_BY_RCP 1
 #endif
@@ -270,6 +274,50 @@ __device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_d
                 }
             }
         }
+    }
+    return hit_mask;
+}
+
+// The decode-once test over the children a PACKET test left (round 5).  In a wave-uniform node step of coherent primary
+// rays most of the eight children are missed by every ray of the wave (bistro-class frame: 1.65 children left on average,
+// none in a fifth of the steps; profiles/r05_cullhist.log).  The packet test (trace_walk_plain.inc): with the rays' common
+// origin and bounds [lo, hi] of their 1/d per axis, each {child, plane} lane of the decode stage also evaluates the
+// plane's parameter at the end of the interval that bounds it from below (near planes) or above (far planes) - the
+// SAME multiplications and additions as the per-ray test, at operands that bound every ray's: round-to-nearest
+// multiplication and addition are monotone in each operand, so the values bound what any ray of the wave computes - and
+// a child whose largest lower bound exceeds its smallest upper bound is entered by no ray: it is left out for the whole
+// wave.  This function is the per-ray test of the children that remain (`keep`, wave-uniform, bit c = child c): the
+// operations of node_intersect_dec on the same operands, child by child in a scalar loop; a child left out would have
+// contributed nothing to the mask.  keep = 0xff: all eight (a wave whose rays do not qualify for the packet test).
+template <int NODE>
+__device__ __forceinline__ uint32_t node_intersect_kept(const Ray &r, float max_distance, const uint4 n0, const uint4 n1,
+                                                        const float *dec_pos, const float *dec_neg, uint32_t keep) {
+    TRX_NODE_FRAME(r, n0, 0)
+    const float2 *const qx = reinterpret_cast<const float2 *>(r.dx < 0.0f ? dec_neg : dec_pos);
+    const float2 *const qy = reinterpret_cast<const float2 *>((r.dy < 0.0f ? dec_neg : dec_pos) + 16);
+    const float2 *const qz = reinterpret_cast<const float2 *>((r.dz < 0.0f ? dec_neg : dec_pos) + 32);
+    // (the node is the same for every lane: its child_meta bytes are scalars, and so is everything derived from them but
+    // the slot of an inner child, which depends on the ray's octant)
+    const uint32_t meta_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1.z), meta_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1.w);
+    const uint32_t oct = r.oct_inv4 & 0xffu;
+    uint32_t hit_mask = 0;
+    // (requesting the planes of the next child before this one's are used - the loop software-pipelined - measured slower,
+    // profiles/r05_ab_19_cull_pipelined.log)
+    for (uint32_t m = keep; m != 0u; m &= m - 1u) {
+        const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_ctz(m))); // (wave-uniform: a scalar)
+        const float2 x = qx[j], y = qy[j], z = qz[j]; // {near, far}
+        const f32x2 tx = plane2<NODE>(f32x2{x.x, x.y}, ax, bx);
+        const f32x2 ty = plane2<NODE>(f32x2{y.x, y.y}, ay, by);
+        const f32x2 tz = plane2<NODE>(f32x2{z.x, z.y}, az, bz);
+        const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0001f);
+        const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), max_distance);
+        const uint32_t mj = ((j < 4u ? meta_lo : meta_hi) >> (8u * (j & 3u))) & 0xffu;
+        const uint32_t child_bits = mj >> 5;
+        // child_bits << bit_index with bit_index = (meta ^ (oct & inner_mask)) & 0x1f, as in node_intersect
+        uint32_t word;
+        if ((mj & 0x18u) == 0x18u) word = child_bits << ((mj ^ oct) & 0x1fu);
+        else word = child_bits << (mj & 0x1fu);
+        if (tmin <= tmax) hit_mask |= word;
     }
     return hit_mask;
 }
