@@ -124,6 +124,13 @@ def test_cpu_baseline_and_legs(line):
     assert g["build_seconds"] < 0.5 * p["build_seconds"] and g["build_seconds"] <= 2.0 and g["nodes_per_ray"] <= p["nodes_per_ray"]
     t1 = legs["traverse1_threads"]
     assert t1["threads"] == 16 and t1["equals_traverse_batch"] is True and t1["rays_per_launch"] > 4 and t1["mrays"] > 0.1
+    # round 5, second half: the incoherent passes against the measured no-locality fetch rate of the same scene (trx_debug_fetch_rate)
+    for leg in (legs["ao_pass_ms"]["fetch_vs_random"], legs["random_rays_ms"]["fetch_vs_random"], hb["ao_pass_fetch_vs_random"]):
+        assert leg["random_fetch_gbs"] > 1000 and leg["requested_gbs"] > 0.4 * leg["random_fetch_gbs"]   # north_star's ">= 40 % of the measured roofline"
+        assert leg["ratio"] == pytest.approx(leg["requested_gbs"] / leg["random_fetch_gbs"], rel=2e-3)
+    assert 4 < legs["random_rays_ms"]["nodes_per_ray"] < 10
+    # ... and the literal-HLSL arithmetic within 7 % of the CPU preset since its divisions went (4 789 of 5 230 before)
+    assert line["value_sem_hlsl"] > 0.93 * line["value"]
 
 
 def test_the_drivers_protocol_lines_of_the_round():
@@ -138,7 +145,7 @@ def test_the_drivers_protocol_lines_of_the_round():
     assert all(d["config"]["wake_frames"] == 64 and d["value"] > 4800 for d in lines)
     assert cold["config"]["wake_frames"] == 0 and cold["value"] < min(d["value"] for d in lines)
     # a GPU still at idle clocks: the per-launch series falls through the timed region
-    assert cold["kernel_ms_per_step"][0] > cold["kernel_ms_per_step"][-1] * 1.02
+    assert cold["kernel_ms_per_step"][0] > cold["kernel_ms_per_step"][-1] * 1.01
 
 
 def test_default_arguments_finish_in_minutes():
