@@ -148,6 +148,9 @@ __device__ __forceinline__ float ubyte(uint32_t x, int j) { return (float)((x >>
 #ifndef TRX_PACKET_CULL
 #define TRX_PACKET_CULL 1
 #endif
+#ifndef TRX_PACKET_CULL_TLAS
+#define TRX_PACKET_CULL_TLAS 1
+#endif
 #ifndef TRX_DIV_BY_RCP
 #define TRX_DIV_BY_RCP 1
 #endif
