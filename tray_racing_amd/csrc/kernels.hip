@@ -148,6 +148,9 @@ __device__ __forceinline__ float ubyte(uint32_t x, int j) { return (float)((x >>
 #ifndef TRX_PACKET_CULL
 #define TRX_PACKET_CULL 1
 #endif
+#ifndef TRX_FRAME_EARLY
+#define TRX_FRAME_EARLY 0
+#endif
 #ifndef TRX_PACKET_CULL_TLAS
 #define TRX_PACKET_CULL_TLAS 1
 #endif
@@ -292,10 +295,18 @@ __device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_d
 // wave.  This function is the per-ray test of the children that remain (`keep`, wave-uniform, bit c = child c): the
 // operations of node_intersect_dec on the same operands, child by child in a scalar loop; a child left out would have
 // contributed nothing to the mask.  keep = 0xff: all eight (a wave whose rays do not qualify for the packet test).
+struct NodeFrame {
+    float ax, ay, az, bx, by, bz;
+};
 template <int NODE>
-__device__ __forceinline__ uint32_t node_intersect_kept(const Ray &r, float max_distance, const uint4 n0, const uint4 n1,
-                                                        const float *dec_pos, const float *dec_neg, uint32_t keep) {
+__device__ __forceinline__ NodeFrame node_frame(const Ray &r, const uint4 n0) {
     TRX_NODE_FRAME(r, n0, 0)
+    return NodeFrame{ax, ay, az, bx, by, bz};
+}
+template <int NODE>
+__device__ __forceinline__ uint32_t node_intersect_kept(const Ray &r, float max_distance, const NodeFrame f, const uint4 n1,
+                                                        const float *dec_pos, const float *dec_neg, uint32_t keep) {
+    const float ax = f.ax, ay = f.ay, az = f.az, bx = f.bx, by = f.by, bz = f.bz;
     const float2 *const qx = reinterpret_cast<const float2 *>(r.dx < 0.0f ? dec_neg : dec_pos);
     const float2 *const qy = reinterpret_cast<const float2 *>((r.dy < 0.0f ? dec_neg : dec_pos) + 16);
     const float2 *const qz = reinterpret_cast<const float2 *>((r.dz < 0.0f ? dec_neg : dec_pos) + 32);
