@@ -148,8 +148,8 @@ __device__ __forceinline__ float ubyte(uint32_t x, int j) { return (float)((x >>
 #ifndef TRX_PACKET_CULL
 #define TRX_PACKET_CULL 1
 #endif
-#ifndef TRX_FRAME_EARLY
-#define TRX_FRAME_EARLY 0
+#ifndef TRX_PACKET_CULL_LITERAL
+#define TRX_PACKET_CULL_LITERAL 1
 #endif
 #ifndef TRX_PACKET_CULL_TLAS
 #define TRX_PACKET_CULL_TLAS 1
@@ -295,12 +295,17 @@ __device__ __forceinline__ uint32_t node_intersect_dec(const Ray &r, float max_d
 // wave.  This function is the per-ray test of the children that remain (`keep`, wave-uniform, bit c = child c): the
 // operations of node_intersect_dec on the same operands, child by child in a scalar loop; a child left out would have
 // contributed nothing to the mask.  keep = 0xff: all eight (a wave whose rays do not qualify for the packet test).
+//   The literal-division variants (NODE bit 0 clear) take part where a step's rays all take both division shortcuts
+// (shortcut level 2: a = e RN(1/d) as here, b = RN(c / d) by div_by_rcp).  RN(c / d) is within 3 x 2^-24 (relative) of
+// RN(c RN(1/d)), the value the bounds are computed from, so the packet test widens the b interval by 2^-21 of its ends'
+// magnitudes (nothing is near the subnormals there: the level-2 flags keep |c| in 2^-60 .. 2^60 or zero, and a zero c gives
+// a zero b on both sides); a is the same product in both variants.
 struct NodeFrame {
     float ax, ay, az, bx, by, bz;
 };
 template <int NODE>
-__device__ __forceinline__ NodeFrame node_frame(const Ray &r, const uint4 n0) {
-    TRX_NODE_FRAME(r, n0, 0)
+__device__ __forceinline__ NodeFrame node_frame(const Ray &r, const uint4 n0, const int pow2) {
+    TRX_NODE_FRAME(r, n0, pow2)
     return NodeFrame{ax, ay, az, bx, by, bz};
 }
 template <int NODE>
