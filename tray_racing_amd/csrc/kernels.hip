@@ -815,7 +815,7 @@ int trace_grid_size(int device, int mode, bool tlas, uint32_t sem, bool count) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
     // Every product variant is held to <= 128 VGPRs without scratch (tests/test_kernel_resources.py) and owns the same
-    // kLdsBytesPerWave of LDS, so all of them fit four waves to a SIMD (16 to a CU: 16 x 10 176 B of the 160 KB): the
+    // kLdsBytesPerWave of LDS, so all of them fit four waves to a SIMD (16 to a CU: 16 x 10 240 B = the 160 KB exactly): the
     // grid sized from one variant per TLAS flavour is resident for every variant, whatever the workgroup shape
     int per_cu = tlas ? occupancy_one<kModePrimary, true, 1, false, false>() : occupancy_one<kModePrimary, false, 1, false, false>();
     if (per_cu <= 0) per_cu = 8;
