@@ -30,6 +30,7 @@ assets/scenes/bistro.ron.
 import argparse
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
@@ -75,6 +76,33 @@ def baseline_metric():
         return "Mrays/s primary rays, Bistro 1920×1080 CWBVH, 1/2/4/8 MI355X"
 
 
+def build_stamp():
+    """What produced this line: a hash of the library that ran (tray_racing_amd/libtrx.so travels to the GPU box as built),
+    of this file, and the commit the library was built at (`make` writes tray_racing_amd/.build_id where git is available -
+    the GPU box's snapshot has no .git).  tests/test_bench_contract.py holds the committed lines of a round to ONE library."""
+    def sha16(path):
+        try:
+            h = hashlib.sha256()
+            with open(path, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 20), b""):
+                    h.update(blk)
+            return h.hexdigest()[:16]
+        except OSError:
+            return None
+    lib_path = os.environ.get("TRX_LIB") or os.path.join(ROOT, "tray_racing_amd", "libtrx.so")
+    head = None
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:  # noqa: BLE001
+        head = None
+    built_at = None
+    try:
+        built_at = open(os.path.join(ROOT, "tray_racing_amd", ".build_id")).read().strip() or None
+    except OSError:
+        pass
+    return {"lib_sha16": sha16(lib_path), "bench_py_sha16": sha16(os.path.abspath(__file__)), "git_head": head, "lib_built_at": built_at}
+
+
 def usable_cores():
     """Cores this process may actually use: CPU affinity capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0))
@@ -104,6 +132,18 @@ def parse():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--scene", default="bistro")
+    ap.add_argument("--input", default="", help="a scene file of the reference (assets/scenes/<name>.ron) or a model (.obj / .json "
+                                                 "triangle list) instead of the procedural stand-in: `data` becomes \"real\"; the "
+                                                 "camera comes from the scene file (a bare model uses --scene's camera)")
+    ap.add_argument("--builder", default="preset", choices=["preset", "ploc_gpu"],
+                    help="preset: binned-SAH BVH2 -> reinsertion -> collapse under --preset (the default); ploc_gpu: the "
+                         "reference-default ploc_cwbvh pipeline (BvhBuildParams of src/main.rs:571-585) with its stages on the GPU")
+    ap.add_argument("--no-scene-cache", action="store_true",
+                    help="N > 1: every rank builds the scene itself (default: rank 0 builds with all cores and the others read "
+                         "its flat buffers from the temporary directory)")
+    ap.add_argument("--setup-only", action="store_true",
+                    help="N > 1 rehearsal without a GPU: rendezvous, scene build / cache hand-over, gather geometry, then one "
+                         "JSON line with the per-rank set-up times (tests/test_dist_gloo.py runs it at world 8)")
     ap.add_argument("--tris", type=int, default=0, help="0 = the scene's reference triangle count")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -250,9 +290,12 @@ def main():
     lib.trx_set_kernel_variant(int(args.kernel_variant, 0))
     if args.dist_backend == "gloo":
         local_rank = 0  # test mode: every rank drives GPU 0
-    if lib.trx_device_count() <= local_rank:
-        raise SystemExit("no HIP device %d (libtrx.so has no CPU fallback)" % local_rank)
-    torch.cuda.set_device(local_rank)
+    if not args.setup_only:
+        if lib.trx_device_count() <= local_rank:
+            raise SystemExit("no HIP device %d (libtrx.so has no CPU fallback)" % local_rank)
+        torch.cuda.set_device(local_rank)
+    elif world == 1 or args.dist_backend != "gloo":
+        raise SystemExit("--setup-only rehearses the N > 1 set-up on CPUs: it needs --gpus N > 1 and --dist-backend gloo")
     if world > 1:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -261,12 +304,90 @@ def main():
 
     w, h = args.width, args.height
     threads = max(1, usable_cores() // world)
-    verts, counts = T.gen_scene(args.scene, args.tris, 1)
-    t0 = time.time()
-    flat = T.flat_build(verts, counts, use_tlas=False, threads=threads, preset=args.preset)
-    build_s = time.time() - t0
-    eye, look, fov = T.scene_camera(args.scene)
+    t_setup0 = time.time()
+
+    def load_input():
+        """(verts, counts, camera) of --input or of the procedural stand-in."""
+        if args.input:
+            if args.input.endswith(".ron"):
+                v, c, e, l, f = T.load_scene(args.input)
+                return v, c, (e, l, f)
+            v, c = T.load_meshs(args.input)
+            return v, c, T.scene_camera(args.scene)
+        v, c = T.gen_scene(args.scene, args.tris, 1)
+        return v, c, T.scene_camera(args.scene)
+
+    def build_flat(v, c, nthreads):
+        if args.builder == "ploc_gpu":
+            try:
+                lib.trx_set_build_device(local_rank)
+                lib.trx_set_build_reinsertion_batches(1)
+                lib.trx_set_build_reinsertion(0.02, 8)   # (the ratio comes from the build parameters: 0.15; 8 iterations)
+                return T.flat_build_params(v, c, T.build_params(), use_tlas=False, threads=nthreads)
+            finally:
+                lib.trx_set_build_device(-1)
+                lib.trx_set_build_reinsertion_batches(0)
+                lib.trx_set_build_preset(args.preset.encode())
+        return T.flat_build(v, c, use_tlas=False, threads=nthreads, preset=args.preset)
+
+    stamp = build_stamp()
+    verts = counts = None
+    scene_cache = "off"
+    if world == 1 or args.no_scene_cache:
+        verts, counts, (eye, look, fov) = load_input()
+        t0 = time.time()
+        flat = build_flat(verts, counts, threads)
+        build_s = time.time() - t0
+    else:
+        # N > 1: ONE build, by rank 0 on every core this job may use (eight identical builds on an eighth of the cores each
+        # is what rounds 1-5 did), handed to the other ranks as flat buffers in the temporary directory of the node - keyed
+        # by input, builder and library, so the next run of the same job on this node (the driver goes N = 2, 4, 8) finds it
+        ident = json.dumps([args.input or args.scene, os.path.getmtime(args.input) if args.input else 0, args.tris, args.preset,
+                            args.builder, stamp["lib_sha16"]])
+        cdir = os.path.join(tempfile.gettempdir(), "trx_bench_scene_" + hashlib.sha256(ident.encode()).hexdigest()[:20])
+        build_s = 0.0
+        if rank == 0:
+            if os.path.exists(os.path.join(cdir, "meta.json")):
+                scene_cache = "hit"
+            else:
+                verts, counts, cam = load_input()
+                t0 = time.time()
+                flat0 = build_flat(verts, counts, usable_cores())
+                build_s = time.time() - t0
+                tmp = tempfile.mkdtemp(prefix="trx_bench_scene_tmp_", dir=tempfile.gettempdir())
+                np.save(os.path.join(tmp, "nodes.npy"), flat0.nodes)
+                np.save(os.path.join(tmp, "tri_verts.npy"), flat0.tri_verts)
+                np.save(os.path.join(tmp, "instance_offsets.npy"), flat0.instance_offsets)
+                json.dump({"tlas_start": int(flat0.tlas_start), "camera": [list(map(float, cam[0])), list(map(float, cam[1])), float(cam[2])],
+                           "build_seconds": build_s}, open(os.path.join(tmp, "meta.json"), "w"))
+                try:
+                    os.replace(tmp, cdir)
+                except OSError:   # another job of the same kind got there first: its copy is as good
+                    shutil.rmtree(tmp, ignore_errors=True)
+                scene_cache = "built"
+                del flat0
+        dist.barrier()
+        meta = json.load(open(os.path.join(cdir, "meta.json")))
+        flat = T.FlatScene(np.load(os.path.join(cdir, "nodes.npy")), np.load(os.path.join(cdir, "tri_verts.npy")),
+                           np.load(os.path.join(cdir, "instance_offsets.npy")), meta["tlas_start"], np.zeros(0, np.uint32), np.zeros(1, np.uint32))
+        eye, look, fov = meta["camera"]
+        if rank != 0:
+            scene_cache = "read"
     view = T.view_from_camera(eye, look, fov, w, h)
+    if args.setup_only:
+        # the rehearsal of the N-rank set-up on hosts without a GPU: the gather geometry for this world, then the times
+        fg = D.FrameGather(w, h, rank, world, "cpu", batch=args.gather_batch if args.gather_batch > 0 else 8)
+        fg.prepare(min(fg.batch, args.steps), args.steps % fg.batch)
+        mine = [time.time() - t_setup0, build_s, float(flat.n_nodes), float(flat.n_tris)]
+        allv = [None] * world
+        dist.all_gather_object(allv, mine)
+        if rank == 0:
+            print(json.dumps({"setup_only": True, "n_gpus": world, "rccl_world": dist.get_world_size(), "scene_cache": scene_cache,
+                              "setup_seconds": [round(x[0], 2) for x in allv], "build_seconds": [round(x[1], 2) for x in allv],
+                              "nodes": [int(x[2]) for x in allv], "tris": [int(x[3]) for x in allv], "records_per_rank": fg.records,
+                              "build": stamp}), flush=True)
+        dist.destroy_process_group()
+        return
     scene = T.Scene(flat, device=local_rank)
 
     shards = max(world, args.sim_shards)
@@ -282,8 +403,12 @@ def main():
     # de-interleave; `streams` batches are in flight, so a gather overlaps the tracing of other batches.
     F = 1 if world == 1 else (args.gather_batch if args.gather_batch > 0 else 8)
     if world > 1 and args.gather == "abi" and args.dist_backend == "nccl":
-        # one communicator per stream's buffer (RCCL orders the collectives of a communicator on its stream)
-        fgs = [D.AbiFrameGather.from_process_group(w, h, torch.device("cuda", local_rank), batch=F) for _ in range(n_streams)]
+        # ONE communicator per rank: the streams' buffers share it, their collectives chained by an event (a communicator's
+        # collectives must be issued in one order on every rank; the batches are dealt to the streams in that order anyway).
+        # Rounds 1-5 created one communicator per stream - eight per rank at N = 8 - for an overlap of gathers that are
+        # ~50 us each: never measured, and eight times the set-up.
+        fg0 = D.AbiFrameGather.from_process_group(w, h, torch.device("cuda", local_rank), batch=F)
+        fgs = [fg0] + [D.AbiFrameGather.sharing(fg0) for _ in range(n_streams - 1)]
     elif world > 1 and args.gather == "abi":
         # test mode (gloo): the shards are staged through host memory below, the frames are assembled by the ABI's kernel
         fgs = [D.AbiFrameGather.without_communicator(w, h, rank, world, torch.device("cuda", local_rank), batch=F)
@@ -397,6 +522,7 @@ def main():
     sync_all()
     run_frames(n_streams * (1 if world == 1 else F), [])
     sync_all()
+    setup_s = time.time() - t_setup0   # scene (generated / loaded / built / read), upload, communicators, first frames
     if args.wake_frames > 0:   # bring the GPU out of its idle clocks (see --wake-frames); reported in config.wake_frames
         run_frames(args.wake_frames, [])
         sync_all()
@@ -481,6 +607,14 @@ def main():
         allk = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allk, mine)
         kernel_ms_ranks = [float(x[0]) for x in allk]
+    setup_ranks, build_ranks, cache_ranks = [setup_s], [build_s], [scene_cache]
+    if world > 1:
+        allv = [None] * world
+        dist.all_gather_object(allv, [setup_s, build_s, scene_cache, time.time() - t_setup0])
+        setup_ranks, build_ranks, cache_ranks = [x[0] for x in allv], [x[1] for x in allv], [x[2] for x in allv]
+        wall_ranks = [x[3] for x in allv]
+    else:
+        wall_ranks = [time.time() - t_setup0]
     rays_per_step = st.n_rays if args.sim_shards > 1 else n_rays_total
     value = rays_per_step * args.steps / elapsed / 1e6
     kernel_ms = region_kernel_ms if region_kernel_ms is not None else sum(launch_ms) / len(launch_ms)
@@ -488,9 +622,62 @@ def main():
     out = None
     legs = {}
     if rank == 0 and world == 1 and args.sim_shards == 1 and not args.no_legs:
-        # (a leg that fails - a scene that does not fit, a build stage that errors - must not take the headline with it)
-        try:
-            s0 = streams[0]
+        ctx = {}  # what later legs need of earlier ones (the bench frame's primary hits on the device, ...)
+        variant0 = int(args.kernel_variant, 0)
+
+        def run_leg(name, fn):
+            """Every leg on its own: one that fails - a scene that does not fit, a build stage that errors - leaves
+            legs[name] = {"error": ...} and neither the headline nor the legs behind it; the process-wide switches a leg may
+            have set (kernel variant, builder device / batching / preset) are put back whatever happened."""
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001
+                legs[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            finally:
+                lib.trx_set_kernel_variant(variant0)
+                lib.trx_set_build_device(-1)
+                lib.trx_set_build_reinsertion_batches(0)
+                lib.trx_set_build_preset(args.preset.encode())
+
+        def timed(fn, reps=12, skip=3):
+            """hipEvent time of fn(i) on the default stream, one call in flight: (min, mean) over `reps` after `skip`."""
+            ts = []
+            for i in range(reps + skip):
+                a, b = ev(), ev()
+                a.record()
+                fn(i)
+                b.record()
+                torch.cuda.synchronize()
+                if i >= skip:
+                    ts.append(a.elapsed_time(b))
+            return min(ts), sum(ts) / len(ts)
+
+        def fetch_vs_random(sc, n_node, n_tri, ms):
+            """north_star's "node-fetch loop against a MEASURED roofline" for an incoherent pass: what the pass asks for
+            per second (counted node steps x 80 B + triangle tests x 48 B over its kernel time) against what this GPU
+            serves when every lane of the same grid fetches UNIFORMLY RANDOM nodes and triangle records of the same
+            scene in the same proportion and does nothing else (trx_debug_fetch_rate).  Not an upper bound: a walk's
+            upper tree levels stay in L1 / L2 and a leaf's triangles share lines, the probe's fetches do neither - a
+            ratio above 1 says the pass runs beyond the no-locality rate of the memory system, i.e. on its caches."""
+            nps, tps = sc.fetch_rate(tris_per_node=n_tri / max(n_node, 1))
+            rnd = NODE_BYTES * nps + TRI_BYTES * tps
+            ach = (NODE_BYTES * n_node + TRI_BYTES * n_tri) / (ms * 1e-3)
+            return {"requested_gbs": round(ach / 1e9, 1), "random_fetch_gbs": round(rnd / 1e9, 1), "ratio": round(ach / rnd, 3),
+                    "nodes_per_s_g": round(n_node / (ms * 1e-3) / 1e9, 2), "tris_per_s_g": round(n_tri / (ms * 1e-3) / 1e9, 2),
+                    "random_nodes_per_s_g": round(nps / 1e9, 2), "random_tris_per_s_g": round(tps / 1e9, 2)}
+
+        def primary_hits():
+            """The bench frame's primary hit records on the device (shared by the AO legs) and how many of them are hits."""
+            if "d_prim" not in ctx:
+                d = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
+                scene.trace_primary_dev(view, w, h, d.data_ptr(), sem=args.sem)
+                torch.cuda.synchronize()
+                ctx["d_prim"] = d
+                ctx["n_ao"] = int(((d & 0xffffffff) != 0x7f800000).sum().item())   # low word = t bits; +inf = miss
+                ctx["d_ao"] = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
+            return ctx["d_prim"], ctx["d_ao"], ctx["n_ao"]
+
+        def leg_reference_protocol():
             # (a) the reference's protocol: 3 passes x [3 discarded + 20 frames], hipEvent pair per frame, min and mean
             passes = [scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
             legs["reference_protocol"] = {
@@ -498,27 +685,29 @@ def main():
                 "min_ms": round(sum(p[0] for p in passes) / 3, 4), "mean_ms": round(sum(p[1] for p in passes) / 3, 4),
                 "mrays_at_min": round(n_rays_total / (sum(p[0] for p in passes) / 3) / 1e3, 1),
             }
+
+        def leg_cold_order():
             # (b) tile-order feedback off: what the first frame of a geometry (or a caller that never repeats one) gets
             lib.trx_set_kernel_variant(VARIANT_COLD)
             cmin, cmean = scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20)
-            lib.trx_set_kernel_variant(0)
             legs["cold_order_ms"] = {"min": round(cmin, 4), "mean": round(cmean, 4)}
+
+        def leg_sem_hlsl():
             # (c) the literal HLSL arithmetic (per-node IEEE divides, tt <= t)
             hmin, hmean = scene.bench_primary(view, w, h, sem=0, warmup=3, frames=20)
             legs["sem_hlsl_ms"] = {"min": round(hmin, 4), "mean": round(hmean, 4)}
+
+        def leg_first_frame():
             # (c') every frame runs as the first frame of its image geometry (natural order while its tiles are measured; the
             #      probe pass that once predicted an order here was measured and removed)
             lib.trx_set_kernel_variant(VARIANT_CUT)
             fmin, fmean = scene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20)
-            lib.trx_set_kernel_variant(0)
             legs["first_frame_ms"] = {"min": round(fmin, 4), "mean": round(fmean, 4)}
+
+        def leg_ao_pass():
             # (c") the AO pass over this frame's primary hits (the reference's second ray per pixel, rt_gpu_software.hlsl:105-128):
             #      one cosine-weighted ray per primary hit, a new noise seed every pass; default stream, hipEvents per launch
-            d_prim = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
-            d_ao = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
-            scene.trace_primary_dev(view, w, h, d_prim.data_ptr(), sem=args.sem)
-            torch.cuda.synchronize()
-            n_ao = int(((d_prim & 0xffffffff) != 0x7f800000).sum().item())   # low word = t bits; +inf = miss
+            d_prim, d_ao, n_ao = primary_hits()
             ao_ev = []
             for k in range(3 + 12):
                 a, b = ev(), ev()
@@ -530,23 +719,14 @@ def main():
             at = [a.elapsed_time(b) for a, b in ao_ev][3:]
             legs["ao_pass_ms"] = {"rays": n_ao, "frames": len(at), "min": round(min(at), 4), "mean": round(sum(at) / len(at), 4),
                                   "mrays_at_mean": round(n_ao / (sum(at) / len(at)) / 1e3, 1)}
-
-            def fetch_vs_random(sc, n_node, n_tri, ms):
-                """north_star's "node-fetch loop against a MEASURED roofline" for an incoherent pass: what the pass asks for
-                per second (counted node steps x 80 B + triangle tests x 48 B over its kernel time) against what this GPU
-                serves when every lane of the same grid fetches UNIFORMLY RANDOM nodes and triangle records of the same
-                scene in the same proportion and does nothing else (trx_debug_fetch_rate).  Not an upper bound: a walk's
-                upper tree levels stay in L1 / L2 and a leaf's triangles share lines, the probe's fetches do neither - a
-                ratio above 1 says the pass runs beyond the no-locality rate of the memory system, i.e. on its caches."""
-                nps, tps = sc.fetch_rate(tris_per_node=n_tri / max(n_node, 1))
-                rnd = NODE_BYTES * nps + TRI_BYTES * tps
-                ach = (NODE_BYTES * n_node + TRI_BYTES * n_tri) / (ms * 1e-3)
-                return {"requested_gbs": round(ach / 1e9, 1), "random_fetch_gbs": round(rnd / 1e9, 1), "ratio": round(ach / rnd, 3),
-                        "nodes_per_s_g": round(n_node / (ms * 1e-3) / 1e9, 2), "tris_per_s_g": round(n_tri / (ms * 1e-3) / 1e9, 2),
-                        "random_nodes_per_s_g": round(nps / 1e9, 2), "random_tris_per_s_g": round(tps / 1e9, 2)}
             ao_st = scene.count_ao(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=0, ao_eps=0.01)
+            legs["ao_pass_ms"]["nodes_per_ray"] = round(int(ao_st.n_node) / max(n_ao, 1), 2)
+            legs["ao_pass_ms"]["tris_per_ray"] = round(int(ao_st.n_tri) / max(n_ao, 1), 2)
             legs["ao_pass_ms"]["fetch_vs_random"] = fetch_vs_random(scene, int(ao_st.n_node), int(ao_st.n_tri), min(at))
+
+        def leg_random_rays():
             # random rays: origins spread over the scene's box, uniformly random directions - incoherent by construction
+            _, d_ao, _ = primary_hits()
             rng_r = np.random.default_rng(5)
             tv = flat.tri_verts.reshape(-1, 3)
             blo, bhi = tv.min(axis=0), tv.max(axis=0)
@@ -571,41 +751,53 @@ def main():
                                       "nodes_per_ray": round(int(rr_st.n_node) / n_rays_total, 2),
                                       "tris_per_ray": round(int(rr_st.n_tri) / n_rays_total, 2),
                                       "fetch_vs_random": fetch_vs_random(scene, int(rr_st.n_node), int(rr_st.n_tri), min(rt))}
-            del d_rr, rr, rd, tv
 
-            def timed(fn, reps=12, skip=3):
-                """hipEvent time of fn(i) on the default stream, one call in flight: (min, mean) over `reps` after `skip`."""
-                ts = []
-                for i in range(reps + skip):
-                    a, b = ev(), ev()
-                    a.record()
-                    fn(i)
-                    b.record()
-                    torch.cuda.synchronize()
-                    if i >= skip:
-                        ts.append(a.elapsed_time(b))
-                return min(ts), sum(ts) / len(ts)
+        def leg_ao_4spp():
             # (c"') BASELINE.json's "4 spp" = AO frames with seeds 0..3 (src/rt_cpu/rt_cpu.rs:95-97): ONE launch
             #       (trx_trace_ao_batch_dev) - the four passes share one drain
+            d_prim, _, n_ao = primary_hits()
             d_ao4 = torch.empty(4 * n_rays_total, dtype=torch.int64, device="cuda")
             a4 = timed(lambda i: scene.trace_ao_batch_dev(view, w, h, d_prim.data_ptr(), d_ao4.data_ptr(), n_rays_total, 4,
                                                           sem=args.sem, frame0=4 * i, ao_eps=0.01))
             legs["ao_4spp_ms"] = {"rays": 4 * n_ao, "launches": 1, "min": round(a4[0], 4), "mean": round(a4[1], 4),
                                   "mrays_at_mean": round(4 * n_ao / a4[1] / 1e3, 1)}
+
+        def leg_frame_primary_ao():
             # (c"") the reference-style frame, device-resident: primary + AO as two launches back to back on one stream, and as
             #       ONE launch (trx_trace_frame_dev: the reference's single dispatch, a lane whose primary ray hits goes on as
             #       the pixel's AO ray) - same records either way
+            d_prim, d_ao, _ = primary_hits()
             f2 = timed(lambda i: (scene.trace_primary_dev(view, w, h, d_prim.data_ptr(), sem=args.sem),
                                   scene.trace_ao_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=i % 4, ao_eps=0.01)))
             f1 = timed(lambda i: scene.trace_frame_dev(view, w, h, d_prim.data_ptr(), d_ao.data_ptr(), sem=args.sem, frame=i % 4, ao_eps=0.01))
             legs["frame_primary_ao_ms"] = {"two_launches": {"min": round(f2[0], 4), "mean": round(f2[1], 4)},
                                            "one_launch": {"min": round(f1[0], 4), "mean": round(f1[1], 4)}}
-            del d_prim, d_ao, d_ao4
+
+        def frame_loop_leg(sc, vw, frames=48):
+            """The reference's frame loop (src/rt_gpu/rt_gpu_software.rs:271-361: primary pass, AO pass, next frame), device
+            resident, `frames` frames with the noise seed advancing (--animate): serial on one stream, and with frame i's AO
+            pass on a second stream under frame i + 1's primary pass (trx_frame_loop); the last frame's records of both modes
+            are compared."""
+            sc.frame_loop(vw, w, h, sem=args.sem, frames=8, overlap=False)          # (the loop's two launch slots learn their orders)
+            sc.frame_loop(vw, w, h, sem=args.sem, frames=8, overlap=True)
+            ser = [sc.frame_loop(vw, w, h, sem=args.sem, frames=frames, overlap=False, fetch=(k == 0)) for k in range(3)]
+            ovl = [sc.frame_loop(vw, w, h, sem=args.sem, frames=frames, overlap=True, fetch=(k == 0)) for k in range(3)]
+            same = bool((ser[0][1] == ovl[0][1]).all() and (ser[0][2] == ovl[0][2]).all())
+            s_ms, o_ms = min(x[0] for x in ser) / frames, min(x[0] for x in ovl) / frames
+            return {"frames": frames, "serial_ms_per_frame": round(s_ms, 4), "overlapped_ms_per_frame": round(o_ms, 4),
+                    "gain": round(1.0 - o_ms / s_ms, 4), "records_identical": same}
+
+        def leg_frame_loop_overlapped():
+            legs["frame_loop_overlapped_ms"] = frame_loop_leg(scene, view)
+
+        def leg_hairball():
             # (c5) BASELINE.json configs[3] itself: the hairball-class stand-in, primary frame, one AO pass, and the 4 spp in one launch
-            if args.scene == "bistro" and args.tris == 0:
-                hv, hc = T.gen_scene("hairball", 0, 1)
-                hflat = T.flat_build(hv, hc, use_tlas=False, threads=threads, preset=args.preset)
-                hscene = T.Scene(hflat, device=local_rank)
+            if not (args.scene == "bistro" and args.tris == 0 and not args.input):
+                return
+            hv, hc = T.gen_scene("hairball", 0, 1)
+            hflat = T.flat_build(hv, hc, use_tlas=False, threads=threads, preset=args.preset)
+            hscene = T.Scene(hflat, device=local_rank)
+            try:
                 he, hl, hf = T.scene_camera("hairball")
                 hview = T.view_from_camera(he, hl, hf, w, h)
                 hp = torch.empty(n_rays_total, dtype=torch.int64, device="cuda")
@@ -626,8 +818,12 @@ def main():
                     "ao_4spp_one_launch_ms": {"min": round(h4[0], 4), "mean": round(h4[1], 4),
                                               "mrays_at_mean": round(4 * h_ao / h4[1] / 1e3, 1)},
                 }
+                del hp, ha
+                legs["hairball_4spp"]["frame_loop"] = frame_loop_leg(hscene, hview, frames=24)
+            finally:
                 hscene.close()
-                del hv, hc, hflat, hp, ha
+
+        def leg_pipelined():
             # (d) frames overlapped on 4 streams (independent frames; the tail of one overlaps the next)
             ps = [torch.cuda.Stream() for _ in range(4)]
             pbuf = [torch.empty(n_rays_total, dtype=torch.int64, device="cuda") for _ in ps]
@@ -643,7 +839,12 @@ def main():
             torch.cuda.synchronize()
             legs["pipelined_mrays"] = round(n_rays_total * 200 / (time.perf_counter() - tp) / 1e6, 1)
             legs["pipelined_frames_in_flight"] = 4
-            # (e) measured HBM ceiling: device-to-device copy of 2 GiB (1 GiB read + 1 GiB written per pass)
+
+        def leg_hbm_copy():
+            # (e) measured HBM ceiling: the float4 copy kernel of the platform guide over 2 x 1 GiB (read + written bytes per
+            #     second, trx_debug_copy_rate), and hipMemcpyDtoD of the same size beside it (what rounds 1-5 quoted: it runs
+            #     about a fifth below the kernel on this part)
+            legs["hbm_copy_gbs"] = round(T.copy_rate(local_rank, 1 << 30, reps=5) / 1e9, 1)
             n64 = (1 << 30) // 8
             src = torch.empty(n64, dtype=torch.int64, device="cuda").fill_(1)
             dst = torch.empty_like(src)
@@ -655,8 +856,9 @@ def main():
                 dst.copy_(src)
             e1.record()
             torch.cuda.synchronize()
-            legs["hbm_copy_gbs"] = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-            del src, dst
+            legs["hbm_memcpy_dtod_gbs"] = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+        def leg_moving_camera():
             # (h) a camera that moves: every frame a new view (the eye and its target advance 5 cm along the street per frame),
             #     the tile order learnt from the PREVIOUS view; what a renderer with temporal coherence gets, between the
             #     static-camera figure and the cold one
@@ -673,13 +875,16 @@ def main():
             torch.cuda.synchronize()
             mt = [a.elapsed_time(b) for a, b in mv][8:]
             legs["moving_camera_ms"] = {"step_m": 0.05, "frames": len(mt), "min": round(min(mt), 4), "mean": round(sum(mt) / len(mt), 4)}
-            del mbuf
+
+        def leg_dense_scene():
             # (g) second headline row: the denser bistro-class stand-in built to the reference's PROFILE_RT legend
             #     (about 30 node visits / 15 triangle tests per primary ray, rt_gpu_software.hlsl:95,102), same protocol
-            if args.scene == "bistro" and args.tris == 0:
-                dv, dc = T.gen_scene("bistro_dense", 0, 1)
-                dflat = T.flat_build(dv, dc, use_tlas=False, threads=threads, preset=args.preset)
-                dscene = T.Scene(dflat, device=local_rank)
+            if not (args.scene == "bistro" and args.tris == 0 and not args.input):
+                return
+            dv, dc = T.gen_scene("bistro_dense", 0, 1)
+            dflat = T.flat_build(dv, dc, use_tlas=False, threads=threads, preset=args.preset)
+            dscene = T.Scene(dflat, device=local_rank)
+            try:
                 dst = dscene.count_primary(view, w, h, sem=args.sem)
                 dp = [dscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
                 legs["dense_scene"] = {
@@ -688,72 +893,72 @@ def main():
                     "min_ms": round(sum(p[0] for p in dp) / 3, 4), "mean_ms": round(sum(p[1] for p in dp) / 3, 4),
                     "mrays_at_mean": round(n_rays_total / (sum(p[1] for p in dp) / 3) / 1e3, 1),
                 }
+            finally:
                 dscene.close()
-                del dv, dc, dflat
-            # (i) the same frame over a tree from the ploc_cwbvh pipeline with the reference's command-line defaults for
-            #     BvhBuildParams (src/main.rs:85-124,571-585: search distance 14, depth threshold 2, 64-bit codes, reinsertion
-            #     0.15, 3 primitives per leaf) - obvhs' own values for the preset name are not in the reference tree, so the
-            #     headline runs this library's medium_build; this leg says what the other builder's tree costs to traverse
-            if args.scene == "bistro" and args.tris == 0:
-                tp0 = time.time()
-                pflat = T.flat_build_params(verts, counts, T.build_params(), use_tlas=False, threads=threads)
-                pbuild = time.time() - tp0
-                pscene = T.Scene(pflat, device=local_rank)
+
+        def tree_leg(pflat, pbuild, params):
+            pscene = T.Scene(pflat, device=local_rank)
+            try:
                 pst = pscene.count_primary(view, w, h, sem=args.sem)
                 pp = [pscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
-                legs["ploc_pipeline"] = {
-                    "params": "reference command-line defaults (ploc_search_distance 14, search_depth_threshold 2, "
-                              "sort_precision 64, reinsertion_batch_ratio 0.15, max_prims_per_leaf 3)",
-                    "build_seconds": round(pbuild, 2), "nodes": int(pflat.n_nodes),
+                return {
+                    "params": params, "build_seconds": round(pbuild, 2), "nodes": int(pflat.n_nodes),
                     "nodes_per_ray": round(pst.n_node / pst.n_rays, 2), "tris_per_ray": round(pst.n_tri / pst.n_rays, 2),
                     "min_ms": round(sum(q[0] for q in pp) / 3, 4), "mean_ms": round(sum(q[1] for q in pp) / 3, 4),
                     "mrays_at_mean": round(n_rays_total / (sum(q[1] for q in pp) / 3) / 1e3, 1),
                 }
+            finally:
                 pscene.close()
-                del pflat
-                # (i') the same pipeline with its GPU stages (round 5): Morton sort + PLOC rounds, and the reinsertion pass with one
-                #      batch per iteration - candidates chosen (area keys + radix sort) and searched as kernels, one thread per
-                #      search, the moves chosen and applied there too - and the BVH2 -> CWBVH collapse + node encoding as kernels; every stage
-                #      byte-identical to its host twin (tests/test_gpu_builder.py)
-                try:
-                    T.load().trx_set_build_device(local_rank)
-                    T.load().trx_set_build_reinsertion_batches(1)
-                    T.load().trx_set_build_reinsertion(0.02, 8)   # (the ratio comes from the build parameters: 0.15; 8 iterations)
-                    tg0 = time.time()
-                    gflat = T.flat_build_params(verts, counts, T.build_params(), use_tlas=False, threads=threads)
-                    gbuild = time.time() - tg0
-                finally:
-                    T.load().trx_set_build_device(-1)
-                    T.load().trx_set_build_reinsertion_batches(0)
-                    T.load().trx_set_build_preset(args.preset.encode())
-                gscene = T.Scene(gflat, device=local_rank)
-                gst = gscene.count_primary(view, w, h, sem=args.sem)
-                gp = [gscene.bench_primary(view, w, h, sem=args.sem, warmup=3, frames=20) for _ in range(3)]
-                legs["ploc_pipeline_gpu_stages"] = {
-                    "params": "the same build parameters; reinsertion in 8 whole-iteration batches (ratio 0.15); BVH2 stage, "
-                              "reinsertion (searches and moves) and collapse + encoding on the GPU",
-                    "build_seconds": round(gbuild, 2), "nodes": int(gflat.n_nodes),
-                    "nodes_per_ray": round(gst.n_node / gst.n_rays, 2), "tris_per_ray": round(gst.n_tri / gst.n_rays, 2),
-                    "min_ms": round(sum(q[0] for q in gp) / 3, 4), "mean_ms": round(sum(q[1] for q in gp) / 3, 4),
-                    "mrays_at_mean": round(n_rays_total / (sum(q[1] for q in gp) / 3) / 1e3, 1),
-                }
-                gscene.close()
-                del gflat
+
+        def leg_ploc_pipeline():
+            # (i) the same frame over a tree from the ploc_cwbvh pipeline with the reference's command-line defaults for
+            #     BvhBuildParams (src/main.rs:85-124,571-585: search distance 14, depth threshold 2, 64-bit codes, reinsertion
+            #     0.15, 3 primitives per leaf) - obvhs' own values for the preset name are not in the reference tree, so the
+            #     headline runs this library's medium_build; this leg says what the other builder's tree costs to traverse
+            if not (args.scene == "bistro" and args.tris == 0 and not args.input):
+                return
+            tp0 = time.time()
+            pflat = T.flat_build_params(verts, counts, T.build_params(), use_tlas=False, threads=threads)
+            legs["ploc_pipeline"] = tree_leg(pflat, time.time() - tp0,
+                                             "reference command-line defaults (ploc_search_distance 14, search_depth_threshold 2, "
+                                             "sort_precision 64, reinsertion_batch_ratio 0.15, max_prims_per_leaf 3)")
+
+        def leg_ploc_pipeline_gpu_stages():
+            # (i') the same pipeline with its GPU stages (round 5): Morton sort + PLOC rounds, and the reinsertion pass with one
+            #      batch per iteration - candidates chosen (area keys + radix sort) and searched as kernels, one thread per
+            #      search, the moves chosen and applied there too - and the BVH2 -> CWBVH collapse + node encoding as kernels; every stage
+            #      byte-identical to its host twin (tests/test_gpu_builder.py)
+            if not (args.scene == "bistro" and args.tris == 0 and not args.input):
+                return
+            lib.trx_set_build_device(local_rank)
+            lib.trx_set_build_reinsertion_batches(1)
+            lib.trx_set_build_reinsertion(0.02, 8)   # (the ratio comes from the build parameters: 0.15; 8 iterations)
+            tg0 = time.time()
+            gflat = T.flat_build_params(verts, counts, T.build_params(), use_tlas=False, threads=threads)
+            gbuild = time.time() - tg0
+            legs["ploc_pipeline_gpu_stages"] = tree_leg(gflat, gbuild,
+                                                        "the same build parameters; reinsertion in 8 whole-iteration batches (ratio 0.15); BVH2 stage, "
+                                                        "reinsertion (searches and moves) and collapse + encoding on the GPU")
+
+        def leg_no_wake():
             # (j) the timed region WITHOUT the wake frames: the GPU idles for a second (as it does while a host builds a scene),
             #     then the W warm-up steps and K timed steps run straight away, on clocks that are still coming up - what the
             #     round-3 protocol measured (profiles/r04_clock_ramp.log); one event pair around the K launches, like `value`
-            if one_pair:
-                torch.cuda.synchronize()
-                time.sleep(1.0)
-                run_frames(args.warmup, None)
-                n0, n1 = ev(), ev()
-                n0.record(streams[0])
-                run_frames(args.steps, None)
-                n1.record(streams[0])
-                torch.cuda.synchronize()
-                nw_ms = n0.elapsed_time(n1) / args.steps
-                legs["no_wake"] = {"idle_s": 1.0, "warmup": args.warmup, "steps": args.steps, "kernel_ms_mean": round(nw_ms, 4),
-                                   "mrays": round(n_rays_total / (nw_ms * 1e-3) / 1e6, 1)}
+            if not one_pair:
+                return
+            torch.cuda.synchronize()
+            time.sleep(1.0)
+            run_frames(args.warmup, None)
+            n0, n1 = ev(), ev()
+            n0.record(streams[0])
+            run_frames(args.steps, None)
+            n1.record(streams[0])
+            torch.cuda.synchronize()
+            nw_ms = n0.elapsed_time(n1) / args.steps
+            legs["no_wake"] = {"idle_s": 1.0, "warmup": args.warmup, "steps": args.steps, "kernel_ms_mean": round(nw_ms, 4),
+                               "mrays": round(n_rays_total / (nw_ms * 1e-3) / 1e6, 1)}
+
+        def leg_traverse1_threads():
             # (k) Traversable::traverse called the way the reference's CPU loop calls it (src/rt_cpu/rt_cpu.rs:35-57): 16 host
             #     threads, ONE ray per call, every call blocking for its RayHit.  Concurrent callers share launches (the
             #     per-scene combiner behind trx_traverse1); a caller still waits one GPU round trip per ray, so this is a latency
@@ -778,19 +983,35 @@ def main():
             scene.traverse_threads(t1_rays[:512], threads=16, sem=args.sem)           # (warms the launch slots)
             t1_hits, t1_s, t1_launches = scene.traverse_threads(t1_rays, threads=16, sem=args.sem)
             tb_hits, tb_ms = scene.traverse_batch(t1_rays, sem=args.sem)
+            one_hits, one_s, _ = scene.traverse_threads(t1_rays[:2000], threads=1, sem=args.sem)
             legs["traverse1_threads"] = {
                 "threads": 16, "rays": n_t1, "mrays": round(n_t1 / t1_s / 1e6, 4), "launches": t1_launches,
                 "rays_per_launch": round(n_t1 / max(t1_launches, 1), 1), "us_per_launch": round(t1_s / max(t1_launches, 1) * 1e6, 1),
-                "equals_traverse_batch": bool((t1_hits == tb_hits).all()),
+                "equals_traverse_batch": bool((t1_hits == tb_hits).all() and (one_hits == tb_hits[:2000]).all()),
                 "traverse_batch_kernel_mrays": round(n_t1 / (tb_ms * 1e-3) / 1e6, 1),
-                "note": "one blocking trx_traverse1 call per ray from 16 host threads; rate = callers in flight / GPU round trip",
+                "one_thread_mrays": round(2000 / one_s / 1e6, 4),
+                "note": "one blocking trx_traverse1 call per ray from 16 host threads (and from one)",
             }
+
+        def leg_footprint():
             # (f) compulsory footprint: distinct nodes / triangles one frame touches
             fn, ft = scene.footprint(view, w, h, sem=args.sem)
             legs["footprint"] = {"nodes": fn, "tris": ft, "bytes": NODE_BYTES * fn + TRI_BYTES * ft + HIT_BYTES * n_rays_total}
-            del s0
-        except Exception as e:  # noqa: BLE001
-            legs["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+
+        for name, fn in (("reference_protocol", leg_reference_protocol), ("cold_order_ms", leg_cold_order), ("sem_hlsl_ms", leg_sem_hlsl),
+                         ("first_frame_ms", leg_first_frame), ("ao_pass_ms", leg_ao_pass), ("random_rays_ms", leg_random_rays),
+                         ("ao_4spp_ms", leg_ao_4spp), ("frame_primary_ao_ms", leg_frame_primary_ao),
+                         ("frame_loop_overlapped_ms", leg_frame_loop_overlapped), ("hairball_4spp", leg_hairball),
+                         ("pipelined_mrays", leg_pipelined), ("hbm_copy_gbs", leg_hbm_copy), ("moving_camera_ms", leg_moving_camera),
+                         ("dense_scene", leg_dense_scene), ("ploc_pipeline", leg_ploc_pipeline),
+                         ("ploc_pipeline_gpu_stages", leg_ploc_pipeline_gpu_stages), ("no_wake", leg_no_wake),
+                         ("traverse1_threads", leg_traverse1_threads), ("footprint", leg_footprint)):
+            run_leg(name, fn)
+            ctx.pop("tmp", None)
+        ctx.clear()
+        failed = [k for k, v in legs.items() if isinstance(v, dict) and "error" in v]
+        if failed:
+            print("WARNING: bench legs failed: %s" % ", ".join(failed), file=sys.stderr)
 
     pmc, pmc_src, pmc_ms = None, None, None
     if rank == 0 and world == 1 and args.sim_shards == 1:
@@ -918,7 +1139,9 @@ def main():
             "unit": "GB/s",
             "frac": round(hbm_gbs / HBM_PEAK_GBS, 4) if hbm_gbs else None,
             "traffic": traffic,
-            "peak_measured": legs.get("hbm_copy_gbs"),
+            # the float4 copy kernel of the platform guide (read + written GB/s, trx_debug_copy_rate); hipMemcpyDtoD, which
+            # rounds 1-5 quoted here, is legs.hbm_memcpy_dtod_gbs
+            "peak_measured": legs.get("hbm_copy_gbs") if isinstance(legs.get("hbm_copy_gbs"), float) else None,
             "requested_gbs": round(req_gbs, 1),
             "bytes_per_launch": int(launch_bytes),
             "compulsory_bytes": legs.get("footprint", {}).get("bytes"),
@@ -946,7 +1169,11 @@ def main():
             # the same frame under the literal HLSL arithmetic (TRX_SEM_HLSL: per-node IEEE divides, tt <= t), the only
             # semantics the reference's tree states in full; `value` runs the CPU-path preset (TRX_SEM_CPU)
             "value_sem_hlsl": (round(n_rays_total / (legs["sem_hlsl_ms"]["mean"] * 1e-3) / 1e6, 2)
-                               if "sem_hlsl_ms" in legs else None),
+                               if "mean" in legs.get("sem_hlsl_ms", {}) else None),
+            # the same frame over the tree of the reference-default ploc_cwbvh pipeline (BvhBuildParams of src/main.rs:571-585,
+            # every stage on the GPU): what `--build ploc_cwbvh` names; `value` walks this library's --preset tree
+            "value_ploc_tree": (legs["ploc_pipeline_gpu_stages"]["mrays_at_mean"]
+                                if "mrays_at_mean" in legs.get("ploc_pipeline_gpu_stages", {}) else None),
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -956,13 +1183,17 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "real" if args.input else "synthetic",
             "config": {
-                "workload": "%s-class procedural stand-in, %d tris, %d CWBVH nodes, primary rays %dx%d "
-                            "(BASELINE.json configs[2])" % (args.scene, flat.n_tris, flat.n_nodes, w, h),
+                "workload": ("%s, %d tris, %d CWBVH nodes, primary rays %dx%d" % (os.path.basename(args.input), flat.n_tris, flat.n_nodes, w, h)
+                             if args.input else
+                             "%s-class procedural stand-in, %d tris, %d CWBVH nodes, primary rays %dx%d "
+                             "(BASELINE.json configs[2])" % (args.scene, flat.n_tris, flat.n_nodes, w, h)),
                 "semantics": "TRX_SEM_CPU" if args.sem == 3 else "bits=%d" % args.sem,
-                "builder": "binned-SAH BVH2 -> reinsertion pass -> SAH-optimal BVH8 collapse (stands in for obvhs "
-                           "ploc_cwbvh), preset %s" % args.preset,
+                "builder": ("PLOC BVH2 -> reinsertion (8 whole-iteration batches) -> SAH-optimal BVH8 collapse, the reference's "
+                            "command-line BvhBuildParams (src/main.rs:571-585), every stage on the GPU" if args.builder == "ploc_gpu" else
+                            "binned-SAH BVH2 -> reinsertion pass -> SAH-optimal BVH8 collapse (stands in for obvhs "
+                            "ploc_cwbvh), preset %s" % args.preset),
                 "parallelism": ("one GPU owns every 8x8 tile" if world == 1 else
                                 "8x8 tiles round-robin over %d ranks; hit shards (8 B/ray) all-gathered in place, %d frames "
                                 "per collective, and de-interleaved to row-major frames on every rank" % (world, F)),
@@ -972,6 +1203,7 @@ def main():
                 # untimed frames ahead of the `warmup` steps that take the GPU out of its idle clocks (--wake-frames 0: none)
                 "wake_frames": args.wake_frames,
                 "build_seconds": round(build_s, 2),
+                "scene_cache": cache_ranks[0],
                 "tile_order": "filed by the first frame of the view on the stream, then replayed unchanged (static camera, as "
                               "the reference benches); a first frame (natural order while the tiles are measured) in "
                               "legs.first_frame_ms, feedback off in legs.cold_order_ms",
@@ -979,8 +1211,15 @@ def main():
             # round 5: roofline.frac is the algorithmic fraction (issued_frac = the old figure), roofline_hbm carries the
             # measured traffic, timed-region repeats, same-protocol N = 1 figure at N > 1, no-wake leg (the round-3 / round-4
             # lines differ from each other by the wake frames: README "Bench protocol")
-            "protocol_version": 5,
+            "protocol_version": 6,
+            "build": stamp,
             "rccl_world": rccl_world,
+            # per rank: wall clock from the start of main() to the end of the set-up frames (scene generated / loaded / built
+            # or read from rank 0's copy, upload, communicators, first frames), the build's share of it, and the whole run
+            "setup_seconds": [round(x, 2) for x in setup_ranks],
+            "build_seconds": [round(x, 2) for x in build_ranks],
+            "scene_cache": cache_ranks,
+            "wall_seconds": [round(x, 2) for x in wall_ranks],
             "n1_same_protocol_mrays": round(n1_same, 2) if n1_same else None,
             "scaling_vs_same_protocol": round(value / n1_same, 4) if n1_same else None,
             "kernel_ms_mean": round(kernel_ms, 4),

@@ -370,6 +370,15 @@ int trx_trace_primary(trx_scene *scene, const trx_view *view, uint32_t width,
 int trx_trace_primary_ao(trx_scene *scene, const trx_view *view, uint32_t width,
                          uint32_t height, uint32_t semantics, uint32_t frame, float ao_eps,
                          trx_hit *out_primary, trx_hit *out_ao, float *out_ms);
+/* The frame loop of rt_gpu_software::start itself (src/rt_gpu/rt_gpu_software.rs:271-361: per RedrawRequested a
+ * primary pass and the AO pass over its hits; --animate advances the noise seed, :285-288), n_frames frames without the
+ * host in between.  overlap == 0: both passes of a frame back to back on one stream (what n_frames calls of
+ * trx_trace_primary_ao enqueue).  overlap != 0: frame i's AO pass runs on a second stream under frame i + 1's primary
+ * pass (two primary-hit buffers; same records).  out_primary / out_ao (host, may be NULL): the LAST frame's records;
+ * out_ms: hipEvent time from the first launch to the end of the last pass (per frame: / n_frames). */
+int trx_frame_loop(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height, uint32_t semantics,
+                   uint32_t frame0, int animate, float ao_eps, uint32_t n_frames, int overlap, trx_hit *out_primary,
+                   trx_hit *out_ao, float *out_ms);
 int trx_trace_rays(trx_scene *scene, const trx_ray *rays, uint64_t n_rays,
                    uint32_t semantics, trx_hit *out_hits, float *out_ms);
 /* The same with RayHit.instance_id per hit (u32 arrays, any of them may be NULL; all 0xFFFFFFFF without a TLAS).
@@ -585,6 +594,11 @@ int trx_scene_camera(const char *name, float eye[3], float look_at[3], float *fo
  * per `o`) or the JSON triangle list. */
 int trx_load_model(const char *path, float **out_verts, uint64_t *out_n_tris,
                    uint64_t **out_object_counts, uint32_t *out_n_objects);
+/* A scene file of the reference (assets/scenes/<name>.ron: model_path, camera) as src/main.rs:259-298 reads it: the
+ * camera, and the model loaded from the path the reference's rule gives (scene path and model path both relative: the
+ * model is taken relative to the scene file's great-grandparent directory, src/main.rs:271-284). */
+int trx_load_scene(const char *path, float **out_verts, uint64_t *out_n_tris, uint64_t **out_object_counts,
+                   uint32_t *out_n_objects, float eye[3], float look_at[3], float *fov_deg);
 void trx_free(void *p);
 
 #ifdef __cplusplus

@@ -62,6 +62,10 @@ int trx_debug_traverse1_threads(trx_scene *scene, const trx_ray *rays, uint64_t 
 int trx_debug_fetch_rate(trx_scene *scene, uint32_t steps, uint32_t tris_per_node_x256, double *out_nodes_per_s,
                          double *out_tris_per_s);
 
+/* Measuring aid: the streaming ceiling of this GPU's memory - a float4 copy kernel over `bytes` (read + written bytes per
+ * second, best of `reps` passes after two warm-up passes): bench.py's `roofline_hbm.peak_measured`. */
+int trx_debug_copy_rate(int device, uint64_t bytes, uint32_t reps, double *out_bytes_per_s);
+
 /* Kernel variant selection (tuning aid; 0 = default).  Returns the previous
  * value.  Variants compute identical results. */
 uint32_t trx_set_kernel_variant(uint32_t variant);

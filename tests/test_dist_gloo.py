@@ -89,22 +89,50 @@ def free_port():
     return p
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_tile_sharding_and_gather():
-    world = 2
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 8])
+def test_tile_sharding_and_gather(world):
+    """world 2, and world 8: the geometry of the first 8-GPU run (one rank per GPU of a node), every rank a process."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
     procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = sorted(q.get(timeout=240) for _ in range(world))
+    results = sorted(q.get(timeout=480) for _ in range(world))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert [r[1] for r in results] == [True, True]
-    assert [r[2] for r in results] == [2.0, 2.0]
+    assert [r[1] for r in results] == [True] * world
+    assert [r[2] for r in results] == [float(world)] * world
     assert sum(r[3] for r in results) == ((W + 7) // 8) * ((H + 7) // 8)
+
+
+@pytest.mark.timeout(900)
+def test_bench_set_up_at_world_8_without_a_gpu(tmp_path):
+    """`bench.py --gpus 8` up to the point where it needs a device (--setup-only, gloo): the rendezvous of eight ranks, ONE
+    scene build by rank 0 handed to the other seven through the node's temporary directory, the gather geometry of a
+    1920x1080 frame dealt to eight ranks - and a second run that finds rank 0's copy instead of building."""
+    import json
+    import subprocess
+    env = dict(os.environ, TMPDIR=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5",
+           "--tris", "200000", "--dist-backend", "gloo", "--setup-only"]
+    lines = []
+    for run in range(2):
+        cmd[cmd.index("--master-port") + 1] = str(free_port())
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
+    first, second = lines
+    for d in lines:
+        assert d["setup_only"] is True and d["n_gpus"] == 8 and d["rccl_world"] == 8
+        assert len(d["setup_seconds"]) == 8 and max(d["setup_seconds"]) < 240          # the driver's budget is 600 s for the whole run
+        assert len(set(d["nodes"])) == 1 and len(set(d["tris"])) == 1 and d["tris"][0] == 200000   # every rank holds the same scene
+        assert d["records_per_rank"] == ((240 * 135 + 7) // 8) * 64 and d["build"]["lib_sha16"]
+    assert first["scene_cache"] == "built" and first["build_seconds"][0] > 0 and first["build_seconds"][1:] == [0.0] * 7
+    assert second["scene_cache"] == "hit" and second["build_seconds"] == [0.0] * 8
 
 
 def test_record_index_table_covers_every_pixel_once():

@@ -856,13 +856,16 @@ def test_fixed_seed_slice_of_the_fuzzer(trx, orc):
 
 
 @pytest.mark.parametrize("world,streams,batch,extra", [(2, 2, 4, []), (4, 8, 8, ["--gather", "abi"]),
-                                                        (2, 2, 4, ["--gather", "abi", "--gather-to", "root"])])
+                                                        (2, 2, 4, ["--gather", "abi", "--gather-to", "root"]),
+                                                        (5, 8, 8, []), (5, 8, 8, ["--gather", "abi"])])
 def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path, world, streams, batch, extra):
     """bench.py's N > 1 path end to end on one GPU: `world` ranks (gloo, shard gather staged through
     host memory) trace their tile shards on device 0 in batches; the frame rank 0 ends up with is
-    checked against the oracle here.  world = 4 runs bench.py's own defaults for more than two GPUs (8 streams, 8
-    frames per gather); more ranks than that cannot share one GPU box: its process guard allows 6 processes on the
-    card, and this test process is one of them.  With `--gather abi` the frames are de-interleaved by the ABI's own
+    checked against the oracle here.  world = 4 and 5 run bench.py's own defaults for more than two GPUs (8 streams, 8
+    frames per gather: what the first 8-GPU run will use); 5 ranks is what can share one GPU box - its process guard allows 6
+    processes on the card, and this test process is one of them - the eight-rank set-up itself (rendezvous, one build
+    handed to seven ranks, gather geometry) runs on CPUs in tests/test_dist_gloo.py.  Every rank must be through set-up,
+    timed region and the same-protocol solo run within 240 s (the driver gives the whole run 600).  With `--gather abi` the frames are de-interleaved by the ABI's own
     kernel (trx_assemble_frames) from the staged shards - RCCL itself needs one GPU per rank - and `--gather-to root`
     sends them to rank 0 only."""
     import json
@@ -892,7 +895,11 @@ def test_bench_two_ranks_share_the_gpu(trx, orc, tmp_path, world, streams, batch
     assert ph["gather_to"] == ("root" if "root" in extra else "all")
     # round 5: a scaling factor is quoted against ONE rank under the same protocol (same streams, same frames per launch, no
     # gather), the timed region is repeated, and the collective's world is reported at top level
-    assert d["protocol_version"] == 5 and d["rccl_world"] == world
+    assert d["protocol_version"] == 6 and d["rccl_world"] == world and d["build"]["lib_sha16"]
+    # round 6: ONE build (rank 0, all cores), the other ranks read its flat buffers; per-rank set-up and wall clock in the line
+    assert len(d["setup_seconds"]) == world == len(d["build_seconds"]) == len(d["wall_seconds"])
+    assert d["scene_cache"][0] in ("built", "hit") and d["scene_cache"][1:] == ["read"] * (world - 1)
+    assert d["build_seconds"][1:] == [0.0] * (world - 1) and max(d["wall_seconds"]) < 240.0
     assert d["n1_same_protocol_mrays"] > 0 and d["scaling_vs_same_protocol"] == pytest.approx(d["value"] / d["n1_same_protocol_mrays"], rel=1e-2, abs=1e-4)
     rep = d["legs"]["timed_region_repeats"]
     assert rep["n"] >= 7 and rep["ms_per_step_min"] <= rep["ms_per_step_median"] <= rep["ms_per_step_max"]
@@ -991,6 +998,16 @@ def test_frame_loop_keeps_one_tile_order_per_pass_kind(trx, orc):
                 if k % 4 == 0 or 22 <= k < 36:
                     assert_hits_equal(gp, want_p, "frame loop primary, variant %d frame %d" % (variant, k))
                     assert_hits_equal(gao, want_ao, "frame loop AO, variant %d frame %d" % (variant, k))
+            # round 6: the same loop without the host between its frames (trx_frame_loop), serial on one stream and with
+            # frame i's AO pass on a second stream under frame i + 1's primary pass; the noise seed advances per frame
+            # (--animate), so the last of n frames carries seed frame0 + n - 1
+            for overlap in (False, True):
+                for n in (1, 2, 7):
+                    _, gp, gao = sc.frame_loop(view, w, h, sem=3, frames=n, frame0=4 - n, animate=True, ao_eps=0.01, overlap=overlap)
+                    assert_hits_equal(gp, want_p, "trx_frame_loop primary, variant %d overlap %d, %d frames" % (variant, overlap, n))
+                    assert_hits_equal(gao, want_ao, "trx_frame_loop AO, variant %d overlap %d, %d frames" % (variant, overlap, n))
+                _, gp, gao = sc.frame_loop(view, w, h, sem=3, frames=40, frame0=3, animate=False, ao_eps=0.01, overlap=overlap)
+                assert_hits_equal(gao, want_ao, "trx_frame_loop AO, static seed, variant %d overlap %d" % (variant, overlap))
     finally:
         lib.trx_set_kernel_variant(0)
         sc.close()

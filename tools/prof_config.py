@@ -51,8 +51,11 @@ def main():
     view = T.view_from_camera(eye, look, fov, w, h)
     sc = T.Scene(flat)
     st = sc.count_primary(view, w, h, sem=3)
+    import hashlib
     info = {"config": cfg, "scene": scene_name, "mode": mode, "width": w, "height": h, "tlas": tlas,
-            "tris": int(flat.n_tris), "nodes": int(flat.n_nodes)}
+            "tris": int(flat.n_tris), "nodes": int(flat.n_nodes),
+            # the library that ran (tools/profile_summary.py refuses to mix libraries in one round's profile set)
+            "lib_sha16": hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16]}
     if mode == "primary":
         mn, mean = sc.bench_primary(view, w, h, sem=3, warmup=3, frames=frames)
         info.update(rays=w * h, n_node=int(st.n_node), n_tri=int(st.n_tri), ms_min=mn, ms_mean=mean)

@@ -5,7 +5,7 @@
 # passes with --kernel-trace only.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/prof_r$(printf %02d "${ROUND:-5}")
+out=gpurun_out/prof_r$(printf %02d "${ROUND:-6}")
 mkdir -p "$out"
 if [ -z "$SKIP_BENCH" ]; then   # (a call is limited to 20 minutes: the seven configs go in three calls, the bench line in the first)
 python3 bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"
@@ -26,4 +26,4 @@ for cfg in ${CONFIGS:-primary_bistro primary_bistro_dense primary_hairball ao_bi
     tail -1 "$out/$cfg.pmc$i.log" | cut -c1-160
   done
 done
-python3 tools/profile_summary.py --round "${ROUND:-5}" "$out" --dry
+python3 tools/profile_summary.py --round "${ROUND:-6}" "$out" --dry

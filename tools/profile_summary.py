@@ -14,7 +14,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 argv = sys.argv[1:]
-ROUND = 5
+ROUND = 6
 if "--round" in argv:
     k = argv.index("--round")
     ROUND = int(argv[k + 1])
@@ -91,7 +91,7 @@ def summarise(cfg):
     rays = info["rays"]
     req = NODE_B * info.get("n_node", 0) + TRI_B * info.get("n_tri", 0) + (HIT_B + info.get("ray_bytes", 0)) * rays
     out = {
-        "config": cfg, "kernel": kernel_name, "scene": info["scene"], "mode": info["mode"],
+        "config": cfg, "kernel": kernel_name, "lib_sha16": info.get("lib_sha16"), "scene": info["scene"], "mode": info["mode"],
         "image": [info["width"], info["height"]], "tlas": info["tlas"], "tris": info["tris"], "nodes": info["nodes"],
         "rays_per_launch": rays,
         "nodes_per_ray": round(info.get("n_node", 0) / max(rays, 1), 2),
@@ -148,13 +148,25 @@ def main():
                 shutil.copy(ks, os.path.join(dst, "%s_kernel_stats_%s.csv" % (TAG, out["config"])))
     if dry:
         return
+    # The bench line of the round: copied only when it is NEWER than the committed one and comes from the library the
+    # summarised configs ran (round 5 shipped a stale line: a later partial re-run of this script copied the bench line of
+    # an older build over the final one).
     b = os.path.join(src, "bench_default.json")
+    target = os.path.join(dst, "%s_bench_default.json" % TAG)
+    libs = {r.get("lib_sha16") for r in results if r.get("lib_sha16")}
     if os.path.exists(b):
         line = open(b).read().strip().splitlines()[-1]
-        json.loads(line)
-        open(os.path.join(dst, "%s_bench_default.json" % TAG), "w").write(line + "\n")
+        lib = (json.loads(line).get("build") or {}).get("lib_sha16")
+        if os.path.exists(target) and os.path.getmtime(b) <= os.path.getmtime(target):
+            print("bench line NOT copied: %s is not newer than %s" % (b, target))
+        elif libs and lib not in libs:
+            print("bench line NOT copied: it ran library %s, the configs summarised here ran %s" % (lib, sorted(libs)))
+        else:
+            open(target, "w").write(line + "\n")
+    if len(libs) > 1:
+        print("WARNING: the summarised configs ran %d different libraries: %s" % (len(libs), sorted(libs)))
     ks = newest("stats_bench/**/*kernel_stats.csv")
-    if ks:
+    if ks and os.path.exists(b) and os.path.getmtime(ks) >= os.path.getmtime(b):
         shutil.copy(ks, os.path.join(dst, "%s_kernel_stats_bench.csv" % TAG))
     # the bench's live counters read profiles/traffic.json only as a fall-back; keep it in step with this round
     pb = [r for r in results if r["config"] == "primary_bistro"]

@@ -116,12 +116,14 @@ SIGNATURES = {
     "trx_scene_check": (_i, [_P, _P]),
     "trx_trace_primary": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _P, C.POINTER(_f)]),
     "trx_trace_primary_ao": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _u32, _f, _P, _P, C.POINTER(_f)]),
+    "trx_frame_loop": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _u32, _i, _f, _u32, _i, _P, _P, C.POINTER(_f)]),
     "trx_trace_primary_ao_inst": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _u32, _f, _P, _P, _P, _P, C.POINTER(_f)]),
     "trx_trace_rays": (_i, [_P, _P, _u64, _u32, _P, C.POINTER(_f)]),
     "trx_trace_rays_inst": (_i, [_P, _P, _u64, _u32, _P, _P, C.POINTER(_f)]),
     "trx_traverse1": (_i, [_P, C.POINTER(Ray), _u32, C.POINTER(RayHit)]),
     "trx_debug_traverse1_stats": (_i, [_P, C.POINTER(_u64), C.POINTER(_u64)]),
     "trx_debug_fetch_rate": (_i, [_P, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "trx_debug_copy_rate": (_i, [_i, _u64, _u32, C.POINTER(C.c_double)]),
     "trx_debug_traverse1_threads": (_i, [_P, _P, _u64, _u32, _u32, _P, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "trx_traverse_batch": (_i, [_P, _P, _u64, _u32, _P, C.POINTER(_f)]),
     "trx_bench_primary": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _u32, _u32, C.POINTER(_f), C.POINTER(_f)]),
@@ -167,6 +169,8 @@ SIGNATURES = {
     "trx_scene_camera": (_i, [C.c_char_p, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f)]),
     "trx_load_model": (_i, [C.c_char_p, C.POINTER(C.POINTER(_f)), C.POINTER(_u64), C.POINTER(C.POINTER(_u64)),
                             C.POINTER(_u32)]),
+    "trx_load_scene": (_i, [C.c_char_p, C.POINTER(C.POINTER(_f)), C.POINTER(_u64), C.POINTER(C.POINTER(_u64)),
+                        C.POINTER(_u32), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f)]),
     "trx_free": (None, [_P]),
 }
 

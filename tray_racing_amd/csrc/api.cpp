@@ -306,6 +306,20 @@ void trx_scene_destroy(trx_scene *s) {
     }
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    {
+        FrameLoop &fl = s->loop;
+        for (int k = 0; k < 2; k++) {
+            if (fl.stream[k]) (void)hipStreamDestroy(fl.stream[k]);
+            if (fl.prim_done[k]) (void)hipEventDestroy(fl.prim_done[k]);
+            if (fl.ao_done[k]) (void)hipEventDestroy(fl.ao_done[k]);
+            if (fl.prim[k]) (void)hipFree(fl.prim[k]);
+            if (fl.prim_inst[k]) (void)hipFree(fl.prim_inst[k]);
+        }
+        if (fl.t0) (void)hipEventDestroy(fl.t0);
+        if (fl.t1) (void)hipEventDestroy(fl.t1);
+        if (fl.ao) (void)hipFree(fl.ao);
+        if (fl.ao_inst) (void)hipFree(fl.ao_inst);
+    }
     delete s->comb;
     delete s;
 }

@@ -625,6 +625,28 @@ int trx_load_model(const char *path, float **out_verts, uint64_t *out_n, uint64_
     return export_mesh(verts, objects, out_verts, out_n, out_counts, out_nobj);
 }
 
+int trx_load_scene(const char *path, float **out_verts, uint64_t *out_n, uint64_t **out_counts, uint32_t *out_nobj, float eye[3],
+                   float look_at[3], float *fov_deg) {
+    if (!path || !out_verts || !out_n || !eye || !look_at || !fov_deg) return fail(TRX_ERR_INVALID, "null argument");
+    std::string model;
+    if (!parse_scene_ron(path, model, eye, look_at, fov_deg)) return fail(TRX_ERR_IO, "Failed to load config: %s", path);
+    {   // (beyond the reference's rule: a model path that does not resolve from the working directory is tried next to the
+        // scene file's great-grandparent directory, so that an ABSOLUTE scene path works from anywhere)
+        FILE *probe = std::fopen(model.c_str(), "rb");
+        if (probe) {
+            std::fclose(probe);
+        } else if (!model.empty() && model[0] != '/') {
+            std::string base = path;
+            for (int up = 0; up < 3; up++) {
+                const size_t sl = base.find_last_of('/');
+                base = sl == std::string::npos ? std::string() : base.substr(0, sl);
+            }
+            if (!base.empty()) model = base + "/" + model;
+        }
+    }
+    return trx_load_model(model.c_str(), out_verts, out_n, out_counts, out_nobj);
+}
+
 void trx_free(void *p) { std::free(p); }
 
 } // extern "C"

@@ -160,6 +160,15 @@ struct RayCombiner {
     }
 };
 
+// trx_frame_loop's streams, events and device buffers (created on first use)
+struct FrameLoop {
+    hipStream_t stream[2] = {nullptr, nullptr};
+    hipEvent_t prim_done[2] = {nullptr, nullptr}, ao_done[2] = {nullptr, nullptr}, t0 = nullptr, t1 = nullptr;
+    trx_hit *prim[2] = {nullptr, nullptr}, *ao = nullptr;
+    uint32_t *prim_inst[2] = {nullptr, nullptr}, *ao_inst = nullptr;
+    uint64_t records = 0;
+};
+
 struct trx_scene {
     int device = 0;
     uint4 *d_nodes = nullptr;
@@ -187,6 +196,7 @@ struct trx_scene {
     uint64_t scratch_hits = 0, scratch_rays = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<uint32_t> blas_tri_start; // geometry_id lookup for trx_traverse1
+    FrameLoop loop;                // trx_frame_loop
     RayCombiner *comb = nullptr;   // trx_traverse1: concurrent single-ray callers share launches (created on first use)
     std::once_flag comb_once;
     // instance transforms (TLAS scenes): object-to-world as given (get_instance_transform), world-to-object rows as

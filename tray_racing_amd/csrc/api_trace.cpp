@@ -401,6 +401,88 @@ int trx_trace_primary_ao_inst(trx_scene *s, const trx_view *view, uint32_t w, ui
     return trx_scene_check(s, nullptr);
 }
 
+// The reference's frame loop, device-resident (src/rt_gpu/rt_gpu_software.rs:271-361: every frame a primary pass and the AO
+// pass over its hits, --animate advancing the noise seed).  Serial: both passes of every frame on one stream, back to back -
+// what trx_trace_primary_ao does per call, without the host in between.  Overlapped: the primary passes on stream A, the AO
+// passes on stream B; AO(i) waits for primary(i), primary(i + 2) waits for AO(i) (two primary buffers), so frame i's AO pass -
+// whose last few hundred rays run alone on an almost idle GPU - overlaps frame i + 1's primary pass.  Each stream keeps its
+// launch slot and so its tile order (api_launch.cpp); the records are those of the serial loop.
+int trx_frame_loop(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint32_t frame0, int animate,
+                   float ao_eps, uint32_t n_frames, int overlap, trx_hit *out_primary, trx_hit *out_ao, float *out_ms) {
+    if (!s || !view) return fail(TRX_ERR_INVALID, "null argument");
+    if (n_frames == 0 || n_frames > 1000000u) return fail(TRX_ERR_INVALID, "n_frames %u outside 1..1000000", n_frames);
+    std::lock_guard<std::recursive_mutex> host_lock(s->host_mu); // serialises users of the scene's scratch buffers
+    HIP_TRY(hipSetDevice(s->device));
+    const uint64_t n = (uint64_t)w * h;
+    if (n == 0 || n > 0x7fffffffull) return fail(TRX_ERR_INVALID, "image %ux%u", w, h);
+    FrameLoop &fl = s->loop;
+    if (!fl.stream[0]) {
+        for (int k = 0; k < 2; k++) HIP_TRY(hipStreamCreateWithFlags(&fl.stream[k], hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(hipEventCreateWithFlags(&fl.prim_done[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&fl.ao_done[k], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreate(&fl.t0));
+        HIP_TRY(hipEventCreate(&fl.t1));
+    }
+    if (fl.records < n) {
+        for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(fl.stream[k]));
+        for (int k = 0; k < 2; k++) {
+            if (fl.prim[k]) (void)hipFree(fl.prim[k]);
+            if (fl.prim_inst[k]) (void)hipFree(fl.prim_inst[k]);
+            fl.prim[k] = nullptr;
+            fl.prim_inst[k] = nullptr;
+        }
+        if (fl.ao) (void)hipFree(fl.ao);
+        if (fl.ao_inst) (void)hipFree(fl.ao_inst);
+        fl.ao = nullptr;
+        fl.ao_inst = nullptr;
+        fl.records = 0;
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(hipMalloc(&fl.prim[k], n * sizeof(trx_hit)));
+            if (s->tlas) HIP_TRY(hipMalloc(&fl.prim_inst[k], n * sizeof(uint32_t)));
+        }
+        HIP_TRY(hipMalloc(&fl.ao, n * sizeof(trx_hit)));
+        if (s->tlas) HIP_TRY(hipMalloc(&fl.ao_inst, n * sizeof(uint32_t)));
+        fl.records = n;
+    }
+    hipStream_t sa = fl.stream[0], sb = overlap ? fl.stream[1] : fl.stream[0];
+    const trx_shard whole{0, 1, 0, 0};
+    HIP_TRY(hipEventRecord(fl.t0, sa));
+    int rc = TRX_OK;
+    for (uint32_t i = 0; i < n_frames && rc == TRX_OK; i++) {
+        const int b = (int)(i & 1u);
+        if (i >= 2 && overlap) HIP_TRY(hipStreamWaitEvent(sa, fl.ao_done[b], 0)); // AO(i - 2) has read this primary buffer
+        rc = trx_trace_primary_inst_dev(s, view, w, h, whole, sem, fl.prim[b], fl.prim_inst[b], sa);
+        if (rc) break;
+        if (overlap) {
+            HIP_TRY(hipEventRecord(fl.prim_done[b], sa));
+            HIP_TRY(hipStreamWaitEvent(sb, fl.prim_done[b], 0));
+        }
+        rc = trx_trace_ao_inst_dev(s, view, w, h, whole, sem, frame0 + (animate ? i : 0u), ao_eps, fl.prim[b], fl.prim_inst[b], fl.ao,
+                                   fl.ao_inst, sb);
+        if (rc) break;
+        if (overlap) HIP_TRY(hipEventRecord(fl.ao_done[b], sb));
+    }
+    if (rc == TRX_OK && overlap) HIP_TRY(hipStreamWaitEvent(sa, fl.ao_done[(n_frames - 1u) & 1u], 0));
+    if (rc == TRX_OK) HIP_TRY(hipEventRecord(fl.t1, sa));
+    // (whatever happened, nothing of this call is left in flight when it returns)
+    const hipError_t e0 = hipStreamSynchronize(fl.stream[0]), e1 = hipStreamSynchronize(fl.stream[1]);
+    if (rc) return rc;
+    HIP_TRY(e0);
+    HIP_TRY(e1);
+    if (out_ms) HIP_TRY(hipEventElapsedTime(out_ms, fl.t0, fl.t1));
+    const int last = (int)((n_frames - 1u) & 1u);
+    if (out_primary) HIP_TRY(hipMemcpy(out_primary, fl.prim[last], n * sizeof(trx_hit), hipMemcpyDeviceToHost));
+    if (out_ao) HIP_TRY(hipMemcpy(out_ao, fl.ao, n * sizeof(trx_hit), hipMemcpyDeviceToHost));
+    for (Slot &sl : s->slots) {
+        if (!sl.ctr) continue;
+        rc = read_overflow(s, sl.ctr);
+        if (rc) return rc;
+    }
+    return TRX_OK;
+}
+
 int trx_trace_rays(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t sem, trx_hit *out_hits, float *out_ms) {
     return trx_trace_rays_inst(s, rays, n, sem, out_hits, nullptr, out_ms);
 }

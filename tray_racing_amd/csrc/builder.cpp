@@ -125,6 +125,39 @@ inline float half_area(const Aabb &b) {
     return dx * dy + dy * dz + dz * dx;
 }
 
+// (a spin-wait hint where the target has one; api_traverse.cpp carries the same helper)
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#endif
+}
+
+// The arrangement a binary split leaves its range in: the k-th misplaced element from the left changes places with the k-th
+// misplaced element from the right (what a bidirectional std::partition does in libstdc++, written out so that the tree
+// does not depend on the standard library: split_parallel() reproduces exactly this arrangement on every core, and a range
+// of two is split by position, so the ORDER inside a side is part of the tree's primitive order).  Returns the first
+// element of the right side.
+template <class Pred>
+inline uint32_t *partition_pairs(uint32_t *first, uint32_t *last, Pred goes_left) {
+    for (;;) {
+        for (;;) {
+            if (first == last) return first;
+            if (!goes_left(*first)) break;
+            ++first;
+        }
+        --last;
+        for (;;) {
+            if (first == last) return first;
+            if (goes_left(*last)) break;
+            --last;
+        }
+        std::swap(*first, *last);
+        ++first;
+    }
+}
+
 // A few dozen short parallel phases in a row (the top of the BVH2 build: five per split) cost more in thread creation than
 // in work when every phase starts its own threads; this keeps the threads and hands them one phase after the other.
 // Workers spin briefly, then yield, between phases; the pool lives only as long as the phases do.
@@ -143,7 +176,7 @@ struct PhasePool {
                 for (;;) {
                     uint64_t g;
                     for (unsigned spins = 0; (g = generation.load(std::memory_order_acquire)) == seen; spins++) {
-                        if (spins < 4000) __builtin_ia32_pause();
+                        if (spins < 4000) cpu_relax();
                         else std::this_thread::yield();
                     }
                     seen = g;
@@ -164,7 +197,7 @@ struct PhasePool {
         done.store(0, std::memory_order_relaxed);
         generation.fetch_add(1, std::memory_order_release);
         f(0);
-        while (done.load(std::memory_order_acquire) != n - 1) __builtin_ia32_pause();
+        while (done.load(std::memory_order_acquire) != n - 1) cpu_relax();
     }
     ~PhasePool() {
         stop = true;
@@ -298,7 +331,7 @@ struct Bvh2Builder {
         if (best_axis >= 0) {
             float lo = cb.mn[best_axis], hi = cb.mx[best_axis];
             float scale = (float)kBins / (hi - lo);
-            auto it = std::partition(idx.begin() + begin, idx.begin() + end, [&](uint32_t p) {
+            uint32_t *it = partition_pairs(idx.begin() + begin, idx.begin() + end, [&](uint32_t p) {
                 int b = (int)((cen[3 * (size_t)p + best_axis] - lo) * scale);
                 b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
                 return b <= best_bin;
@@ -428,9 +461,8 @@ struct Bvh2Builder {
                 b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
                 return b <= best_bin;
             };
-            // The arrangement std::partition leaves (libstdc++'s bidirectional algorithm: the k-th misplaced element from the
-            // left changes places with the k-th misplaced element from the right), produced on every core: a range of two
-            // is split by position, so the ORDER inside a side is part of the tree's primitive order.
+            // The arrangement partition_pairs() leaves - the k-th misplaced element from the left changes places with the k-th
+            // misplaced element from the right - produced on every core.
             on_all([&](int t) {
                 uint32_t c = 0;
                 for (uint32_t i = chunk(t).first; i < chunk(t).second; i++) c += goes_left(idx[i]) ? 1u : 0u;
@@ -532,7 +564,10 @@ struct Bvh2Builder {
         std::vector<Task> pending{Task{0, 0, n}}, queue;
         const auto t_top = std::chrono::steady_clock::now();
         {
-            PhasePool pool(threads);
+            // (the pool's threads exist only when a split can run on them: the BLASes of a two-level scene are thousands of
+            // small builds)
+            const bool parallel_top = threads > 1 && n >= kParallelSplitMin && n > grain;
+            PhasePool pool(parallel_top ? threads : 1);
             top_pool = &pool;
             while (!pending.empty()) {
                 Task t = pending.back();

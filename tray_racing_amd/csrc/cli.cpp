@@ -38,6 +38,7 @@ struct Options { // src/main.rs:65-171 (flags this backend cannot honour are rej
     bool dry_run = false; // load + build only (no device needed)
     bool gpu_build = false; // --gpu-build: Morton sort + PLOC rounds of the build on the device (trx_set_build_device)
     bool split = false;   // --split: pre-splitting of large triangles
+    bool overlap = false; // --overlap: frame i's AO pass under frame i + 1's primary pass (trx_frame_loop, two streams)
     int device = 0;
     unsigned semantics = TRX_SEM_HLSL; // the GPU path of the reference is the HLSL text
 };
@@ -60,49 +61,13 @@ void check(int rc, const char *what) {
     if (rc != TRX_OK) die(std::string(what) + ": " + trx_last_error());
 }
 
-std::string dirname_of(const std::string &p) {
-    size_t k = p.find_last_of('/');
-    if (k == std::string::npos) return "";
-    return p.substr(0, k);
-}
-
-// The subset of RON the reference's scene files use (assets/scenes/*.ron): model_path, camera(eye,
-// look_at, fov, exposure), sun_direction; `//` comments.
-bool parse_ron(const std::string &path, std::string &model_path, Camera &cam) {
-    std::ifstream f(path);
-    if (!f) return false;
-    std::stringstream ss;
-    std::string line;
-    while (std::getline(f, line)) {
-        size_t c = line.find("//");
-        if (c != std::string::npos) line.erase(c);
-        ss << line << '\n';
-    }
-    const std::string s = ss.str();
-    auto tuple3 = [&](const char *key, float out[3]) {
-        size_t k = s.find(key);
-        if (k == std::string::npos) return false;
-        k = s.find('(', k);
-        if (k == std::string::npos) return false;
-        return std::sscanf(s.c_str() + k, "( %f , %f , %f", &out[0], &out[1], &out[2]) == 3;
-    };
-    size_t k = s.find("model_path");
-    if (k == std::string::npos) return false;
-    size_t q0 = s.find('"', k), q1 = q0 == std::string::npos ? q0 : s.find('"', q0 + 1);
-    if (q1 == std::string::npos) return false;
-    model_path = s.substr(q0 + 1, q1 - q0 - 1);
-    if (!tuple3("eye", cam.eye) || !tuple3("look_at", cam.look_at)) return false;
-    k = s.find("fov");
-    if (k == std::string::npos || std::sscanf(s.c_str() + s.find(':', k) + 1, " %f", &cam.fov) != 1) return false;
-    return true;
-}
-
 void usage() {
     std::puts("tray_racing_hip -i <scene.ron|demoscene|standin:<name>>[,...] [--benchmark] [--render-time s]\n"
               "  [--build ploc_cwbvh] [--max-prims-per-leaf 1..3] [--collapse-traversal-cost c] [--preset p]\n"
               "  [--width w] [--height h] [--animate] [--tlas] [--flatten-blas] [--passes n] [--verbose] [--device d]\n"
               "  [--png] [--cpu-semantics] [--dry-run (load + build only, needs no GPU)] [-r reinsertion_batch_ratio]\n"
               "  [--search-distance d] [--search-depth-threshold n] [--sort-precision 64|128] [--split] [--gpu-build]\n"
+              "  [--overlap (frames stay on the device, frame i's AO pass under frame i+1's primary pass; reports the average)]\n"
               "stand-in names: cornell demoscene kitchen bistro hairball san_miguel (seeded procedural scenes)");
 }
 
@@ -135,6 +100,7 @@ Options parse_args(int argc, char **argv) {
         else if (a == "--cpu-semantics") o.semantics = TRX_SEM_CPU;
         else if (a == "--dry-run") o.dry_run = true;
         else if (a == "--gpu-build") o.gpu_build = true;
+        else if (a == "--overlap") o.overlap = true;
         else if (a == "-h" || a == "--help") {
             usage();
             std::exit(0);
@@ -244,19 +210,12 @@ Stats render_input(const Options &o, const std::string &input) {
         check(trx_gen_scene(name.c_str(), 0, 1, &verts, &n_tris, &counts, &n_objects), "scene");
         check(trx_scene_camera(name.c_str(), cam.eye, cam.look_at, &cam.fov), "camera");
     } else {
-        std::string model;
-        if (!parse_ron(input, model, cam)) die("Failed to load config: " + input); // src/main.rs:262-267
-        if (!input.empty() && input[0] != '/' && !model.empty() && model[0] != '/') {
-            // "If we got a relative path to both the scene and the model, assume the path to the model is
-            // relative to the path to the scene" (three levels up, src/main.rs:271-284)
-            std::string base = dirname_of(dirname_of(dirname_of(input)));
-            if (!base.empty()) model = base + "/" + model;
-        }
         size_t k = input.find_last_of('/');
         st.name = input.substr(k == std::string::npos ? 0 : k + 1);
         k = st.name.find_last_of('.');
         if (k != std::string::npos) st.name.erase(k);
-        check(trx_load_model(model.c_str(), &verts, &n_tris, &counts, &n_objects), "model");
+        // scene file + model through the library's loader (src/main.rs:259-298: "Failed to load config" / the model's error)
+        check(trx_load_scene(input.c_str(), &verts, &n_tris, &counts, &n_objects, cam.eye, cam.look_at, &cam.fov), "scene");
     }
     const bool tlas = o.tlas && !o.flatten_blas; // src/main.rs:300-308
     if (o.verbose) std::printf("%u objects \"%s\"\ntriangles %llu\n", n_objects, st.name.c_str(), (unsigned long long)n_tris);
@@ -310,19 +269,36 @@ Stats render_input(const Options &o, const std::string &input) {
     // is the MINIMUM frame time (src/rt_gpu/rt_gpu_software.rs:289-302,339,376)
     double total_ms = 0, min_ms = 1e30;
     unsigned frames = 0, frame_count = 0;
-    if (o.benchmark) {
+    if (o.overlap) {
+        // The same loop without the host between its frames, and with frame i's AO pass on a second stream under frame
+        // i + 1's primary pass: batches of frames until render_time is used up.  A frame has no time of its own here, so the
+        // result is the average over the last batch (with --benchmark: the best batch's average).
+        unsigned batch = 16;
         float ms = 0;
-        check(trx_trace_primary_ao(scene, &view, o.width, o.height, o.semantics, 0, 0.0001f, nullptr, nullptr, &ms), "warm-up");
+        if (o.benchmark) check(trx_frame_loop(scene, &view, o.width, o.height, o.semantics, 0, 0, 0.0001f, 8, 1, nullptr, nullptr, &ms), "warm-up");
+        do {
+            check(trx_frame_loop(scene, &view, o.width, o.height, o.semantics, frame_count, o.animate ? 1 : 0, 0.0001f, batch, 1, nullptr,
+                                 nullptr, &ms), "trace");
+            total_ms += ms;
+            min_ms = std::min(min_ms, (double)ms / batch);
+            frames += batch;
+            if (o.animate) frame_count = frames;
+        } while (total_ms < o.render_time * 1000.0 && frames < 100000);
+    } else {
+        if (o.benchmark) {
+            float ms = 0;
+            check(trx_trace_primary_ao(scene, &view, o.width, o.height, o.semantics, 0, 0.0001f, nullptr, nullptr, &ms), "warm-up");
+        }
+        do {
+            float ms = 0;
+            check(trx_trace_primary_ao(scene, &view, o.width, o.height, o.semantics, frame_count, 0.0001f, nullptr, nullptr, &ms),
+                  "trace");
+            total_ms += ms;
+            min_ms = std::min(min_ms, (double)ms);
+            frames++;
+            if (o.animate) frame_count = frames;
+        } while (total_ms < o.render_time * 1000.0 && frames < 100000);
     }
-    do {
-        float ms = 0;
-        check(trx_trace_primary_ao(scene, &view, o.width, o.height, o.semantics, frame_count, 0.0001f, nullptr, nullptr, &ms),
-              "trace");
-        total_ms += ms;
-        min_ms = std::min(min_ms, (double)ms);
-        frames++;
-        if (o.animate) frame_count = frames;
-    } while (total_ms < o.render_time * 1000.0 && frames < 100000);
     st.traversal_ms = o.benchmark ? min_ms : total_ms / frames;
     if (o.verbose) std::printf("%.2fms   avg render time over %u frames (min %.3fms)\n", total_ms / frames, frames, min_ms);
     if (o.png) save_png(o, scene, view, frame_count, st.name);

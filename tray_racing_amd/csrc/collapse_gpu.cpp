@@ -91,13 +91,15 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, uint32_t want
 }
 
 // ---- 1. BVH2 levels
-__global__ __launch_bounds__(kBlock) void k2_expand(const DevNode *nodes, const uint32_t *in, uint32_t n_in, uint32_t *out, uint32_t *counter) {
+// (capacity = entries `out` can take; an append past it is dropped and the host, which reads the counter, reports the links)
+__global__ __launch_bounds__(kBlock) void k2_expand(const DevNode *nodes, const uint32_t *in, uint32_t n_in, uint32_t *out, uint32_t *counter,
+                                                     uint32_t capacity) {
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
     uint32_t left = 0, right = 0, prim, count = 0;
     if (t < n_in) load_links(nodes, in[t], left, right, prim, count);
     const bool inner = count > 1;
     const uint32_t at = wave_append(counter, inner ? 2u : 0u);
-    if (inner) {
+    if (inner && at + 2u <= capacity) {
         out[at] = left;
         out[at + 1] = right;
     }
@@ -485,7 +487,8 @@ bool collapse_encode_device(int device, const void *nodes, size_t n_nodes, uint3
         }
         if (end >= n) break; // every node is listed: the last level holds leaves only
         CG_TRY(hipMemsetAsync(b.counter, 0, 4, nullptr));
-        hipLaunchKernelGGL(k2_expand, grid_for(end - begin), dim3(kBlock), 0, nullptr, b.nodes, b.list + begin, end - begin, b.list + end, b.counter);
+        hipLaunchKernelGGL(k2_expand, grid_for(end - begin), dim3(kBlock), 0, nullptr, b.nodes, b.list + begin, end - begin, b.list + end, b.counter,
+                           (uint32_t)(n - end));
         CG_TRY(hipGetLastError());
         uint32_t made = 0;
         CG_TRY(hipMemcpy(&made, b.counter, 4, hipMemcpyDeviceToHost));

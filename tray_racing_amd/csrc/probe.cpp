@@ -45,7 +45,56 @@ __global__ void __launch_bounds__(2 * kWave) k_fetch_probe(const uint4 *nodes, u
     sink[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// The streaming ceiling: one float4 in, one float4 out per lane and step, grid-stride over `n` float4 - the copy kernel the
+// platform guide measures (MI355X_MICROARCH.md: 6.29 TB/s read + written); hipMemcpyDtoD, which bench.py used until round 5,
+// reaches about 5.0 TB/s on the same box.
+__global__ void __launch_bounds__(256) k_copy_probe(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 } // namespace
+
+extern "C" int trx_debug_copy_rate(int device, uint64_t bytes, uint32_t reps, double *out_bytes_per_s) {
+    if (!out_bytes_per_s || reps == 0 || reps > 64) return fail(TRX_ERR_INVALID, "reps in 1 .. 64");
+    if (bytes < (1ull << 20) || bytes > (8ull << 30) || (bytes & 15u)) return fail(TRX_ERR_INVALID, "bytes: a multiple of 16 in 1 MiB .. 8 GiB");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return fail(TRX_ERR_NO_DEVICE, "no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device));
+    float4 *src = nullptr, *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&src, bytes);
+    if (e == hipSuccess) e = hipMalloc(&dst, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(src, 1, bytes, nullptr);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    const size_t n = bytes / sizeof(float4);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    float best = 0.0f;
+    if (e == hipSuccess) {
+        const int blocks = prop.multiProcessorCount * 8; // (2 048 lanes per CU in flight: the guide's shape)
+        for (uint32_t rep = 0; rep < reps + 2u && e == hipSuccess; rep++) { // (two warm-up passes)
+            e = hipEventRecord(e0, nullptr);
+            if (e == hipSuccess) {
+                k_copy_probe<<<blocks, 256, 0, nullptr>>>(src, dst, n);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.0f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e == hipSuccess && rep >= 2u && (best == 0.0f || ms < best)) best = ms;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    if (e != hipSuccess || best <= 0.0f) return fail(e == hipErrorOutOfMemory ? TRX_ERR_OOM : TRX_ERR_NO_DEVICE, "copy probe failed: %s", hipGetErrorString(e));
+    *out_bytes_per_s = 2.0 * (double)bytes / (best * 1e-3); // read + written
+    return TRX_OK;
+}
 
 extern "C" int trx_debug_fetch_rate(trx_scene *s, uint32_t steps, uint32_t tris_per_node_x256, double *out_nodes_per_s,
                                     double *out_tris_per_s) {

@@ -295,7 +295,10 @@ __device__ __forceinline__ uint32_t wave_append2(uint32_t *counter, uint32_t wan
     base = __shfl(base, 63, 64);
     return base + scan - want;
 }
-__global__ void __launch_bounds__(kBlock) k_level(const DevNode *nodes, const uint32_t *in, uint32_t n_in, uint32_t *out, uint32_t *counter) {
+// (capacity = entries `out` can take: links that no longer describe a tree - the very case the host reports - must not turn
+// into stores past the list; an append that does not fit is dropped, the counter still says how many were wanted)
+__global__ void __launch_bounds__(kBlock) k_level(const DevNode *nodes, const uint32_t *in, uint32_t n_in, uint32_t *out, uint32_t *counter,
+                                                   uint32_t capacity) {
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
     uint32_t left = 0, right = 0, count = 0;
     if (t < n_in) {
@@ -307,7 +310,7 @@ __global__ void __launch_bounds__(kBlock) k_level(const DevNode *nodes, const ui
     }
     const bool inner = count > 1;
     const uint32_t at = wave_append2(counter, inner ? 2u : 0u);
-    if (inner) {
+    if (inner && at + 2u <= capacity) {
         out[at] = left;
         out[at + 1] = right;
     }
@@ -550,7 +553,7 @@ bool reinsert_dev_iteration_resident(ReinsertDevice *c, uint32_t take, uint32_t 
             if (end == begin || end >= n) break;
             RG_TRY(hipMemsetAsync(c->d_words + 3, 0, 4, nullptr));
             hipLaunchKernelGGL(k_level, dim3((end - begin + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, c->d_nodes, c->d_list + begin,
-                               end - begin, c->d_list + end, c->d_words + 3);
+                               end - begin, c->d_list + end, c->d_words + 3, (uint32_t)(n - end));
             RG_TRY(hipGetLastError());
             uint32_t made = 0;
             RG_TRY(hipMemcpy(&made, c->d_words + 3, 4, hipMemcpyDeviceToHost));

@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -808,5 +810,47 @@ bool load_model(const std::string &path, std::vector<float> &verts, std::vector<
         return load_json(path, verts, objects);
     return load_obj(path, verts, objects);
 }
+
+// The subset of RON the reference's scene files use (assets/scenes/*.ron): model_path, camera(eye, look_at, fov,
+// exposure), sun_direction; `//` comments.  "If we got a relative path to both the scene and the model, assume the path to
+// the model is relative to the path to the scene" - three levels up (src/main.rs:271-284).
+bool parse_scene_ron(const std::string &path, std::string &model_path, float eye[3], float look_at[3], float *fov_deg) {
+    std::ifstream f(path);
+    if (!f) return false;
+    std::stringstream ss;
+    std::string line;
+    while (std::getline(f, line)) {
+        const size_t c = line.find("//");
+        if (c != std::string::npos) line.erase(c);
+        ss << line << '\n';
+    }
+    const std::string s = ss.str();
+    auto tuple3 = [&](const char *key, float out[3]) {
+        size_t k = s.find(key);
+        if (k == std::string::npos) return false;
+        k = s.find('(', k);
+        if (k == std::string::npos) return false;
+        return std::sscanf(s.c_str() + k, "( %f , %f , %f", &out[0], &out[1], &out[2]) == 3;
+    };
+    size_t k = s.find("model_path");
+    if (k == std::string::npos) return false;
+    const size_t q0 = s.find('"', k), q1 = q0 == std::string::npos ? q0 : s.find('"', q0 + 1);
+    if (q1 == std::string::npos) return false;
+    model_path = s.substr(q0 + 1, q1 - q0 - 1);
+    if (!tuple3("eye", eye) || !tuple3("look_at", look_at)) return false;
+    k = s.find("fov");
+    const size_t colon = k == std::string::npos ? k : s.find(':', k);
+    if (colon == std::string::npos || std::sscanf(s.c_str() + colon + 1, " %f", fov_deg) != 1) return false;
+    if (!path.empty() && path[0] != '/' && !model_path.empty() && model_path[0] != '/') {
+        std::string base = path;
+        for (int up = 0; up < 3; up++) {
+            const size_t sl = base.find_last_of('/');
+            base = sl == std::string::npos ? std::string() : base.substr(0, sl);
+        }
+        if (!base.empty()) model_path = base + "/" + model_path;
+    }
+    return true;
+}
+
 
 } // namespace trx

@@ -148,6 +148,8 @@ class AbiFrameGather(FrameGather):
         from . import _lib as L
         self._L, self._C = L, C
         self._comm = C.c_void_p()
+        self._owns = True
+        self._chain = None   # streams that share one communicator: the event the previous collective recorded
         if id_bytes is None:
             return  # no communicator: the caller moves the shards itself (tests: staged through gloo), the ABI assembles
         dev = self.device.index if self.device.index is not None else 0
@@ -158,6 +160,17 @@ class AbiFrameGather(FrameGather):
     def without_communicator(cls, width, height, rank, world, device, batch=1):
         """Only trx_assemble_frames (and the buffer layout) from the ABI; the shards travel by the caller's means."""
         return cls(width, height, rank, world, device, None, batch=batch)
+
+    @classmethod
+    def sharing(cls, other):
+        """Another buffer on `other`'s communicator (one communicator per rank, several streams): the collectives of the
+        buffers that share it are chained by an event, so they reach RCCL in one order on every rank whatever their streams."""
+        fg = cls(other.width, other.height, other.rank, other.world, other.device, None, batch=other.batch)
+        fg._comm, fg._owns = other._comm, False
+        if other._chain is None:
+            other._chain = {"event": None}
+        fg._chain = other._chain
+        return fg
 
     @staticmethod
     def unique_id():
@@ -189,14 +202,20 @@ class AbiFrameGather(FrameGather):
         if local is not None:
             assert m == 1
             self.slot(0, 1).copy_(local)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        cur = torch.cuda.current_stream(self.device)
+        stream = cur.cuda_stream
         lib = self._L.load()
+        if self._chain is not None and self._chain["event"] is not None:
+            cur.wait_event(self._chain["event"])   # the previous collective on this communicator (another stream's)
         if root is None:
             self._L.check(lib.trx_gather_shards(self._comm, self._C.c_void_p(self.flat.data_ptr()), m * self.records,
                                                 self._C.c_void_p(stream)))
         else:
             self._L.check(lib.trx_gather_shards_root(self._comm, self._C.c_void_p(self.flat.data_ptr()), m * self.records,
                                                      int(root), self._C.c_void_p(stream)))
+        if self._chain is not None:
+            self._chain["event"] = torch.cuda.Event()
+            self._chain["event"].record(cur)
         return None  # enqueued on the current stream: nothing to wait for on the host
 
     def assemble(self, out=None, m=1):
@@ -212,9 +231,9 @@ class AbiFrameGather(FrameGather):
         pass  # no index tensors to build
 
     def close(self):
-        if self._comm:
+        if self._comm and self._owns:
             self._L.load().trx_comm_destroy(self._comm)
-            self._comm = self._C.c_void_p()
+        self._comm = self._C.c_void_p()
 
     def __del__(self):
         try:

@@ -50,6 +50,25 @@ def load_meshs(path):
     return _take_mesh(vp, n, cp, nobj)
 
 
+def load_scene(path):
+    """A scene file of the reference (assets/scenes/*.ron) as src/main.rs:259-298 reads it: (verts [n,9], triangles per
+    object, eye, look_at, fov) - trx_load_scene."""
+    lib = L.load()
+    vp, cp = C.POINTER(C.c_float)(), C.POINTER(C.c_uint64)()
+    n, nobj = C.c_uint64(), C.c_uint32()
+    eye, look, fov = (C.c_float * 3)(), (C.c_float * 3)(), C.c_float()
+    L.check(lib.trx_load_scene(str(path).encode(), C.byref(vp), C.byref(n), C.byref(cp), C.byref(nobj), eye, look, C.byref(fov)))
+    verts, counts = _take_mesh(vp, n, cp, nobj)
+    return verts, counts, list(eye), list(look), fov.value
+
+
+def copy_rate(device=0, nbytes=1 << 30, reps=5):
+    """Streaming ceiling of the device's memory, bytes read + written per second by a float4 copy kernel (trx_debug_copy_rate)."""
+    out = C.c_double()
+    L.check(L.load().trx_debug_copy_rate(device, nbytes, reps, C.byref(out)))
+    return out.value
+
+
 def scene_camera(name):
     lib = L.load()
     eye, look, fov = (C.c_float * 3)(), (C.c_float * 3)(), C.c_float()
@@ -302,6 +321,16 @@ class Scene:
         L.check(self._lib.trx_trace_primary_ao(self._h, C.byref(view), width, height, sem, frame, ao_eps, _ptr(prim),
                                                _ptr(ao), C.byref(ms)))
         return prim, ao, ms.value
+
+    def frame_loop(self, view, width, height, sem=L.SEM_HLSL, frames=16, frame0=0, animate=True, ao_eps=0.01, overlap=False,
+                   fetch=True):
+        """The reference's frame loop, device-resident (trx_frame_loop): (total ms, last primary records, last AO records)."""
+        prim = np.empty(width * height, dtype=HIT_DTYPE) if fetch else None
+        ao = np.empty(width * height, dtype=HIT_DTYPE) if fetch else None
+        ms = C.c_float()
+        L.check(self._lib.trx_frame_loop(self._h, C.byref(view), width, height, sem, frame0, 1 if animate else 0, ao_eps, frames,
+                                         1 if overlap else 0, _ptr(prim) if fetch else None, _ptr(ao) if fetch else None, C.byref(ms)))
+        return ms.value, prim, ao
 
     def trace_primary_ao_inst(self, view, width, height, sem=L.SEM_HLSL, frame=0, ao_eps=0.01):
         """(primary, primary instance ids, ao, ao instance ids, ms): RayHit.instance_id beside every hit."""
