@@ -3,7 +3,9 @@
  * takes the pixels i = k, k + T, k + 2T ... of the frame and calls trx_traverse1 for each.  Rays come from a file
  * (32-byte trx_ray records, written by the test from the oracle's primary-ray generator), RayHits go to a file
  * (16-byte trx_rayhit records); stdout: "<rays> <seconds> <launches>".
- * usage: traverse_threads <scene> <tris> <threads> <semantics> <rays.bin> <hits.bin> */
+ * usage: traverse_threads <scene> <tris> <threads> <semantics> <rays.bin> <hits.bin> [semantics of the odd threads [tlas]]
+ * (an eighth argument builds the scene two-level: the single-ray path of two-level scenes is the launch combiner, that of
+ * single-level scenes the resident ray service) */
 #define _POSIX_C_SOURCE 200809L
 #include <pthread.h>
 #include <stdio.h>
@@ -47,6 +49,8 @@ int main(int argc, char **argv) {
     if (argc < 7) return 2;
     const int threads = atoi(argv[3]);
     const uint32_t sem = (uint32_t)atoi(argv[4]);
+    const uint32_t sem_odd = argc > 7 ? (uint32_t)atoi(argv[7]) : sem; /* callers of mixed semantics at once */
+    const int tlas = argc > 8 ? atoi(argv[8]) : 0;
     if (threads < 1 || threads > 4096) return 2;
     FILE *f = fopen(argv[5], "rb");
     if (!f) return 3;
@@ -64,10 +68,12 @@ int main(int argc, char **argv) {
     uint32_t n_objects = 0;
     CHECK(trx_gen_scene(argv[1], (uint64_t)atoll(argv[2]), 1, &verts, &n_tris, &counts, &n_objects));
     trx_flat *flat = NULL;
-    CHECK(trx_flat_build(verts, counts, n_objects, 0, 3, 0, &flat));
+    CHECK(trx_flat_build(verts, counts, n_objects, tlas, 3, 0, &flat));
     trx_scene *scene = NULL;
-    CHECK(trx_scene_create(flat->bvh_bytes, flat->n_nodes, flat->tri_verts, flat->n_tris, TRX_TRI_VERTS_36, NULL, 0, 0, 0,
-                           &scene));
+    CHECK(trx_scene_create(flat->bvh_bytes, flat->n_nodes, flat->tri_verts, flat->n_tris, TRX_TRI_VERTS_36,
+                           flat->n_instances ? flat->instance_offsets : NULL, flat->n_instances, flat->tlas_start, 0, &scene));
+    if (flat->instance_entry_nodes && flat->n_instances)
+        CHECK(trx_scene_set_instance_entry_nodes(scene, flat->instance_entry_nodes, flat->n_instances));
     /* one ray ahead of the clock: the first call creates the combiner (pinned buffers, streams) */
     if (n) CHECK(trx_traverse1(scene, &rays[0], sem, &hits[0]));
 
@@ -83,7 +89,7 @@ int main(int argc, char **argv) {
         jobs[k].n = n;
         jobs[k].first = (uint64_t)k;
         jobs[k].stride = (uint64_t)threads;
-        jobs[k].sem = sem;
+        jobs[k].sem = (k & 1) ? sem_odd : sem;
         jobs[k].rc = 0;
         if (pthread_create(&tid[k], NULL, worker, &jobs[k]) != 0) return 4;
     }

@@ -132,3 +132,97 @@ uint64_t spec_ao_rays(const orc_scene *s, const orc_view *view, uint32_t w, uint
         }
     return n;
 }
+
+/* ---- variant D: a prefetcher that walks AHEAD of the consumer -------------------------------------------------------
+ * consumer  = the sequential walk, whose "fetch + test node" is a look-up in a table of parked tests (keyed by node index,
+ *             direct-mapped, `cache` entries, newer tests overwrite); a miss makes that node candidate 0 of the next trip.
+ * prefetcher = its own stack F of {node, tmin}: a tested node's children that pass with the t of the moment go on F
+ *             (nearest last = on top), whether or not the consumer has reached the node; a trip pops up to G - 1 (or G)
+ *             entries whose tmin still passes the current t and that are not parked yet, and tests them.
+ * Nothing here can change the result: parked tests are t-independent, the consumer filters with its own t.
+ * Returns trips; *tests = node tests made (>= nodes visited: some are wasted). */
+typedef struct { uint32_t node; float tmin; } fent_t;
+static uint32_t sim_deep(const orc_scene *s, const orc_ray *ray, uint32_t sem, int G, int cache, uint32_t *n_nodes, uint32_t *n_tests) {
+    float o[3], d[3], inv[3];
+    for (int k = 0; k < 3; k++) {
+        o[k] = ray->origin[k];
+        d[k] = ray->direction[k] == 0.0f ? 1.1920929e-7f : ray->direction[k];
+        inv[k] = 1.0f / d[k];
+    }
+    const uint32_t oct4 = orc_octant_inv4(d);
+    float t = ray->tmax;
+    static __thread fent_t F[MAXP];
+    static __thread uint32_t tag[1024];
+    static __thread uint32_t cstack[MAXP]; /* consumer: pending nodes, DFS order (top = next) */
+    for (int i = 0; i < cache; i++) tag[i] = 0xffffffffu;
+    int nf = 0, nc = 0;
+    cstack[nc++] = 0;
+    F[nf++] = (fent_t){0, 0.0f};
+    uint32_t trips = 0, visited = 0, tests = 0;
+    for (;;) {
+        /* consume while the next node's test is parked */
+        while (nc > 0) {
+            const uint32_t node = cstack[nc - 1];
+            if (tag[node % (uint32_t)cache] != node) break;
+            nc--;
+            visited++;
+            const uint32_t *n = s->nodes + (size_t)node * 20;
+            const uint32_t mask = orc_node_intersect(o, d, inv, oct4, t, n, sem);
+            const uint32_t imask = n[3] >> 24, child_base = n[4], prim_base = n[5];
+            for (int b = 24; b < 32; b++)
+                if (mask & (1u << b)) {
+                    const uint32_t slot = (uint32_t)(b - 24) ^ (oct4 & 0xffu);
+                    if (nc < MAXP) cstack[nc++] = child_base + (uint32_t)__builtin_popcount(imask & ((1u << slot) - 1u));
+                }
+            for (uint32_t m = mask & 0x00ffffffu; m;) {
+                const int b = 31 - __builtin_clz(m);
+                m &= ~(1u << b);
+                orc_intersect_tri(o, d, s->tris + (size_t)(prim_base + b) * 9, ray->tmin, &t, sem);
+            }
+        }
+        if (nc == 0) break;
+        /* a trip: the consumer's blocked node first, then the prefetcher's stack */
+        trips++;
+        uint32_t cand[8];
+        int ncand = 0;
+        cand[ncand++] = cstack[nc - 1];
+        while (ncand < G && nf > 0) {
+            const fent_t e = F[--nf];
+            if (e.tmin > t) continue;                               /* culled since it was found */
+            if (tag[e.node % (uint32_t)cache] == e.node) continue;  /* parked already */
+            int dup = 0;
+            for (int k = 0; k < ncand; k++) dup |= cand[k] == e.node;
+            if (!dup) cand[ncand++] = e.node;
+        }
+        for (int k = 0; k < ncand; k++) {
+            const uint32_t node = cand[k];
+            tests++;
+            tag[node % (uint32_t)cache] = node;
+            const uint32_t *n = s->nodes + (size_t)node * 20;
+            const uint32_t mask = orc_node_intersect(o, d, inv, oct4, t, n, sem); /* children that pass with the t of this moment */
+            const uint32_t imask = n[3] >> 24, child_base = n[4];
+            for (int b = 24; b < 32; b++)
+                if (mask & (1u << b)) {
+                    const uint32_t slot = (uint32_t)(b - 24) ^ (oct4 & 0xffu);
+                    if (nf < MAXP) F[nf++] = (fent_t){child_base + (uint32_t)__builtin_popcount(imask & ((1u << slot) - 1u)), 0.0f};
+                }
+        }
+        if (trips > 100000u) break;
+    }
+    *n_nodes = visited;
+    *n_tests = tests;
+    return trips;
+}
+
+/* out: [n][1 + 2 * 4] = {nodes, trips G=2,4,8,16?..}: G in {2, 4, 8}, then tests for the same */
+void spec_sim_deep(const orc_scene *s, const orc_ray *rays, uint64_t n, uint32_t sem, int cache, uint32_t *out) {
+#pragma omp parallel for schedule(dynamic, 256)
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t nn = 0, nt = 0;
+        for (int g = 0; g < 3; g++) {
+            out[i * 7 + 1 + g] = sim_deep(s, rays + i, sem, 2 << g, cache, &nn, &nt);
+            out[i * 7 + 4 + g] = nt;
+        }
+        out[i * 7] = nn;
+    }
+}

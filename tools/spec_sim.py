@@ -33,7 +33,7 @@ sim.spec_ao_rays.restype = C.c_uint64
 n = sim.spec_ao_rays(C.byref(osc.c), C.byref(ov), w, h, prim.ctypes.data_as(C.c_void_p), 0, C.c_float(0.01), rays.ctypes.data_as(C.c_void_p))
 rays = rays[:n]
 print("scene %s: %d tris, %d nodes, %d AO rays" % (scene, flat.n_tris, flat.n_nodes, n))
-for cap in (16, 32, 1000):
+for cap in (2, 4, 8, 32):
     out = np.zeros((n, 9), dtype=np.uint32)
     sim.spec_sim(C.byref(osc.c), rays.ctypes.data_as(C.c_void_p), C.c_uint64(n), 3, cap, out.ctypes.data_as(C.c_void_p))
     nodes = out[:, 0]
@@ -43,3 +43,13 @@ for cap in (16, 32, 1000):
         o = out[sel].astype(np.float64)
         print("  %-14s nodes %7.1f | full records: trips G=1 %6.1f G=2 %6.1f G=4 %6.1f G=8 %6.1f | node records: G=1 %6.1f G=2 %6.1f G=4 %6.1f G=8 %6.1f" % (
             (name, o[:, 0].mean()) + tuple(o[:, k].mean() for k in range(1, 9))))
+for cache in (64, 256):
+    out = np.zeros((n, 7), dtype=np.uint32)
+    sim.spec_sim_deep(C.byref(osc.c), rays.ctypes.data_as(C.c_void_p), C.c_uint64(n), 3, cache, out.ctypes.data_as(C.c_void_p))
+    nodes = out[:, 0]
+    order = np.argsort(nodes)[::-1]
+    print("prefetcher ahead of the consumer, %d parked tests" % cache)
+    for name, sel in (("all rays", order), ("longest 300", order[:300]), ("longest 3000", order[:3000]), ("longest 30000", order[:30000])):
+        o = out[sel].astype(np.float64)
+        print("  %-14s nodes %7.1f | trips G=2 %6.1f G=4 %6.1f G=8 %6.1f | node tests G=2 %6.1f G=4 %6.1f G=8 %6.1f" % (
+            (name, o[:, 0].mean()) + tuple(o[:, k].mean() for k in range(1, 7))))

@@ -285,6 +285,10 @@ int trx_scene_create(const void *bvh_bytes, uint64_t n_nodes, const void *tri_by
 void trx_scene_destroy(trx_scene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    for (RayService *&v : s->svc) { // (resident kernels first: the device-wide synchronisation below would wait for them)
+        delete v;
+        v = nullptr;
+    }
     (void)hipDeviceSynchronize();
     if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_tris) (void)hipFree(s->d_tris);
@@ -308,8 +312,9 @@ void trx_scene_destroy(trx_scene *s) {
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     {
         FrameLoop &fl = s->loop;
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 2; k++)
             if (fl.stream[k]) (void)hipStreamDestroy(fl.stream[k]);
+        for (int k = 0; k < FrameLoop::kBuffers; k++) {
             if (fl.prim_done[k]) (void)hipEventDestroy(fl.prim_done[k]);
             if (fl.ao_done[k]) (void)hipEventDestroy(fl.ao_done[k]);
             if (fl.prim[k]) (void)hipFree(fl.prim[k]);

@@ -65,6 +65,7 @@ struct Slot {
     uint32_t spill_waves = 0;  // waves the spill area is sized for
     hipEvent_t done = nullptr; // everything enqueued for this slot has finished
     bool used = false;
+    bool pinned = false;               // a resident kernel (the ray service) runs on this slot: never recycled for another stream
     hipStream_t last_stream = nullptr; // stream of the last launch on this slot
     uint64_t last_use = 0;             // launch counter at that time (oldest slot is recycled first)
     // tile-cost feedback: the previous frame of a kind (primary / AO) traced on this slot measured every tile; the
@@ -125,6 +126,7 @@ struct RayCombiner {
     std::mutex mu;
     std::condition_variable cv;              // the open batch changed, or a batch became free
     std::atomic<int> inside{0};              // callers inside trx_traverse1 (spinning only pays while they fit the host's cores)
+    int waiting = 0;                         // ... of which wait on cv (another semantics' batch is open, or no batch is free): mu held
     int cores = 1;
     int open = -1;
     int device = 0;
@@ -162,11 +164,43 @@ struct RayCombiner {
 
 // trx_frame_loop's streams, events and device buffers (created on first use)
 struct FrameLoop {
+    static constexpr int kBuffers = 4; // primary-hit buffers: the primary passes may run this many frames ahead of the AO passes
     hipStream_t stream[2] = {nullptr, nullptr};
-    hipEvent_t prim_done[2] = {nullptr, nullptr}, ao_done[2] = {nullptr, nullptr}, t0 = nullptr, t1 = nullptr;
-    trx_hit *prim[2] = {nullptr, nullptr}, *ao = nullptr;
-    uint32_t *prim_inst[2] = {nullptr, nullptr}, *ao_inst = nullptr;
+    hipEvent_t prim_done[kBuffers] = {}, ao_done[kBuffers] = {}, t0 = nullptr, t1 = nullptr;
+    trx_hit *prim[kBuffers] = {}, *ao = nullptr;
+    uint32_t *prim_inst[kBuffers] = {}, *ao_inst = nullptr;
     uint64_t records = 0;
+};
+
+// trx_traverse1 over single-level scenes: a RESIDENT kernel answers the callers' rays out of a ring in pinned host memory
+// (kernels.h, kSvcRays; kernel side in trace_service.inc) - no launch, no stream synchronisation per ray.  A caller claims
+// a slot, writes its ray as three 16-byte granules that carry a fresh sequence number, and spins on the slot's answer
+// word.  The kernel is started by the first call and stopped by a watchdog thread after kIdleStopNs without a call (or by
+// trx_scene_destroy), so that device-wide synchronisations elsewhere in the process wait for it no longer than that; the
+// same thread bumps the heartbeat without which the kernel leaves by itself.
+struct RayService {
+    static constexpr uint32_t kGroups = 8, kSlots = kGroups * trx::kSvcRays;
+    static constexpr int64_t kIdleStopNs = 50 * 1000 * 1000, kBeatNs = 2 * 1000 * 1000, kGiveUpNs = 5LL * 1000 * 1000 * 1000;
+    trx_scene *scene = nullptr;
+    uint32_t sem = 0;
+    uint32_t *ring = nullptr, *ctl = nullptr; // pinned, device-visible
+    hipStream_t stream = nullptr;
+    std::mutex mu;                    // start / stop
+    std::atomic<bool> running{false};
+    std::atomic<int> inside{0};
+    std::atomic<int64_t> last_use_ns{0};
+    std::atomic<uint32_t> busy[kSlots];
+    uint32_t seq[kSlots];             // last sequence number used on the slot (its current owner's to bump)
+    std::thread watchdog;
+    std::atomic<bool> quit{false};
+    bool ok = false;
+    std::string init_err;
+    std::atomic<uint64_t> starts{0}, rays{0};
+    std::atomic<uint64_t> walk_ticks{0}, walk_trips{0}, call_ns{0}; // statistics (TRX_SERVICE_STATS=1 prints them when the service goes)
+    RayService(trx_scene *s, uint32_t semantics);
+    ~RayService();
+    int start_locked();  // mu held
+    void stop_locked();  // mu held
 };
 
 struct trx_scene {
@@ -197,8 +231,10 @@ struct trx_scene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<uint32_t> blas_tri_start; // geometry_id lookup for trx_traverse1
     FrameLoop loop;                // trx_frame_loop
-    RayCombiner *comb = nullptr;   // trx_traverse1: concurrent single-ray callers share launches (created on first use)
+    RayCombiner *comb = nullptr;   // trx_traverse1 over two-level scenes: concurrent single-ray callers share launches (created on first use)
     std::once_flag comb_once;
+    RayService *svc[8] = {};       // trx_traverse1 over single-level scenes: one resident kernel per semantics word in use
+    std::mutex svc_mu;             // creation of the services
     // instance transforms (TLAS scenes): object-to-world as given (get_instance_transform), world-to-object rows as
     // the kernels use them, and their device copy; empty / null = identity
     std::vector<float> inst_o2w, inst_w2o;

@@ -58,10 +58,10 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
         if (s->slots[i].used && s->slots[i].last_stream == stream) pick = i;
     for (int i = 0; i < kSlots && pick < 0; i++)
         if (!s->slots[i].used) pick = i;
-    if (pick < 0) {
-        pick = 0;
-        for (int i = 1; i < kSlots; i++)
-            if (s->slots[i].last_use < s->slots[pick].last_use) pick = i;
+    if (pick < 0) { // the oldest slot no resident kernel sits on (at most kSlots - 1 are pinned: one per ray service)
+        for (int i = 0; i < kSlots; i++)
+            if (!s->slots[i].pinned && (pick < 0 || s->slots[i].last_use < s->slots[pick].last_use)) pick = i;
+        if (pick < 0) return fail(TRX_ERR_INVALID, "every launch slot of the scene is held by a resident kernel");
     }
     Slot &slot = s->slots[pick];
     const bool same_stream = slot.used && slot.last_stream == stream;
@@ -71,8 +71,10 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     // incoherent single-level passes (AO, explicit rays) run two waves to a workgroup, so that the second can hand its last rays to the first
     // when both are draining (kernels.hip, "drain"); an explicit 1 or 4 here switches that off
     // (two-level scenes: explicit rays only, see kMerge in kernels.hip)
-    const bool merge_default = (wpb != 1 && wpb != 2 && wpb != 4) && mode != kModePrimary && mode != kModeFused && (!s->tlas || mode == kModeRays) && !count;
+    const bool merge_default = (wpb != 1 && wpb != 2 && wpb != 4) && mode != kModePrimary && mode != kModeFused && mode != kModeService &&
+                               (!s->tlas || mode == kModeRays) && !count;
     if (wpb != 1 && wpb != 2 && wpb != 4) wpb = merge_default ? 2u : kDefaultWavesPerBlock;
+    if (mode == kModeService) wpb = 2u; // a walker and a porter (kernels.h, kSvcRays); n_items = 64 per WAVE of the grid
     const uint32_t per_cu = (variant >> 8) & 0x1fu;
     int grid = per_cu ? (int)(std::min(per_cu, 32u) * (uint32_t)s->cu_count) : s->grid;
     // no more waves than chunks of work: a batch of one ray (trx_traverse1) is a one-wave launch with a
@@ -196,7 +198,10 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     p.single_queue = ((variant >> 21) & 1u) | (p.single_queue ? 1u : 0u); // (a caller may ask for it: trx_traverse1's small batches)
     // tile order feedback (image modes, whole-tile refills only)
     // (an AO batch deals its tiles seed by seed within a queue: it has no tile order to learn)
-    const bool lpt = mode != kModeRays && mode != kModeFused && p.refill_idle == 64u && !((variant >> 20) & 1u) &&
+    // (Round 6 tried an order for one-seed AO passes with mid-tile refills as well - first pass of a view natural, second
+    // measuring with whole tiles, then replayed frozen: hairball-class pass 0.809 -> 0.799 ms, bistro-class 0.892 -> 0.895,
+    // profiles/r06_ab_ao_tile_order.log - the longest rays take the whole pass wherever they start, as round 3 found; removed.)
+    const bool lpt = mode != kModeRays && mode != kModeFused && mode != kModeService && p.refill_idle == 64u && !((variant >> 20) & 1u) &&
                      !(mode == kModeAo && p.n_frames > 1);
     // the drain's parking area covers the second wave's parked tile-list entries (lds_pend): a pass that files tiles
     // (whole-tile refills with the order feedback on - reachable for AO through trx_set_kernel_variant) does not merge
@@ -303,9 +308,11 @@ int enqueue(trx_scene *s, TraceParams &p, int mode, uint32_t sem, bool count, hi
     if (p.tune & 0x1000u) pipe = true;
     if (p.tune & 0x10000u) pipe = false;
 #endif
+    if (mode == kModeService) pipe = false;
     HIP_TRY(launch_trace(p, mode, s->tlas, sem, count, pipe, grid, stream));
     HIP_TRY(hipEventRecord(slot.done, stream));
     slot.used = true;
+    if (mode == kModeService) slot.pinned = true; // (until the service is stopped: RayService::stop_locked)
     if (ctr_out) *ctr_out = slot.ctr;
     return TRX_OK;
 }

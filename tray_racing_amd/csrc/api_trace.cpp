@@ -404,8 +404,9 @@ int trx_trace_primary_ao_inst(trx_scene *s, const trx_view *view, uint32_t w, ui
 // The reference's frame loop, device-resident (src/rt_gpu/rt_gpu_software.rs:271-361: every frame a primary pass and the AO
 // pass over its hits, --animate advancing the noise seed).  Serial: both passes of every frame on one stream, back to back -
 // what trx_trace_primary_ao does per call, without the host in between.  Overlapped: the primary passes on stream A, the AO
-// passes on stream B; AO(i) waits for primary(i), primary(i + 2) waits for AO(i) (two primary buffers), so frame i's AO pass -
-// whose last few hundred rays run alone on an almost idle GPU - overlaps frame i + 1's primary pass.  Each stream keeps its
+// passes on stream B; AO(i) waits for primary(i), primary(i + 4) waits for AO(i) (four primary-hit buffers), so frame i's AO
+// pass - whose last few hundred rays run alone on an almost idle GPU - overlaps a later frame's primary pass and the
+// primary passes' own tails overlap AO passes.  Each stream keeps its
 // launch slot and so its tile order (api_launch.cpp); the records are those of the serial loop.
 int trx_frame_loop(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, uint32_t sem, uint32_t frame0, int animate,
                    float ao_eps, uint32_t n_frames, int overlap, trx_hit *out_primary, trx_hit *out_ao, float *out_ms) {
@@ -418,7 +419,7 @@ int trx_frame_loop(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, u
     FrameLoop &fl = s->loop;
     if (!fl.stream[0]) {
         for (int k = 0; k < 2; k++) HIP_TRY(hipStreamCreateWithFlags(&fl.stream[k], hipStreamNonBlocking));
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < FrameLoop::kBuffers; k++) {
             HIP_TRY(hipEventCreateWithFlags(&fl.prim_done[k], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&fl.ao_done[k], hipEventDisableTiming));
         }
@@ -427,7 +428,7 @@ int trx_frame_loop(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, u
     }
     if (fl.records < n) {
         for (int k = 0; k < 2; k++) HIP_TRY(hipStreamSynchronize(fl.stream[k]));
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < FrameLoop::kBuffers; k++) {
             if (fl.prim[k]) (void)hipFree(fl.prim[k]);
             if (fl.prim_inst[k]) (void)hipFree(fl.prim_inst[k]);
             fl.prim[k] = nullptr;
@@ -438,7 +439,7 @@ int trx_frame_loop(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, u
         fl.ao = nullptr;
         fl.ao_inst = nullptr;
         fl.records = 0;
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < FrameLoop::kBuffers; k++) {
             HIP_TRY(hipMalloc(&fl.prim[k], n * sizeof(trx_hit)));
             if (s->tlas) HIP_TRY(hipMalloc(&fl.prim_inst[k], n * sizeof(uint32_t)));
         }
@@ -451,8 +452,8 @@ int trx_frame_loop(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, u
     HIP_TRY(hipEventRecord(fl.t0, sa));
     int rc = TRX_OK;
     for (uint32_t i = 0; i < n_frames && rc == TRX_OK; i++) {
-        const int b = (int)(i & 1u);
-        if (i >= 2 && overlap) HIP_TRY(hipStreamWaitEvent(sa, fl.ao_done[b], 0)); // AO(i - 2) has read this primary buffer
+        const int b = (int)(i % (uint32_t)FrameLoop::kBuffers);
+        if (i >= (uint32_t)FrameLoop::kBuffers && overlap) HIP_TRY(hipStreamWaitEvent(sa, fl.ao_done[b], 0)); // AO(i - 4) has read this buffer
         rc = trx_trace_primary_inst_dev(s, view, w, h, whole, sem, fl.prim[b], fl.prim_inst[b], sa);
         if (rc) break;
         if (overlap) {
@@ -464,7 +465,7 @@ int trx_frame_loop(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, u
         if (rc) break;
         if (overlap) HIP_TRY(hipEventRecord(fl.ao_done[b], sb));
     }
-    if (rc == TRX_OK && overlap) HIP_TRY(hipStreamWaitEvent(sa, fl.ao_done[(n_frames - 1u) & 1u], 0));
+    if (rc == TRX_OK && overlap) HIP_TRY(hipStreamWaitEvent(sa, fl.ao_done[(n_frames - 1u) % (uint32_t)FrameLoop::kBuffers], 0));
     if (rc == TRX_OK) HIP_TRY(hipEventRecord(fl.t1, sa));
     // (whatever happened, nothing of this call is left in flight when it returns)
     const hipError_t e0 = hipStreamSynchronize(fl.stream[0]), e1 = hipStreamSynchronize(fl.stream[1]);
@@ -472,7 +473,7 @@ int trx_frame_loop(trx_scene *s, const trx_view *view, uint32_t w, uint32_t h, u
     HIP_TRY(e0);
     HIP_TRY(e1);
     if (out_ms) HIP_TRY(hipEventElapsedTime(out_ms, fl.t0, fl.t1));
-    const int last = (int)((n_frames - 1u) & 1u);
+    const int last = (int)((n_frames - 1u) % (uint32_t)FrameLoop::kBuffers);
     if (out_primary) HIP_TRY(hipMemcpy(out_primary, fl.prim[last], n * sizeof(trx_hit), hipMemcpyDeviceToHost));
     if (out_ao) HIP_TRY(hipMemcpy(out_ao, fl.ao, n * sizeof(trx_hit), hipMemcpyDeviceToHost));
     for (Slot &sl : s->slots) {

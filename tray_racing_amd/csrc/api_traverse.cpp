@@ -19,6 +19,120 @@ static inline void cpu_relax() {
 #endif
 }
 
+// ---- the ray service (single-level scenes): host side ----------------------------------------------------------------
+#include <emmintrin.h>
+
+// Every live service, so that a process that exits without destroying its scenes still stops its resident kernels first
+// (the HIP runtime's own teardown would otherwise meet a kernel that waits for a heartbeat nobody sends any more).
+static std::mutex g_services_mu;
+static std::vector<RayService *> g_services;
+static void stop_services_at_exit() {
+    std::lock_guard<std::mutex> lock(g_services_mu);
+    for (RayService *v : g_services) {
+        v->quit.store(true, std::memory_order_release);
+        if (v->watchdog.joinable()) v->watchdog.join();
+        std::lock_guard<std::mutex> l2(v->mu);
+        v->stop_locked();
+    }
+    g_services.clear();
+}
+
+RayService::RayService(trx_scene *s, uint32_t semantics) : scene(s), sem(semantics) {
+    for (auto &b : busy) b.store(0u, std::memory_order_relaxed);
+    std::memset(seq, 0, sizeof(seq));
+    hipError_t e = hipHostMalloc((void **)&ring, (size_t)kSlots * kSvcSlotWords * 4, hipHostMallocCoherent | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctl, 64, hipHostMallocCoherent | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        init_err = hipGetErrorString(e);
+        return;
+    }
+    std::memset(ring, 0, (size_t)kSlots * kSvcSlotWords * 4);
+    std::memset(ctl, 0, 64);
+    last_use_ns.store(now_ns(), std::memory_order_relaxed);
+    try {
+        watchdog = std::thread([this]() {
+            (void)hipSetDevice(scene->device);
+            int64_t beat = 0;
+            while (!quit.load(std::memory_order_acquire)) {
+                std::this_thread::sleep_for(std::chrono::nanoseconds(kBeatNs));
+                reinterpret_cast<volatile uint32_t *>(ctl)[1] = (uint32_t)++beat;
+                if (running.load(std::memory_order_acquire) && inside.load(std::memory_order_acquire) == 0 &&
+                    now_ns() - last_use_ns.load(std::memory_order_relaxed) > kIdleStopNs) {
+                    std::lock_guard<std::mutex> lock(mu);
+                    if (inside.load(std::memory_order_acquire) == 0) stop_locked();
+                }
+            }
+        });
+    } catch (const std::exception &) {
+        init_err = "could not start the service's watchdog thread";
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_services_mu);
+        static bool registered = false;
+        if (!registered) {
+            registered = true;
+            std::atexit(stop_services_at_exit);
+        }
+        g_services.push_back(this);
+    }
+    ok = true;
+}
+
+RayService::~RayService() {
+    if (getenv("TRX_SERVICE_STATS") && rays.load() != 0) {
+        const double n = (double)rays.load();
+        fprintf(stderr, "[trx ray service sem %u] %llu rays, %llu starts: %.2f us per call from post to answer, of which %.2f us between "
+                        "admission and answer on the GPU (%.1f trips of the walk)\n", sem, (unsigned long long)rays.load(),
+                (unsigned long long)starts.load(), call_ns.load() / n * 1e-3, walk_ticks.load() / n * 1e-2, walk_trips.load() / n);
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_services_mu);
+        g_services.erase(std::remove(g_services.begin(), g_services.end(), this), g_services.end());
+    }
+    quit.store(true, std::memory_order_release);
+    if (watchdog.joinable()) watchdog.join();
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        stop_locked();
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+    if (ring) (void)hipHostFree(ring);
+    if (ctl) (void)hipHostFree(ctl);
+}
+
+int RayService::start_locked() {
+    if (running.load(std::memory_order_acquire)) return TRX_OK;
+    reinterpret_cast<volatile uint32_t *>(ctl)[0] = 0u;
+    TraceParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.n_items = 2u * kGroups * 64u; // (a chunk per wave: enqueue() sizes the grid from it - kGroups workgroups of two waves)
+    p.n_frames = 1;
+    p.svc_ring = ring;
+    p.svc_ctl = ctl;
+    const int rc = enqueue(scene, p, kModeService, sem, false, stream, nullptr);
+    if (rc) return rc;
+    running.store(true, std::memory_order_release);
+    starts.fetch_add(1, std::memory_order_relaxed);
+    return TRX_OK;
+}
+
+void RayService::stop_locked() {
+    if (!running.load(std::memory_order_acquire)) return;
+    (void)hipSetDevice(scene->device);
+    reinterpret_cast<volatile uint32_t *>(ctl)[0] = 1u;
+    (void)hipStreamSynchronize(stream);
+    {
+        std::lock_guard<std::mutex> lock(scene->mu);
+        for (Slot &sl : scene->slots)
+            if (sl.used && sl.last_stream == stream) sl.pinned = false;
+    }
+    running.store(false, std::memory_order_release);
+}
+
+static int traverse1_service(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *out);
+
 extern "C" {
 
 // {t, global triangle} (+ the TLAS primitive it was found in) as obvhs' RayHit: (geometry_id, primitive_id local to
@@ -45,6 +159,8 @@ static void to_rayhit(const trx_scene *s, const trx_hit h, uint32_t inst, trx_ra
 int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *out) {
     if (!s || !ray || !out) return fail(TRX_ERR_INVALID, "null argument");
     if (sem & ~7u) return fail(TRX_ERR_INVALID, "unknown semantics bits 0x%x", sem);
+    // single-level scenes: the resident ray service (no launch per ray); two-level scenes: the combiner below
+    if (!s->tlas) return traverse1_service(s, ray, sem, out);
     HIP_TRY(hipSetDevice(s->device));
     std::call_once(s->comb_once, [s]() { s->comb = new (std::nothrow) RayCombiner(s->device); });
     RayCombiner *c = s->comb;
@@ -63,7 +179,11 @@ int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *ou
                 bi = c->open;
                 break;
             }
-            c->cv.wait(lock); // an open batch of another semantics closes within kMaxWait: wait for it rather than mix
+            // an open batch of another semantics closes within kMaxWait: wait for it rather than mix.  (Counted: such a caller
+            // is inside trx_traverse1 but will not join the open batch, so its leader must not expect it.)
+            c->waiting++;
+            c->cv.wait(lock);
+            c->waiting--;
             continue;
         }
         for (int i = 0; i < (int)RayCombiner::kBatches && bi < 0; i++)
@@ -79,7 +199,9 @@ int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *ou
             leader = true;
             break;
         }
+        c->waiting++;
         c->cv.wait(lock); // every batch is in flight or being read: one frees up when its last reader leaves
+        c->waiting--;
     }
     RayCombiner::Batch &b = c->batch[bi];
     const uint32_t idx = b.n++;
@@ -106,7 +228,7 @@ int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *ou
             for (int j = 0; j < (int)RayCombiner::kBatches; j++)
                 if (j != bi && c->batch[j].state != RayCombiner::Batch::kFree)
                     elsewhere += c->batch[j].n - std::min(c->batch[j].n, c->batch[j].read.load(std::memory_order_relaxed));
-            const int expected = c->inside.load(std::memory_order_relaxed) - (int)elsewhere;
+            const int expected = c->inside.load(std::memory_order_relaxed) - (int)elsewhere - c->waiting;
             if (((int)b.n >= expected && t - t_last > RayCombiner::kQuietNs) || t - t0 > RayCombiner::kMaxWaitNs) break;
         }
         if (c->open == bi) c->open = -1;
@@ -212,6 +334,11 @@ int trx_debug_traverse1_stats(trx_scene *s, uint64_t *out_launches, uint64_t *ou
         l = s->comb->launches;
         r = s->comb->rays;
     }
+    for (RayService *v : s->svc)
+        if (v) { // (the service launches once per start, not per ray)
+            l += v->starts.load(std::memory_order_relaxed);
+            r += v->rays.load(std::memory_order_relaxed);
+        }
     if (out_launches) *out_launches = l;
     if (out_rays) *out_rays = r;
     return TRX_OK;
@@ -236,3 +363,94 @@ int trx_traverse_batch(trx_scene *s, const trx_ray *rays, uint64_t n, uint32_t s
 }
 
 } // extern "C"
+
+// Traversable::traverse through the ray service: claim a slot, post the ray, spin for the answer.
+static int traverse1_service(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *out) {
+    RayService *v = s->svc[sem & 7u];
+    if (!v) {
+        std::lock_guard<std::mutex> lock(s->svc_mu);
+        v = s->svc[sem & 7u];
+        if (!v) {
+            HIP_TRY(hipSetDevice(s->device));
+            v = new (std::nothrow) RayService(s, sem);
+            if (!v || !v->ok) {
+                const std::string why = v ? v->init_err : "allocation failed";
+                delete v;
+                return fail(TRX_ERR_OOM, "ray service: %s", why.c_str());
+            }
+            s->svc[sem & 7u] = v;
+        }
+    }
+    struct Inside {
+        RayService *v;
+        explicit Inside(RayService *p) : v(p) { v->inside.fetch_add(1, std::memory_order_acq_rel); }
+        ~Inside() {
+            v->last_use_ns.store(now_ns(), std::memory_order_relaxed);
+            v->inside.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    } inside(v);
+    auto ensure_running = [&]() -> int {
+        if (v->running.load(std::memory_order_acquire)) return TRX_OK;
+        std::lock_guard<std::mutex> lock(v->mu);
+        HIP_TRY(hipSetDevice(s->device));
+        return v->start_locked();
+    };
+    int rc = ensure_running();
+    if (rc) return rc;
+    // a slot of one's own: the thread's last slot if it is free, else the next free one.  Callers are spread over the
+    // workgroups first (position j of the order = workgroup j % kGroups, ray j / kGroups of it): walkers on different CUs
+    // step their rays side by side, the rays of one walker step together.
+    static std::atomic<uint32_t> next_thread{0};
+    thread_local uint32_t my_pos = next_thread.fetch_add(1, std::memory_order_relaxed) % RayService::kSlots;
+    auto slot_at = [](uint32_t j) { return (j % RayService::kGroups) * trx::kSvcRays + (j / RayService::kGroups) % trx::kSvcRays; };
+    uint32_t k = slot_at(my_pos);
+    for (uint32_t tries = 0;; tries++) {
+        uint32_t expect = 0u;
+        if (v->busy[k].compare_exchange_strong(expect, 1u, std::memory_order_acquire)) break;
+        my_pos = (my_pos + 1u) % RayService::kSlots;
+        k = slot_at(my_pos);
+        if (tries > RayService::kSlots) std::this_thread::yield(); // more callers than slots: wait for one
+    }
+    uint32_t seq = v->seq[k] + 1u;
+    if (seq == 0u) seq = 1u;
+    v->seq[k] = seq;
+    uint32_t *slot = v->ring + (size_t)k * kSvcSlotWords;
+    const float tmax = ray->tmax;
+    // three 16-byte stores, each whole on its own (the kernel takes the request once all three carry `seq`)
+    auto bits = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
+    _mm_store_si128(reinterpret_cast<__m128i *>(slot), _mm_set_epi32((int)seq, bits(ray->origin[2]), bits(ray->origin[1]), bits(ray->origin[0])));
+    _mm_store_si128(reinterpret_cast<__m128i *>(slot + 4), _mm_set_epi32((int)seq, bits(ray->direction[2]), bits(ray->direction[1]), bits(ray->direction[0])));
+    _mm_store_si128(reinterpret_cast<__m128i *>(slot + 8), _mm_set_epi32((int)seq, 0, bits(tmax), bits(ray->tmin)));
+    _mm_sfence();
+    const volatile uint32_t *ans = slot + 16;
+    const int64_t t0 = now_ns();
+    const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+    for (uint32_t spins = 0; ans[3] != seq; spins++) {
+        if (v->inside.load(std::memory_order_relaxed) > cores) std::this_thread::yield();
+        else cpu_relax();
+        if ((spins & 0x3ffu) == 0x3ffu) {
+            // (the service stops itself after 50 ms without callers; one that arrives at that very moment starts it again -
+            // its request is still in the ring)
+            rc = ensure_running();
+            if (rc || now_ns() - t0 > RayService::kGiveUpNs) {
+                v->busy[k].store(0u, std::memory_order_release);
+                return rc ? rc : fail(TRX_ERR_NO_DEVICE, "the ray service did not answer within %lld s", (long long)(RayService::kGiveUpNs / 1000000000));
+            }
+        }
+    }
+    const __m128i a = _mm_load_si128(reinterpret_cast<const __m128i *>(slot + 16));
+    alignas(16) uint32_t w[4];
+    _mm_store_si128(reinterpret_cast<__m128i *>(w), a);
+    v->busy[k].store(0u, std::memory_order_release);
+    v->rays.fetch_add(1, std::memory_order_relaxed);
+    if (w[3] != seq) return fail(TRX_ERR_NO_DEVICE, "the ray service's answer was torn");
+    v->walk_ticks.fetch_add((w[2] >> 1) & 0x7fffu, std::memory_order_relaxed);
+    v->walk_trips.fetch_add(w[2] >> 16, std::memory_order_relaxed);
+    v->call_ns.fetch_add((uint64_t)(now_ns() - t0), std::memory_order_relaxed);
+    if (w[2] & 1u) return fail(TRX_ERR_STACK_OVERFLOW, "a ray overflowed the %d-entry traversal stack (or the step cap)", kLdsStack + kSpillStack);
+    trx_hit h;
+    std::memcpy(&h.t, &w[0], 4);
+    h.prim = w[1];
+    to_rayhit(s, h, 0xFFFFFFFFu, out);
+    return TRX_OK;
+}

@@ -44,7 +44,25 @@ constexpr uint32_t kMaxSteps = 1u << 22; // per-ray iteration cap: every wave re
 
 // kModeFused: the reference's whole pixel program in one launch (rt_gpu_software.hlsl:47-144): a lane whose primary
 // ray ends in a hit becomes that pixel's AO ray in place
-enum TraceMode : int { kModePrimary = 0, kModeAo = 1, kModeRays = 2, kModeFused = 3 };
+// kModeService: a resident kernel that answers single-ray requests out of a ring in pinned host memory (trx_traverse1:
+// Traversable::traverse called ray by ray from a thread pool, src/rt_cpu/rt_cpu.rs:35-57) - no launch per ray, see below
+enum TraceMode : int { kModePrimary = 0, kModeAo = 1, kModeRays = 2, kModeFused = 3, kModeService = 4 };
+
+// The ray service (k_trace<kModeService>; api_traverse.cpp holds the host side).  A workgroup is two waves: the WALKER
+// steps up to kSvcRays rays, eight lanes to a ray (the thin walk of an incoherent pass's last rays), and never touches
+// host memory - a load from it takes 1.5-2 us, and a wave's loads return in order, so a poll in flight would hold up
+// every node fetch behind it; the PORTER polls the workgroup's kSvcRays request slots, hands complete requests to the
+// walker through mailboxes in LDS and carries the walker's answers back to the slots' answer words.
+//   slot k of the ring = 128 bytes: [0..47] the request, three 16-byte granules {ox oy oz seq}{dx dy dz seq}{tmin tmax 0
+// seq}, each written by ONE 16-byte store of the host (a request is complete when the three carry the same seq, and new
+// when that differs from the slot's last answer); [64..79] the answer {t, prim, overflow, seq}, one 16-byte store of the
+// GPU.  Host and GPU never write the same 64-byte line.
+//   control words (pinned host memory): [0] != 0: leave (set when no caller is inside trx_traverse1); [1] a heartbeat
+// the host bumps every few milliseconds while the service is up - a porter that sees it stand still for kSvcDeadTicks of
+// the 100 MHz wall clock takes the host for dead and leaves as well: every wave of the grid reaches its exit.
+constexpr uint32_t kSvcRays = 8;                 // request slots per workgroup (one ray per eight lanes of the walker)
+constexpr uint32_t kSvcSlotWords = 32;           // 128 bytes per slot
+constexpr unsigned long long kSvcDeadTicks = 200000000ull; // 2 s without a heartbeat
 
 constexpr int kMaxBatchFrames = 8;
 
@@ -145,6 +163,9 @@ struct TraceParams {
     uint32_t new_view;    // camera cut: the schedule tuner starts over
     uint32_t uni_decode;  // coherent primary walk: decode the child planes of a node step once per wave when every lane visits the same node
     uint32_t any_hit;     // explicit rays only: stop at the first accepted hit, write one byte (0/1) per ray
+    // kModeService: the request / answer ring and the control words (all pinned host memory), see kSvcRays
+    uint32_t *svc_ring;
+    const uint32_t *svc_ctl;
     uint32_t *over_host;  // null, or a word in pinned host memory that is set when a ray of THIS launch overflows (trx_traverse1:
                           // the caller learns it from the word, without a device-to-host copy of the slot's sticky counter)
     // frames per launch: primary passes - frame f = local_tile / tiles_per_frame uses views[f]; AO passes - one view

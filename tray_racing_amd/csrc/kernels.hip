@@ -688,6 +688,15 @@ __device__ __forceinline__ void flush_pending_plain(const TraceParams &P, uint32
     __builtin_amdgcn_wave_barrier();
 }
 
+// 16-byte and 8-byte accesses that go all the way to memory (`sc0 sc1`: system scope): the ray service's porter reads request
+// granules out of pinned host memory and writes answers there while the host looks on (trace_service.inc)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 sys_load128(const void *p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 // PIPE (BLAS-only walks): the fetch of a ray's NEXT node is issued right after the node test that names it, before
 // the triangle phase of the node just tested, so the two memory round trips of a step overlap (the next node does
 // not depend on the triangles' results, only its test does: it reads the shrunken t).  A ray then occupies its lane
@@ -702,6 +711,9 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 #include "trace_queues.inc"
 #include "trace_stack.inc"
 #include "trace_thin.inc"
+    if constexpr (MODE == kModeService) {
+#include "trace_service.inc"
+    } else {
     for (;;) {
         TRX_STAMP(k_pop);
 #include "trace_refill.inc"
@@ -746,6 +758,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
     }
     if (kThin && !kFused && go_thin) thin_all(); // returns with no ray left
 
+    }
+
 #include "trace_epilogue.inc"
 }
 
@@ -773,24 +787,30 @@ hipError_t launch_node(const TraceParams &p, int node, int grid, hipStream_t str
 
 template <int MODE>
 hipError_t launch_mode(const TraceParams &p, bool tlas, int node, bool count, bool pipe, int grid, hipStream_t stream) {
-    // (the one-launch frame exists for single-level scenes: the two-level walk has no registers to spare for the in-place
-    // hand-over - it spills - so trx_trace_frame_dev runs a two-level frame as two launches, api_trace.cpp)
-    if constexpr (MODE == kModeFused) {
-        if (tlas) return hipErrorInvalidValue;
-    } else
-    if (tlas) { // the two-level walk is not pipelined
-        if (count) return launch_node<MODE, true, false, true>(p, node, grid, stream);
-        return launch_node<MODE, true, false, false>(p, node, grid, stream);
-    }
-    // (coherent primary rays do not gain from the pipelined walk)
-    if constexpr (MODE != kModePrimary) {
-        if (pipe) {
-            if (count) return launch_node<MODE, false, true, true>(p, node, grid, stream);
-            return launch_node<MODE, false, true, false>(p, node, grid, stream);
+    if constexpr (MODE == kModeService) {
+        // (single-level scenes; the resident kernel is the plain thin walk: no pipelining, no counting)
+        if (tlas || count) return hipErrorInvalidValue;
+        return launch_node<MODE, false, false, false>(p, node, grid, stream);
+    } else {
+        // (the one-launch frame exists for single-level scenes: the two-level walk has no registers to spare for the in-place
+        // hand-over - it spills - so trx_trace_frame_dev runs a two-level frame as two launches, api_trace.cpp)
+        if constexpr (MODE == kModeFused) {
+            if (tlas) return hipErrorInvalidValue;
+        } else
+        if (tlas) { // the two-level walk is not pipelined
+            if (count) return launch_node<MODE, true, false, true>(p, node, grid, stream);
+            return launch_node<MODE, true, false, false>(p, node, grid, stream);
         }
+        // (coherent primary rays do not gain from the pipelined walk)
+        if constexpr (MODE != kModePrimary) {
+            if (pipe) {
+                if (count) return launch_node<MODE, false, true, true>(p, node, grid, stream);
+                return launch_node<MODE, false, true, false>(p, node, grid, stream);
+            }
+        }
+        if (count) return launch_node<MODE, false, false, true>(p, node, grid, stream);
+        return launch_node<MODE, false, false, false>(p, node, grid, stream);
     }
-    if (count) return launch_node<MODE, false, false, true>(p, node, grid, stream);
-    return launch_node<MODE, false, false, false>(p, node, grid, stream);
 }
 
 template <int MODE, bool TLAS, int NODE, bool PIPE, bool COUNT>
@@ -831,6 +851,7 @@ hipError_t launch_trace(const TraceParams &p, int mode, bool tlas, uint32_t sem,
     case kModeAo: return launch_mode<kModeAo>(p, tlas, node, count, pipe, grid, stream);
     case kModeRays: return launch_mode<kModeRays>(p, tlas, node, count, pipe, grid, stream);
     case kModeFused: return launch_mode<kModeFused>(p, tlas, node, count, pipe, grid, stream);
+    case kModeService: return launch_mode<kModeService>(p, tlas, node, count, pipe, grid, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -45,12 +45,38 @@ __global__ void __launch_bounds__(2 * kWave) k_fetch_probe(const uint4 *nodes, u
     sink[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
-// The streaming ceiling: one float4 in, one float4 out per lane and step, grid-stride over `n` float4 - the copy kernel the
-// platform guide measures (MI355X_MICROARCH.md: 6.29 TB/s read + written); hipMemcpyDtoD, which bench.py used until round 5,
-// reaches about 5.0 TB/s on the same box.
+// The streaming ceiling: float4 in, float4 out, grid-stride over `n` float4 - the copy kernel the platform guide measures
+// (MI355X_MICROARCH.md: 6.29 TB/s read + written); hipMemcpyDtoD, which bench.py used until round 5, reaches about 5.0 TB/s
+// on the same box.  U independent float4 per lane and trip (bytes in flight per lane), NT = non-temporal loads and stores;
+// trx_debug_copy_rate reports the fastest shape, as a ceiling should.
+template <int U, bool NT>
 __global__ void __launch_bounds__(256) k_copy_probe(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (size_t)(U - 1) * stride < n; i += (size_t)U * stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float4 *p = src + i + (size_t)u * stride;
+            if (NT) {
+                v[u].x = __builtin_nontemporal_load(&p->x); v[u].y = __builtin_nontemporal_load(&p->y);
+                v[u].z = __builtin_nontemporal_load(&p->z); v[u].w = __builtin_nontemporal_load(&p->w);
+            } else {
+                v[u] = *p;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float4 *q = dst + i + (size_t)u * stride;
+            if (NT) {
+                __builtin_nontemporal_store(v[u].x, &q->x); __builtin_nontemporal_store(v[u].y, &q->y);
+                __builtin_nontemporal_store(v[u].z, &q->z); __builtin_nontemporal_store(v[u].w, &q->w);
+            } else {
+                *q = v[u];
+            }
+        }
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
 }
 
 } // namespace
@@ -73,18 +99,24 @@ extern "C" int trx_debug_copy_rate(int device, uint64_t bytes, uint32_t reps, do
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     float best = 0.0f;
     if (e == hipSuccess) {
-        const int blocks = prop.multiProcessorCount * 8; // (2 048 lanes per CU in flight: the guide's shape)
-        for (uint32_t rep = 0; rep < reps + 2u && e == hipSuccess; rep++) { // (two warm-up passes)
-            e = hipEventRecord(e0, nullptr);
-            if (e == hipSuccess) {
-                k_copy_probe<<<blocks, 256, 0, nullptr>>>(src, dst, n);
-                e = hipGetLastError();
+        typedef void (*copy_kernel)(const float4 *, float4 *, size_t);
+        const copy_kernel shapes[4] = {k_copy_probe<1, false>, k_copy_probe<4, false>, k_copy_probe<1, true>, k_copy_probe<4, true>};
+        for (int shape = 0; shape < 4 && e == hipSuccess; shape++) {
+            for (int per_cu = 8; per_cu <= 32 && e == hipSuccess; per_cu *= 2) { // (2 048 .. 8 192 lanes per CU in flight)
+                const int blocks = prop.multiProcessorCount * per_cu;
+                for (uint32_t rep = 0; rep < reps + 1u && e == hipSuccess; rep++) { // (one warm-up pass per shape)
+                    e = hipEventRecord(e0, nullptr);
+                    if (e == hipSuccess) {
+                        hipLaunchKernelGGL(shapes[shape], dim3(blocks), dim3(256), 0, nullptr, src, dst, n);
+                        e = hipGetLastError();
+                    }
+                    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+                    if (e == hipSuccess) e = hipEventSynchronize(e1);
+                    float ms = 0.0f;
+                    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+                    if (e == hipSuccess && rep >= 1u && (best == 0.0f || ms < best)) best = ms;
+                }
             }
-            if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
-            if (e == hipSuccess) e = hipEventSynchronize(e1);
-            float ms = 0.0f;
-            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-            if (e == hipSuccess && rep >= 2u && (best == 0.0f || ms < best)) best = ms;
         }
     }
     if (e0) (void)hipEventDestroy(e0);
