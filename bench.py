@@ -318,16 +318,8 @@ def main():
         return v, c, T.scene_camera(args.scene)
 
     def build_flat(v, c, nthreads):
-        if args.builder == "ploc_gpu":
-            try:
-                lib.trx_set_build_device(local_rank)
-                lib.trx_set_build_reinsertion_batches(1)
-                lib.trx_set_build_reinsertion(0.02, 8)   # (the ratio comes from the build parameters: 0.15; 8 iterations)
-                return T.flat_build_params(v, c, T.build_params(), use_tlas=False, threads=nthreads)
-            finally:
-                lib.trx_set_build_device(-1)
-                lib.trx_set_build_reinsertion_batches(0)
-                lib.trx_set_build_preset(args.preset.encode())
+        if args.builder == "ploc_gpu":   # the preset's build with every stage on the device (trx_flat_build_preset_device)
+            return T.flat_build_preset_device(v, c, preset=args.preset, device=local_rank, threads=nthreads)
         return T.flat_build(v, c, use_tlas=False, threads=nthreads, preset=args.preset)
 
     stamp = build_stamp()
@@ -940,6 +932,21 @@ def main():
                                                         "the same build parameters; reinsertion in 8 whole-iteration batches (ratio 0.15); BVH2 stage, "
                                                         "reinsertion (searches and moves) and collapse + encoding on the GPU")
 
+        def leg_medium_build_gpu():
+            # (i") review item 8: the headline's own preset built with every stage on the device - trx_flat_build_preset_device:
+            #      the ploc_cwbvh pipeline under the preset's reinsertion budget - against the host preset's build time and walk
+            if not (args.scene == "bistro" and args.tris == 0 and not args.input):
+                return
+            ts = []
+            for _ in range(2):   # (the second build finds the device buffers and the module in place)
+                tg0 = time.time()
+                gflat = T.flat_build_preset_device(verts, counts, preset=args.preset, device=local_rank, threads=threads)
+                ts.append(time.time() - tg0)
+            legs["preset_build_gpu"] = tree_leg(gflat, min(ts), "preset %s, every stage on the GPU" % args.preset)
+            legs["preset_build_gpu"]["build_seconds_first"] = round(ts[0], 2)
+            legs["preset_build_gpu"]["host_preset_build_seconds"] = round(build_s, 2)
+            legs["preset_build_gpu"]["host_preset_nodes_per_ray"] = round(st.n_node / max(st.n_rays, 1), 2)
+
         def leg_no_wake():
             # (j) the timed region WITHOUT the wake frames: the GPU idles for a second (as it does while a host builds a scene),
             #     then the W warm-up steps and K timed steps run straight away, on clocks that are still coming up - what the
@@ -1004,7 +1011,8 @@ def main():
                          ("frame_loop_overlapped_ms", leg_frame_loop_overlapped), ("hairball_4spp", leg_hairball),
                          ("pipelined_mrays", leg_pipelined), ("hbm_copy_gbs", leg_hbm_copy), ("moving_camera_ms", leg_moving_camera),
                          ("dense_scene", leg_dense_scene), ("ploc_pipeline", leg_ploc_pipeline),
-                         ("ploc_pipeline_gpu_stages", leg_ploc_pipeline_gpu_stages), ("no_wake", leg_no_wake),
+                         ("ploc_pipeline_gpu_stages", leg_ploc_pipeline_gpu_stages), ("preset_build_gpu", leg_medium_build_gpu),
+                         ("no_wake", leg_no_wake),
                          ("traverse1_threads", leg_traverse1_threads), ("footprint", leg_footprint)):
             run_leg(name, fn)
             ctx.pop("tmp", None)
@@ -1190,8 +1198,9 @@ def main():
                              "%s-class procedural stand-in, %d tris, %d CWBVH nodes, primary rays %dx%d "
                              "(BASELINE.json configs[2])" % (args.scene, flat.n_tris, flat.n_nodes, w, h)),
                 "semantics": "TRX_SEM_CPU" if args.sem == 3 else "bits=%d" % args.sem,
-                "builder": ("PLOC BVH2 -> reinsertion (8 whole-iteration batches) -> SAH-optimal BVH8 collapse, the reference's "
-                            "command-line BvhBuildParams (src/main.rs:571-585), every stage on the GPU" if args.builder == "ploc_gpu" else
+                "builder": ("PLOC BVH2 (the reference's search parameters) -> reinsertion in whole-iteration batches -> SAH-optimal BVH8 "
+                            "collapse, every stage on the GPU, budget of preset %s (trx_flat_build_preset_device)" % args.preset
+                            if args.builder == "ploc_gpu" else
                             "binned-SAH BVH2 -> reinsertion pass -> SAH-optimal BVH8 collapse (stands in for obvhs "
                             "ploc_cwbvh), preset %s" % args.preset),
                 "parallelism": ("one GPU owns every 8x8 tile" if world == 1 else

@@ -159,3 +159,33 @@ def test_device_collapse_and_encoding_equal_the_host_stage(trx, orc, max_prims, 
         lib.trx_set_build_reinsertion_batches(0)
         lib.trx_set_build_costs(1.0, 0.3)
         lib.trx_set_build_preset(b"medium_build")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["very_fast_build", "medium_build", "slow_build"])
+def test_a_presets_build_with_every_stage_on_the_device(trx, orc, preset):
+    """Round 6 (review item 8): trx_flat_build_preset_device - the ploc_cwbvh pipeline (Morton sort + PLOC rounds,
+    whole-iteration reinsertion, collapse + encoding, all kernels) under a preset's reinsertion budget.  Its bytes are those
+    of the same pipeline on the host cores (device = -1), the tree validates against its triangles, and a frame traced
+    over it equals the oracle's."""
+    for name, n in (("bistro", 150000), ("hairball", 90000)):
+        verts, counts = trx.gen_scene(name, n, 1)
+        dev = trx.flat_build_preset_device(verts, counts, preset=preset, device=0)
+        host = trx.flat_build_preset_device(verts, counts, preset=preset, device=-1)
+        assert host.nodes.shape == dev.nodes.shape and (host.nodes == dev.nodes).all(), (name, preset)
+        assert (host.tri_source == dev.tri_source).all(), (name, preset)
+        osc = orc.Scene.from_flat(dev)
+        if preset != "slow_build":   # (pre-split references cover part of their triangle: validated against their build boxes)
+            assert osc.validate() == (0, "")
+        else:
+            assert osc.validate(boxes=dev.tri_boxes) == (0, "")
+        eye, look, fov = trx.scene_camera(name)
+        w, h = 96, 64
+        view = trx.view_from_camera(eye, look, fov, w, h)
+        sc = trx.Scene(dev)
+        got, _ = sc.trace_primary(view, w, h, sem=3)
+        sc.close()
+        want, _ = osc.trace_primary(orc.view_from_bytes(view), w, h, sem=3)
+        assert (got["prim"] == want["prim"]).all() and (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+    with pytest.raises(trx.TrxError, match="unknown preset"):
+        trx.flat_build_preset_device(verts, counts, preset="no_such_build", device=0)

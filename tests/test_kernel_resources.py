@@ -74,3 +74,57 @@ def test_stack_pops_are_lds_reads_and_the_node_fetch_is_not_waited_for_at_once()
         assert n >= 100, what + ": the node fetch is waited for after %d instructions" % n
         pipes += 1
     assert pipes == 3 * 4   # AO, explicit rays and the one-launch frame, four node-test semantics
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_scalar_registers_parked_in_lanes_inside_loops():
+    """Round 6 (review item 7).  The kernels carry more wave-uniform values than there are scalar registers; the compiler
+    parks the excess in lanes of a vector register (v_writelane / v_readlane on a register nothing else touches) - no
+    scratch, but every read-back is a vector issue slot.  Where are they?  Counted per kernel: all of them, and those
+    inside loops of depth >= 2 that take no work-queue ticket (= everything nested in the trip except the refill's loop:
+    the plain walk's loop, the triangle rounds).  Findings this test holds in place:
+      * the headline kernel k_trace<primary, BLAS, reciprocal arithmetic> has 14 inside its walk loop, ALL on the path
+        that reads or writes a stack entry past the LDS part (the base of the wave's HBM area) or in the decode stage of a
+        wave-uniform step (six lane-role masks); the pipelined AO kernel has 4 (triangle rounds);
+      * taking them out was built and measured (TRX_SPILL_BASE_LATE, TRX_DECODE_LANE_AFRESH): 0 in the loop, 76 instead of
+        128 in all - and the frame 0.7-1.2 % slower (another register assignment; profiles/r06_ab_lane_spills.log), so
+        the product keeps them.  The bound below is today's count plus a margin: a change that doubles it should be seen."""
+    import collections
+    subprocess.run(["make", "-C", CSRC, "build/kernels.s"], check=True, capture_output=True, timeout=600)
+    text = open(os.path.join(CSRC, "build", "kernels.s")).read()
+    inner, total = {}, {}
+    for (mode, tlas, node, pipe, count), body in _kernel_bodies(text):
+        if count or mode == 4:
+            continue
+        use = collections.defaultdict(set)
+        for l in body:
+            if not _is_inst(l):
+                continue
+            op = l.split()[0]
+            for v in re.findall(r"\bv(\d+)\b", l):
+                use[int(v)].add(op)
+            for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", l):
+                for v in range(int(a), int(b) + 1):
+                    use[v].add(op)
+        parked = {v for v, ops in use.items() if ops <= {"v_writelane_b32", "v_readlane_b32"}}
+        per_loop, ticket_loops, header, depth, n_all = collections.Counter(), set(), None, 0, 0
+        for l in body:
+            s = l.strip()
+            if re.match(r"^(\.LBB\d+_\d+:|; %bb\.)", s):
+                d = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", s)
+                header, depth = (d.group(1), int(d.group(2))) if d else (None, 0)
+                if not d and re.match(r"^\.LBB\d+_\d+:", s):   # a loop header's own label carries no such comment: next lines say
+                    header = None
+                continue
+            if depth >= 2 and "global_atomic_add" in s:
+                ticket_loops.add(header)
+            if s.startswith(("v_writelane_b32", "v_readlane_b32")) and any(int(v) in parked for v in re.findall(r"\bv(\d+)\b", s)):
+                n_all += 1
+                if depth >= 2:
+                    per_loop[header] += 1
+        inner[(mode, tlas, node, pipe)] = sum(n for h, n in per_loop.items() if h not in ticket_loops)
+        total[(mode, tlas, node, pipe)] = n_all
+    assert len(inner) >= 36
+    assert inner[(0, 0, 1, 0)] <= 16 and total[(0, 0, 1, 0)] <= 140, (inner[(0, 0, 1, 0)], total[(0, 0, 1, 0)])   # the bench line's kernel
+    assert inner[(1, 0, 1, 1)] <= 10, inner[(1, 0, 1, 1)]                                                         # the AO pass's kernel
+    assert max(inner.values()) <= 24 and max(total.values()) <= 400, (max(inner.values()), max(total.values()))

@@ -162,6 +162,7 @@ SIGNATURES = {
     "trx_flat_build": (_i, [_P, _P, _u32, _i, _u32, _i, C.POINTER(C.POINTER(Flat))]),
     "trx_flat_build_instanced": (_i, [_P, _P, _u32, _P, _P, _u32, _u32, _i, C.POINTER(C.POINTER(Flat))]),
     "trx_flat_build_params": (_i, [_P, _P, _u32, _i, C.POINTER(BuildParams), _i, C.POINTER(C.POINTER(Flat))]),
+    "trx_flat_build_preset_device": (_i, [_P, _P, _u32, _i, C.c_char_p, _u32, _i, _i, C.POINTER(C.POINTER(Flat))]),
     "trx_build_params_default": (None, [C.POINTER(BuildParams)]),
     "trx_flat_destroy": (None, [C.POINTER(Flat)]),
     "trx_gen_scene": (_i, [C.c_char_p, _u64, _u64, C.POINTER(C.POINTER(_f)), C.POINTER(_u64),

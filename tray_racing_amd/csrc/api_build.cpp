@@ -208,6 +208,41 @@ int trx_flat_build_params(const float *verts, const uint64_t *object_tri_counts,
     return flat_build_impl(verts, object_tri_counts, n_objects, use_tlas, bp->max_prims_per_leaf, threads, b, out);
 }
 
+// A preset's build with EVERY stage on the device (review item 8: the presets' own BVH2 stage is a top-down binned-SAH build
+// on the host cores, 0.2 s of a 0.96 s medium_build, followed by 0.39 s of one-at-a-time reinsertion searches that are
+// sequential by definition).  The device has no top-down builder; it has the whole ploc_cwbvh pipeline - Morton sort +
+// PLOC rounds, the reinsertion pass in whole-iteration batches (selection, searches, moves, refit), collapse + encoding -
+// so a preset built there is that pipeline with the reference's PLOC parameters (search distance 14, depth threshold 2,
+// 64-bit codes, src/main.rs:85-98) and a reinsertion budget per preset name, chosen so that medium_build's tree is walked
+// with no more node visits than the host preset's (bistro-class bench view: 17.46 against 17.82) in less than half its
+// build time.  device < 0: the same pipeline on the host cores - its twin, byte for byte (tests/test_gpu_builder.py).
+int trx_flat_build_preset_device(const float *verts, const uint64_t *object_tri_counts, uint32_t n_objects, int use_tlas,
+                                 const char *preset, uint32_t max_prims, int threads, int device, trx_flat **out) {
+    struct Budget { const char *name; float ratio; int iters; float split; };
+    static const Budget budgets[] = {{"fastest_build", 0.0f, 0, 0.0f}, {"very_fast_build", 0.05f, 2, 0.0f}, {"fast_build", 0.10f, 4, 0.0f},
+                                     {"medium_build", 0.15f, 8, 0.0f}, {"slow_build", 0.15f, 12, 0.3f},     {"very_slow_build", 0.30f, 16, 0.3f}};
+    if (!preset) return fail(TRX_ERR_INVALID, "preset is null");
+    const Budget *bu = nullptr;
+    for (const Budget &b : budgets)
+        if (std::strcmp(preset, b.name) == 0) bu = &b;
+    if (!bu) return fail(TRX_ERR_INVALID, "unknown preset '%s'", preset);
+    if (device >= 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || device >= n) return fail(TRX_ERR_NO_DEVICE, "no HIP device %d for the build", device);
+    }
+    BuildSettings b = build_settings(); // costs and re-braiding stay the caller's
+    b.ploc_distance = 14;
+    b.ploc_depth_threshold = 2;
+    b.ploc_sort_bits = 64;
+    b.ploc_device = device < 0 ? -1 : device;
+    b.reinsert_ratio = bu->ratio;
+    b.reinsert_iters = bu->iters;
+    b.reinsert_whole = true;
+    b.reinsert_batched = true;
+    b.pre_split = bu->split;
+    return flat_build_impl(verts, object_tri_counts, n_objects, use_tlas, max_prims, threads, b, out);
+}
+
 void trx_build_params_default(trx_build_params *bp) {
     if (!bp) return;
     // the defaults of the reference's command line (src/main.rs:85-124,158-163)

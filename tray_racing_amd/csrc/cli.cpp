@@ -239,7 +239,11 @@ Stats render_input(const Options &o, const std::string &input) {
         // the reference tree, so the names select this library's own settings of matching cost
         check(trx_set_build_costs(o.collapse_traversal_cost, 0.3f), "build costs");
         check(trx_set_build_preset(o.preset.c_str()), "preset");
-        check(trx_flat_build(verts, counts, n_objects, tlas ? 1 : 0, o.max_prims_per_leaf, 0, &flat), "build");
+        if (o.gpu_build) // every stage of the preset's build on the device (PLOC + whole-iteration reinsertion + collapse)
+            check(trx_flat_build_preset_device(verts, counts, n_objects, tlas ? 1 : 0, o.preset.c_str(), o.max_prims_per_leaf, 0, o.device,
+                                               &flat), "build");
+        else
+            check(trx_flat_build(verts, counts, n_objects, tlas ? 1 : 0, o.max_prims_per_leaf, 0, &flat), "build");
     }
     st.blas_build_time_s = flat->blas_build_s;
     st.tlas_build_time_ms = flat->tlas_build_s * 1000.0;

@@ -765,6 +765,8 @@ __global__ void __launch_bounds__(kMaxBlock, TRX_MIN_WAVES) k_trace(const TraceP
 
 
 #undef wave_global
+#undef spill
+#undef wray
 
 template <int MODE, bool TLAS, int NODE, bool PIPE, bool COUNT>
 hipError_t launch_one(const TraceParams &p, int grid, hipStream_t stream) {

@@ -229,6 +229,17 @@ def flat_build_params(verts, object_counts, params, use_tlas=False, threads=0):
     return _take_flat(lib, fp)
 
 
+def flat_build_preset_device(verts, object_counts, preset="medium_build", device=0, use_tlas=False, max_prims_per_leaf=3, threads=0):
+    """A preset's build with every stage on the device (trx_flat_build_preset_device); device < 0: its host twin."""
+    lib = L.load()
+    verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
+    counts = np.ascontiguousarray(object_counts if object_counts is not None else [verts.shape[0]], dtype=np.uint64)
+    fp = C.POINTER(L.Flat)()
+    L.check(lib.trx_flat_build_preset_device(_ptr(verts), _ptr(counts), counts.size, 1 if use_tlas else 0, preset.encode(),
+                                             max_prims_per_leaf, threads, device, C.byref(fp)))
+    return _take_flat(lib, fp)
+
+
 def pack_tris_f16(tri_verts):
     """obvhs RtCompressedTriangle (24 B): v0 f32x3 + f16 edges, e2 in the low half (query.hlsl:75-85)."""
     v = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
