@@ -992,12 +992,14 @@ def main():
             tb_hits, tb_ms = scene.traverse_batch(t1_rays, sem=args.sem)
             one_hits, one_s, _ = scene.traverse_threads(t1_rays[:2000], threads=1, sem=args.sem)
             legs["traverse1_threads"] = {
-                "threads": 16, "rays": n_t1, "mrays": round(n_t1 / t1_s / 1e6, 4), "launches": t1_launches,
-                "rays_per_launch": round(n_t1 / max(t1_launches, 1), 1), "us_per_launch": round(t1_s / max(t1_launches, 1) * 1e6, 1),
+                "threads": 16, "rays": n_t1, "mrays": round(n_t1 / t1_s / 1e6, 4),
+                # (single-level scenes since round 6: a resident kernel answers the calls - `service_starts` kernel launches for
+                # all of them instead of one per batch of callers)
+                "service_starts": t1_launches, "us_per_call_and_thread": round(t1_s / n_t1 * 16 * 1e6, 2),
                 "equals_traverse_batch": bool((t1_hits == tb_hits).all() and (one_hits == tb_hits[:2000]).all()),
                 "traverse_batch_kernel_mrays": round(n_t1 / (tb_ms * 1e-3) / 1e6, 1),
-                "one_thread_mrays": round(2000 / one_s / 1e6, 4),
-                "note": "one blocking trx_traverse1 call per ray from 16 host threads (and from one)",
+                "one_thread_mrays": round(2000 / one_s / 1e6, 4), "one_thread_us_per_call": round(one_s / 2000 * 1e6, 2),
+                "note": "one blocking trx_traverse1 call per ray from 16 host threads (and from one): Traversable::traverse, literally",
             }
 
         def leg_footprint():

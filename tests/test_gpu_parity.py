@@ -439,6 +439,48 @@ def test_stack_spill_to_hbm_and_overflow_detection(trx, orc):
     sc.close()
 
 
+def test_the_ray_service_walks_deep_stacks_and_reports_overflow_per_call(trx, orc):
+    """trx_traverse1 over a single-level scene is answered by the resident ray service (round 6), whose walker is the thin
+    walk: a stack past its LDS part goes to the wave's HBM area, one past 64 entries comes back as THIS call's
+    TRX_ERR_STACK_OVERFLOW (the answer carries it; the launch slot's sticky flag stays clear and the next call is served).
+    Eight threads at once, each ray checked against the oracle."""
+    import threading
+    for depth in (10, 13, 40, 64):
+        nodes, tris = deep_chain_scene(depth)
+        osc = orc.Scene(nodes, tris)
+        sc = trx.Scene(trx.FlatScene(nodes, tris, [], 0, np.arange(depth), [0, depth]))
+        rays = np.zeros(64, dtype=trx.RAY_DTYPE)
+        rays["origin"] = (0.3, 0.3, 1)
+        rays["direction"] = (0, 0, -1)
+        rays["origin"][1::2] = (0.3, 0.3, -100)
+        rays["direction"][1::2] = (0, 0, 1)
+        rays["tmax"] = F32_MAX
+        want, _ = osc.trace_rays(rays, sem=0)
+        bad = []
+
+        def work(ids):
+            for i in ids:
+                h = sc.traverse(rays["origin"][i], rays["direction"][i], sem=0)
+                if np.float32(h.t).view(np.uint32) != want["t"][i].view(np.uint32) or h.primitive_id != want["prim"][i]:
+                    bad.append((depth, i, h.t, h.primitive_id))
+        ts = [threading.Thread(target=work, args=(range(k, 64, 8),)) for k in range(8)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not bad, bad[:3]
+        sc.close()
+    nodes, tris = deep_chain_scene(70)
+    sc = trx.Scene(trx.FlatScene(nodes, tris, [], 0, np.arange(70), [0, 70]))
+    with pytest.raises(trx.TrxError) as e:
+        sc.traverse((0.3, 0.3, 1), (0, 0, -1), sem=0)
+    assert e.value.code == -4 and "overflowed" in str(e.value)
+    h = sc.traverse((0.3, 0.3, -100), (0, 0, 1), sem=0)   # the service goes on answering
+    assert h.primitive_id != 0xFFFFFFFF
+    sc.check()                                             # ... and no launch slot carries a sticky overflow
+    sc.close()
+
+
 # ---- the Traversable surface ---------------------------------------------------------------------
 
 def test_traverse_single_ray_and_concurrent_callers(trx, orc):

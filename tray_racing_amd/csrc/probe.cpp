@@ -49,31 +49,21 @@ __global__ void __launch_bounds__(2 * kWave) k_fetch_probe(const uint4 *nodes, u
 // (MI355X_MICROARCH.md: 6.29 TB/s read + written); hipMemcpyDtoD, which bench.py used until round 5, reaches about 5.0 TB/s
 // on the same box.  U independent float4 per lane and trip (bytes in flight per lane), NT = non-temporal loads and stores;
 // trx_debug_copy_rate reports the fastest shape, as a ceiling should.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <int U, bool NT>
-__global__ void __launch_bounds__(256) k_copy_probe(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
+__global__ void __launch_bounds__(256) k_copy_probe(const float4 *__restrict__ src4, float4 *__restrict__ dst4, size_t n) {
+    const f32x4_t *__restrict__ src = reinterpret_cast<const f32x4_t *>(src4);
+    f32x4_t *__restrict__ dst = reinterpret_cast<f32x4_t *>(dst4);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i + (size_t)(U - 1) * stride < n; i += (size_t)U * stride) {
-        float4 v[U];
+        f32x4_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = NT ? __builtin_nontemporal_load(src + i + (size_t)u * stride) : src[i + (size_t)u * stride];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const float4 *p = src + i + (size_t)u * stride;
-            if (NT) {
-                v[u].x = __builtin_nontemporal_load(&p->x); v[u].y = __builtin_nontemporal_load(&p->y);
-                v[u].z = __builtin_nontemporal_load(&p->z); v[u].w = __builtin_nontemporal_load(&p->w);
-            } else {
-                v[u] = *p;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            float4 *q = dst + i + (size_t)u * stride;
-            if (NT) {
-                __builtin_nontemporal_store(v[u].x, &q->x); __builtin_nontemporal_store(v[u].y, &q->y);
-                __builtin_nontemporal_store(v[u].z, &q->z); __builtin_nontemporal_store(v[u].w, &q->w);
-            } else {
-                *q = v[u];
-            }
+            if (NT) __builtin_nontemporal_store(v[u], dst + i + (size_t)u * stride);
+            else dst[i + (size_t)u * stride] = v[u];
         }
     }
     for (; i < n; i += stride) dst[i] = src[i];
@@ -100,8 +90,9 @@ extern "C" int trx_debug_copy_rate(int device, uint64_t bytes, uint32_t reps, do
     float best = 0.0f;
     if (e == hipSuccess) {
         typedef void (*copy_kernel)(const float4 *, float4 *, size_t);
-        const copy_kernel shapes[4] = {k_copy_probe<1, false>, k_copy_probe<4, false>, k_copy_probe<1, true>, k_copy_probe<4, true>};
-        for (int shape = 0; shape < 4 && e == hipSuccess; shape++) {
+        const copy_kernel shapes[6] = {k_copy_probe<1, false>, k_copy_probe<4, false>, k_copy_probe<8, false>,
+                                       k_copy_probe<1, true>,  k_copy_probe<4, true>,  k_copy_probe<8, true>};
+        for (int shape = 0; shape < 6 && e == hipSuccess; shape++) {
             for (int per_cu = 8; per_cu <= 32 && e == hipSuccess; per_cu *= 2) { // (2 048 .. 8 192 lanes per CU in flight)
                 const int blocks = prop.multiProcessorCount * per_cu;
                 for (uint32_t rep = 0; rep < reps + 1u && e == hipSuccess; rep++) { // (one warm-up pass per shape)
