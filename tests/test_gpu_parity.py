@@ -481,6 +481,43 @@ def test_the_ray_service_walks_deep_stacks_and_reports_overflow_per_call(trx, or
     sc.close()
 
 
+def test_the_ray_service_restarts_after_idling_and_serves_more_callers_than_slots(trx, orc):
+    """The resident kernel stops itself 50 ms after the last call (a device-wide synchronisation elsewhere waits no longer
+    than that) and the next call starts it again - its request is served all the same; 100 threads on its 64 slots wait
+    their turn; two scenes run a service each, side by side."""
+    import ctypes as C
+    import time
+    w, h = 48, 32
+    scenes = []
+    for name in ("kitchen", "bistro"):
+        flat, view, osc, ov = make_scene(trx, orc, name, 20000, w, h)
+        rays = osc.primary_rays(ov, w, h)
+        scenes.append((trx.Scene(flat), rays, osc.trace_rays(rays, sem=3)[0]))
+    lib = trx.load()
+
+    def starts(sc):
+        n = C.c_uint64()
+        assert lib.trx_debug_traverse1_stats(sc.handle, C.byref(n), None) == 0
+        return n.value
+    try:
+        for sc, rays, want in scenes:
+            got, _, _ = sc.traverse_threads(rays[:64], threads=4, sem=3)
+            assert (got["t"].view(np.uint32) == want["t"][:64].view(np.uint32)).all()
+        s0 = [starts(sc) for sc, _, _ in scenes]
+        assert min(s0) >= 1
+        time.sleep(0.4)                                   # both services have stopped themselves by now
+        import torch
+        torch.cuda.synchronize()                          # ... so a device-wide synchronisation returns at once
+        for (sc, rays, want), before in zip(scenes, s0):
+            got, _, _ = sc.traverse_threads(rays, threads=100, sem=3)   # more callers than slots
+            hit = want["prim"] != 0xFFFFFFFF
+            assert (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all() and (got["primitive_id"][hit] == want["prim"][hit]).all()
+            assert starts(sc) == before + 1               # one new start for the whole loop
+    finally:
+        for sc, _, _ in scenes:
+            sc.close()
+
+
 # ---- the Traversable surface ---------------------------------------------------------------------
 
 def test_traverse_single_ray_and_concurrent_callers(trx, orc):
