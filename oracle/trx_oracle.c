@@ -237,7 +237,7 @@ float orc_hash_noise(uint32_t x, uint32_t y, uint32_t frame) {
  * CORE-MATH based C library returns - differs from this algorithm by one ulp for 1.3 % of the arguments: the exposure
  * tool reports that column too.) */
 static int g_ao_libm = 0;
-/* Exposure measurement only (tools/semantics_exposure.py): AO directions from this platform's libm sinf / cosf (1), the
+/* Exposure measurement only (tests/analysis/semantics_exposure.py): AO directions from this platform's libm sinf / cosf (1), the
  * way the reference calls its platform's, or from a correctly rounded sin / cos (2: binary64 libm rounded once to
  * binary32), instead of the explicit evaluation below.  The product has no such switch. */
 void orc_set_ao_libm(int on) { g_ao_libm = on; }

@@ -4,7 +4,7 @@ is the HLSL (TRX_SEM_HLSL): rays of each BASELINE frame whose (t, prim) differ b
 (2) the AO directions using an explicit sin / cos where the reference calls its platform's: AO rays whose hit differs
 when this platform's libm sinf / cosf is used instead (since round 4 the explicit evaluation is glibc's own binary64
 algorithm, so on a glibc host this column is 0), and when a correctly rounded sin / cos is (another C library).
-Oracle only (CPU), full BASELINE sizes by default.  usage: python tools/semantics_exposure.py [--scale 4] [--json out]"""
+Oracle only (CPU), full BASELINE sizes by default.  usage: python tests/analysis/semantics_exposure.py [--scale 4] [--json out]"""
 import argparse
 import json
 import os
@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tray_racing_amd as T  # noqa: E402
 from oracle import binding as O  # noqa: E402
 

@@ -1,5 +1,5 @@
 /* spec_sim.c - development aid (CPU, links the oracle): how many TRIPS does one ray's walk take when every trip may
- * test up to G pending nodes of the ray ahead of the walk (tools/spec_sim.py drives it)?
+ * test up to G pending nodes of the ray ahead of the walk (tests/analysis/spec_sim.py drives it)?
  *
  * The sequential walk (query.hlsl:328-438) visits its nodes in depth-first order; every hit bit of the current group and
  * of the stacked groups names a node that WILL be fetched and tested (nothing on the stack is culled later), and what a
@@ -15,7 +15,7 @@
  *           filtered mask names triangles (they travel with the next trip's node fetches).
  * Output per ray: node visits, trips of A and B for G = 1, 2, 4, 8.
  */
-#include "../oracle/trx_oracle.h"
+#include "../../oracle/trx_oracle.h"
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -1,5 +1,5 @@
 """Development aid (CPU only, oracle side): trips of a lone ray's walk when up to G pending nodes are tested per trip
-(tools/spec_sim.c has the model).  usage: python tools/spec_sim.py [scene] [tris] [width] [height]"""
+(tests/analysis/spec_sim.c has the model).  usage: python tests/analysis/spec_sim.py [scene] [tris] [width] [height]"""
 import ctypes as C
 import os
 import subprocess
@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import tray_racing_amd as T  # noqa: E402
 from oracle import binding as O  # noqa: E402
@@ -17,7 +17,7 @@ tris = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 w = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
 h = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
 so = "/tmp/spec_sim.so"
-subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-ffp-contract=off", os.path.join(ROOT, "tools", "spec_sim.c"),
+subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-ffp-contract=off", os.path.join(ROOT, "tests", "analysis", "spec_sim.c"),
                        "-o", so, "-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
 O.load()
 sim = C.CDLL(so)

@@ -1,11 +1,11 @@
 """Oracle only (CPU): quality of the upper tree of a two-level scene - node visits per primary ray split into TLAS and BLAS
 visits, BLAS (sub)trees entered and triangle tests per ray - per re-braiding area fraction.
-usage: python tools/tlas_quality.py [scene] [scale] [fraction ...]   (default: san_miguel, image sides / 4)"""
+usage: python tests/analysis/tlas_quality.py [scene] [scale] [fraction ...]   (default: san_miguel, image sides / 4)"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tray_racing_amd as T  # noqa: E402
 from oracle import binding as O  # noqa: E402
 

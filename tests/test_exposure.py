@@ -1,4 +1,4 @@
-"""What "parity unpinned" can cost, measured on the oracle (CPU): tools/semantics_exposure.py at reduced size.
+"""What "parity unpinned" can cost, measured on the oracle (CPU): tests/analysis/semantics_exposure.py at reduced size.
 The full-size counts are committed as profiles/r04_semantics_exposure.{txt,json} and quoted in DESIGN.md section 3."""
 import importlib.util
 import json
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _tool():
-    spec = importlib.util.spec_from_file_location("semantics_exposure", os.path.join(ROOT, "tools", "semantics_exposure.py"))
+    spec = importlib.util.spec_from_file_location("semantics_exposure", os.path.join(ROOT, "tests", "analysis", "semantics_exposure.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
