@@ -1133,6 +1133,24 @@ def test_frame_loop_keeps_one_tile_order_per_pass_kind(trx, orc):
         sc.close()
 
 
+def test_frame_loop_over_a_two_level_scene(trx, orc):
+    """trx_frame_loop over a TLAS scene (its passes carry instance ids between them; the two-level AO kernel has neither thin
+    waves nor the drain hand-over): serial and overlapped, last frame equal to the oracle's primary + AO frame."""
+    w, h = 200, 120
+    flat, view, osc, ov = make_scene(trx, orc, "san_miguel", 120000, w, h, tlas=True)
+    want_p = osc.trace_primary(ov, w, h, sem=3)[0]
+    want_ao = osc.trace_ao(ov, w, h, want_p, sem=3, frame=5, ao_eps=0.01)[0]
+    sc = trx.Scene(flat)
+    try:
+        for overlap in (False, True):
+            for n in (1, 3, 6):
+                _, gp, gao = sc.frame_loop(view, w, h, sem=3, frames=n, frame0=6 - n, animate=True, ao_eps=0.01, overlap=overlap)
+                assert_hits_equal(gp, want_p, "two-level frame loop primary, overlap %d, %d frames" % (overlap, n))
+                assert_hits_equal(gao, want_ao, "two-level frame loop AO, overlap %d, %d frames" % (overlap, n))
+    finally:
+        sc.close()
+
+
 def test_camera_cuts_and_schedule_modes_never_change_the_hits(trx, orc):
     """The tile order is replayed whatever the camera did (a stale order measured no worse than none); a camera cut
     restarts the schedule tuner.  Alternating between two unrelated cameras (every frame a cut), drifting slowly, variant
