@@ -49,6 +49,12 @@ int trx_debug_tile_profile(trx_scene *scene, const trx_view *view, uint32_t widt
  * shared a launch on average).  Either pointer may be NULL. */
 int trx_debug_traverse1_stats(trx_scene *scene, uint64_t *out_launches, uint64_t *out_rays);
 
+/* The ray services of the scene (single-level scenes: a resident kernel answers trx_traverse1, include/trx.h) so far: calls
+ * answered, kernel starts, nanoseconds callers spent between posting a ray and reading its answer, the GPU-side share of
+ * that in 100 MHz ticks (admission to answer) and the trips of the walks.  Any pointer may be NULL. */
+int trx_debug_service_stats(trx_scene *scene, uint64_t *out_rays, uint64_t *out_starts, uint64_t *out_call_ns,
+                            uint64_t *out_walk_ticks, uint64_t *out_walk_trips);
+
 /* Measuring aid: the reference's CPU pixel loop over the literal Traversable::traverse (src/rt_cpu/rt_cpu.rs:35-57) -
  * `threads` host threads, thread k calls trx_traverse1 for rays k, k + threads, ... - with the loop's wall-clock seconds and
  * the launches its calls shared. */

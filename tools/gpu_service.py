@@ -94,4 +94,7 @@ stop = True
 t.join()
 print("primary frame alone: min %.4f mean %.4f ms; with the ray service resident (one caller every 5 ms): min %.4f mean %.4f ms" % (
     min(b[0] for b in base), sum(b[1] for b in base) / 3, min(b[0] for b in withsvc), sum(b[1] for b in withsvc) / 3))
+st = sc.service_stats()
+print("ray service: %d rays, %d starts: %.2f us per call from post to answer (all thread counts above), of which %.2f us between admission "
+      "and answer on the GPU (%.1f trips of the walk)" % (st["rays"], st["starts"], st["us_per_call"], st["gpu_us_per_call"], st["trips_per_call"]))
 sc.close()

@@ -124,6 +124,7 @@ SIGNATURES = {
     "trx_debug_traverse1_stats": (_i, [_P, C.POINTER(_u64), C.POINTER(_u64)]),
     "trx_debug_fetch_rate": (_i, [_P, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "trx_debug_copy_rate": (_i, [_i, _u64, _u32, C.POINTER(C.c_double)]),
+    "trx_debug_service_stats": (_i, [_P] + [C.POINTER(_u64)] * 5),
     "trx_debug_traverse1_threads": (_i, [_P, _P, _u64, _u32, _u32, _P, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "trx_traverse_batch": (_i, [_P, _P, _u64, _u32, _P, C.POINTER(_f)]),
     "trx_bench_primary": (_i, [_P, C.POINTER(View), _u32, _u32, _u32, _u32, _u32, C.POINTER(_f), C.POINTER(_f)]),

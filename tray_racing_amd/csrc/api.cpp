@@ -340,6 +340,8 @@ uint64_t trx_scene_device_bytes(const trx_scene *s) {
             if (o.lists) bytes += 2ull * (16 * kLptShards + (uint64_t)16 * kLptShards * (o.capacity / 2 + 64)) * sizeof(uint32_t);
         if (sl.ctr) bytes += sizeof(SlotCounters);
     }
+    // trx_frame_loop's record buffers (four primary, one AO; instance ids beside them on two-level scenes)
+    bytes += s->loop.records * (FrameLoop::kBuffers + 1) * (sizeof(trx_hit) + (s->tlas ? sizeof(uint32_t) : 0));
     return bytes;
 }
 int trx_scene_device(const trx_scene *s) { return s ? s->device : -1; }

@@ -196,7 +196,7 @@ struct RayService {
     bool ok = false;
     std::string init_err;
     std::atomic<uint64_t> starts{0}, rays{0};
-    std::atomic<uint64_t> walk_ticks{0}, walk_trips{0}, call_ns{0}; // statistics (TRX_SERVICE_STATS=1 prints them when the service goes)
+    std::atomic<uint64_t> walk_ticks{0}, walk_trips{0}, call_ns{0}; // statistics (trx_debug_service_stats)
     RayService(trx_scene *s, uint32_t semantics);
     ~RayService();
     int start_locked();  // mu held

@@ -81,12 +81,6 @@ RayService::RayService(trx_scene *s, uint32_t semantics) : scene(s), sem(semanti
 }
 
 RayService::~RayService() {
-    if (getenv("TRX_SERVICE_STATS") && rays.load() != 0) {
-        const double n = (double)rays.load();
-        fprintf(stderr, "[trx ray service sem %u] %llu rays, %llu starts: %.2f us per call from post to answer, of which %.2f us between "
-                        "admission and answer on the GPU (%.1f trips of the walk)\n", sem, (unsigned long long)rays.load(),
-                (unsigned long long)starts.load(), call_ns.load() / n * 1e-3, walk_ticks.load() / n * 1e-2, walk_trips.load() / n);
-    }
     {
         std::lock_guard<std::mutex> lock(g_services_mu);
         g_services.erase(std::remove(g_services.begin(), g_services.end(), this), g_services.end());
@@ -341,6 +335,29 @@ int trx_debug_traverse1_stats(trx_scene *s, uint64_t *out_launches, uint64_t *ou
         }
     if (out_launches) *out_launches = l;
     if (out_rays) *out_rays = r;
+    return TRX_OK;
+}
+
+// What the ray services of a scene have done so far (summed over the semantics words in use): calls answered, kernel starts,
+// nanoseconds callers spent between posting a ray and reading its answer, and of that the GPU-side share - 100 MHz ticks
+// from a ray's admission to its answer - with the walk's trips.  Any pointer may be NULL.
+int trx_debug_service_stats(trx_scene *s, uint64_t *out_rays, uint64_t *out_starts, uint64_t *out_call_ns, uint64_t *out_walk_ticks,
+                            uint64_t *out_walk_trips) {
+    if (!s) return fail(TRX_ERR_INVALID, "null argument");
+    uint64_t r = 0, st = 0, ns = 0, tk = 0, tr = 0;
+    for (RayService *v : s->svc)
+        if (v) {
+            r += v->rays.load(std::memory_order_relaxed);
+            st += v->starts.load(std::memory_order_relaxed);
+            ns += v->call_ns.load(std::memory_order_relaxed);
+            tk += v->walk_ticks.load(std::memory_order_relaxed);
+            tr += v->walk_trips.load(std::memory_order_relaxed);
+        }
+    if (out_rays) *out_rays = r;
+    if (out_starts) *out_starts = st;
+    if (out_call_ns) *out_call_ns = ns;
+    if (out_walk_ticks) *out_walk_ticks = tk;
+    if (out_walk_trips) *out_walk_trips = tr;
     return TRX_OK;
 }
 

@@ -394,6 +394,14 @@ class Scene:
                                                       C.byref(secs), C.byref(launches)))
         return out, secs.value, int(launches.value)
 
+    def service_stats(self):
+        """The scene's ray services so far (trx_debug_service_stats): dict of rays, starts, us_per_call, gpu_us_per_call, trips_per_call."""
+        v = [C.c_uint64() for _ in range(5)]
+        L.check(self._lib.trx_debug_service_stats(self._h, *[C.byref(x) for x in v]))
+        n = max(v[0].value, 1)
+        return {"rays": v[0].value, "starts": v[1].value, "us_per_call": v[2].value / n * 1e-3, "gpu_us_per_call": v[3].value / n * 1e-2,
+                "trips_per_call": v[4].value / n}
+
     def traverse_batch(self, rays, sem=L.SEM_HLSL):
         """Traversable::traverse for a whole batch in one launch: (RAYHIT_DTYPE array, ms)."""
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
