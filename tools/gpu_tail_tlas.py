@@ -4,7 +4,14 @@ sys.path.insert(0, os.getcwd())
 import tray_racing_amd as T
 from tray_racing_amd import _lib as L
 lib = L.load()
-for name, tlas, w, h in (("san_miguel", True, 3840, 2160), ("san_miguel", False, 3840, 2160), ("hairball", False, 1920, 1080)):
+cases = (("san_miguel", True, 3840, 2160), ("san_miguel", False, 3840, 2160), ("hairball", False, 1920, 1080))
+if len(sys.argv) > 1:   # scene[:tlas[:WxH]] ...
+    cases = []
+    for a in sys.argv[1:]:
+        f = a.split(":")
+        wh = f[2].split("x") if len(f) > 2 else ("1920", "1080")
+        cases.append((f[0], len(f) > 1 and f[1] == "1", int(wh[0]), int(wh[1])))
+for name, tlas, w, h in cases:
     verts, counts = T.gen_scene(name, 0, 1)
     flat = T.flat_build(verts, counts, use_tlas=tlas)
     eye, look, fov = T.scene_camera(name)
