@@ -187,16 +187,32 @@ struct RayService {
     hipStream_t stream = nullptr;
     std::mutex mu;                    // start / stop
     std::atomic<bool> running{false};
-    std::atomic<int> inside{0};
-    std::atomic<int64_t> last_use_ns{0};
-    std::atomic<uint32_t> busy[kSlots];
-    uint32_t seq[kSlots];             // last sequence number used on the slot (its current owner's to bump)
+    // Per slot, on cache lines of its own: everything a call writes on the host side.  (Until late in round 6 every call
+    // bumped seven process-wide words - a count of callers inside, the last use, four statistics - and the slots' busy
+    // flags sat sixteen to a line: from ten threads on the calls queued for those lines, 2.2-2.5 us apiece system-wide,
+    // whatever the walk took - 0.40-0.47 Mrays/s was that queue, not the GPU.)
+    struct alignas(128) Caller {
+        std::atomic<uint32_t> busy{0};     // a caller owns the slot
+        uint32_t seq = 0;                  // last sequence number used on the slot (its current owner's to bump)
+        std::atomic<int64_t> last_use_ns{0};
+        std::atomic<uint64_t> rays{0}, walk_ticks{0}, walk_trips{0}, call_ns{0}; // statistics (trx_debug_service_stats)
+    };
+    Caller caller[kSlots];
     std::thread watchdog;
     std::atomic<bool> quit{false};
     bool ok = false;
     std::string init_err;
-    std::atomic<uint64_t> starts{0}, rays{0};
-    std::atomic<uint64_t> walk_ticks{0}, walk_trips{0}, call_ns{0}; // statistics (trx_debug_service_stats)
+    std::atomic<uint64_t> starts{0};
+    bool idle_since(int64_t t_ns) const { // no slot owned, none used since t_ns
+        for (const Caller &c : caller)
+            if (c.busy.load(std::memory_order_acquire) != 0u || c.last_use_ns.load(std::memory_order_relaxed) > t_ns) return false;
+        return true;
+    }
+    uint64_t sum(std::atomic<uint64_t> Caller::*field) const {
+        uint64_t n = 0;
+        for (const Caller &c : caller) n += (c.*field).load(std::memory_order_relaxed);
+        return n;
+    }
     RayService(trx_scene *s, uint32_t semantics);
     ~RayService();
     int start_locked();  // mu held

@@ -38,8 +38,6 @@ static void stop_services_at_exit() {
 }
 
 RayService::RayService(trx_scene *s, uint32_t semantics) : scene(s), sem(semantics) {
-    for (auto &b : busy) b.store(0u, std::memory_order_relaxed);
-    std::memset(seq, 0, sizeof(seq));
     hipError_t e = hipHostMalloc((void **)&ring, (size_t)kSlots * kSvcSlotWords * 4, hipHostMallocCoherent | hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctl, 64, hipHostMallocCoherent | hipHostMallocMapped);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
@@ -49,7 +47,7 @@ RayService::RayService(trx_scene *s, uint32_t semantics) : scene(s), sem(semanti
     }
     std::memset(ring, 0, (size_t)kSlots * kSvcSlotWords * 4);
     std::memset(ctl, 0, 64);
-    last_use_ns.store(now_ns(), std::memory_order_relaxed);
+    caller[0].last_use_ns.store(now_ns(), std::memory_order_relaxed);
     try {
         watchdog = std::thread([this]() {
             (void)hipSetDevice(scene->device);
@@ -57,10 +55,11 @@ RayService::RayService(trx_scene *s, uint32_t semantics) : scene(s), sem(semanti
             while (!quit.load(std::memory_order_acquire)) {
                 std::this_thread::sleep_for(std::chrono::nanoseconds(kBeatNs));
                 reinterpret_cast<volatile uint32_t *>(ctl)[1] = (uint32_t)++beat;
-                if (running.load(std::memory_order_acquire) && inside.load(std::memory_order_acquire) == 0 &&
-                    now_ns() - last_use_ns.load(std::memory_order_relaxed) > kIdleStopNs) {
+                // (a caller that claims a slot at this very moment finds the service stopped and starts it again - its request
+                // is still in the ring: traverse1_service looks every 1024 spins)
+                if (running.load(std::memory_order_acquire) && idle_since(now_ns() - kIdleStopNs)) {
                     std::lock_guard<std::mutex> lock(mu);
-                    if (inside.load(std::memory_order_acquire) == 0) stop_locked();
+                    if (idle_since(now_ns() - kIdleStopNs)) stop_locked();
                 }
             }
         });
@@ -117,6 +116,14 @@ void RayService::stop_locked() {
     (void)hipSetDevice(scene->device);
     reinterpret_cast<volatile uint32_t *>(ctl)[0] = 1u;
     (void)hipStreamSynchronize(stream);
+#ifdef TRX_SVC_PHASES   // (tuning builds, trace_thin.inc: cycles per step of the walkers' trips)
+    for (uint32_t g = 0; g < kGroups; g++) {
+        const volatile uint32_t *w = ring + (size_t)g * trx::kSvcRays * trx::kSvcSlotWords + 20;
+        if (w[7] != 0u)
+            fprintf(stderr, "SVC_PHASES group %u: %u trips; cycles per trip: (0) %.0f (1) %.0f (2) %.0f (3) %.0f (4) %.0f (5) %.0f back-edge %.0f\n", g, w[7],
+                    (double)w[0] / w[7], (double)w[1] / w[7], (double)w[2] / w[7], (double)w[3] / w[7], (double)w[4] / w[7], (double)w[5] / w[7], (double)w[6] / w[7]);
+    }
+#endif
     {
         std::lock_guard<std::mutex> lock(scene->mu);
         for (Slot &sl : scene->slots)
@@ -331,7 +338,7 @@ int trx_debug_traverse1_stats(trx_scene *s, uint64_t *out_launches, uint64_t *ou
     for (RayService *v : s->svc)
         if (v) { // (the service launches once per start, not per ray)
             l += v->starts.load(std::memory_order_relaxed);
-            r += v->rays.load(std::memory_order_relaxed);
+            r += v->sum(&RayService::Caller::rays);
         }
     if (out_launches) *out_launches = l;
     if (out_rays) *out_rays = r;
@@ -347,11 +354,11 @@ int trx_debug_service_stats(trx_scene *s, uint64_t *out_rays, uint64_t *out_star
     uint64_t r = 0, st = 0, ns = 0, tk = 0, tr = 0;
     for (RayService *v : s->svc)
         if (v) {
-            r += v->rays.load(std::memory_order_relaxed);
+            r += v->sum(&RayService::Caller::rays);
             st += v->starts.load(std::memory_order_relaxed);
-            ns += v->call_ns.load(std::memory_order_relaxed);
-            tk += v->walk_ticks.load(std::memory_order_relaxed);
-            tr += v->walk_trips.load(std::memory_order_relaxed);
+            ns += v->sum(&RayService::Caller::call_ns);
+            tk += v->sum(&RayService::Caller::walk_ticks);
+            tr += v->sum(&RayService::Caller::walk_trips);
         }
     if (out_rays) *out_rays = r;
     if (out_starts) *out_starts = st;
@@ -398,14 +405,6 @@ static int traverse1_service(trx_scene *s, const trx_ray *ray, uint32_t sem, trx
             s->svc[sem & 7u] = v;
         }
     }
-    struct Inside {
-        RayService *v;
-        explicit Inside(RayService *p) : v(p) { v->inside.fetch_add(1, std::memory_order_acq_rel); }
-        ~Inside() {
-            v->last_use_ns.store(now_ns(), std::memory_order_relaxed);
-            v->inside.fetch_sub(1, std::memory_order_acq_rel);
-        }
-    } inside(v);
     auto ensure_running = [&]() -> int {
         if (v->running.load(std::memory_order_acquire)) return TRX_OK;
         std::lock_guard<std::mutex> lock(v->mu);
@@ -423,14 +422,15 @@ static int traverse1_service(trx_scene *s, const trx_ray *ray, uint32_t sem, trx
     uint32_t k = slot_at(my_pos);
     for (uint32_t tries = 0;; tries++) {
         uint32_t expect = 0u;
-        if (v->busy[k].compare_exchange_strong(expect, 1u, std::memory_order_acquire)) break;
+        if (v->caller[k].busy.compare_exchange_strong(expect, 1u, std::memory_order_acquire)) break;
         my_pos = (my_pos + 1u) % RayService::kSlots;
         k = slot_at(my_pos);
         if (tries > RayService::kSlots) std::this_thread::yield(); // more callers than slots: wait for one
     }
-    uint32_t seq = v->seq[k] + 1u;
+    RayService::Caller &me = v->caller[k];
+    uint32_t seq = me.seq + 1u;
     if (seq == 0u) seq = 1u;
-    v->seq[k] = seq;
+    me.seq = seq;
     uint32_t *slot = v->ring + (size_t)k * kSvcSlotWords;
     const float tmax = ray->tmax;
     // three 16-byte stores, each whole on its own (the kernel takes the request once all three carry `seq`)
@@ -441,16 +441,25 @@ static int traverse1_service(trx_scene *s, const trx_ray *ray, uint32_t sem, trx
     _mm_sfence();
     const volatile uint32_t *ans = slot + 16;
     const int64_t t0 = now_ns();
-    const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+    // (more calling threads than cores: give the core away between looks.  Threads are counted once, when they first call.)
+    static std::atomic<int> calling_threads{0};
+    struct Registered {
+        Registered() { calling_threads.fetch_add(1, std::memory_order_relaxed); }
+        ~Registered() { calling_threads.fetch_sub(1, std::memory_order_relaxed); }
+    };
+    thread_local Registered registered;
+    (void)registered;
+    static const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+    const bool crowded = calling_threads.load(std::memory_order_relaxed) > cores;
     for (uint32_t spins = 0; ans[3] != seq; spins++) {
-        if (v->inside.load(std::memory_order_relaxed) > cores) std::this_thread::yield();
+        if (crowded) std::this_thread::yield();
         else cpu_relax();
         if ((spins & 0x3ffu) == 0x3ffu) {
             // (the service stops itself after 50 ms without callers; one that arrives at that very moment starts it again -
             // its request is still in the ring)
             rc = ensure_running();
             if (rc || now_ns() - t0 > RayService::kGiveUpNs) {
-                v->busy[k].store(0u, std::memory_order_release);
+                me.busy.store(0u, std::memory_order_release);
                 return rc ? rc : fail(TRX_ERR_NO_DEVICE, "the ray service did not answer within %lld s", (long long)(RayService::kGiveUpNs / 1000000000));
             }
         }
@@ -458,12 +467,14 @@ static int traverse1_service(trx_scene *s, const trx_ray *ray, uint32_t sem, trx
     const __m128i a = _mm_load_si128(reinterpret_cast<const __m128i *>(slot + 16));
     alignas(16) uint32_t w[4];
     _mm_store_si128(reinterpret_cast<__m128i *>(w), a);
-    v->busy[k].store(0u, std::memory_order_release);
-    v->rays.fetch_add(1, std::memory_order_relaxed);
+    const int64_t t1 = now_ns();
+    me.rays.fetch_add(1, std::memory_order_relaxed);
+    me.walk_ticks.fetch_add((w[2] >> 1) & 0x7fffu, std::memory_order_relaxed);
+    me.walk_trips.fetch_add(w[2] >> 16, std::memory_order_relaxed);
+    me.call_ns.fetch_add((uint64_t)(t1 - t0), std::memory_order_relaxed);
+    me.last_use_ns.store(t1, std::memory_order_relaxed);
+    me.busy.store(0u, std::memory_order_release);
     if (w[3] != seq) return fail(TRX_ERR_NO_DEVICE, "the ray service's answer was torn");
-    v->walk_ticks.fetch_add((w[2] >> 1) & 0x7fffu, std::memory_order_relaxed);
-    v->walk_trips.fetch_add(w[2] >> 16, std::memory_order_relaxed);
-    v->call_ns.fetch_add((uint64_t)(now_ns() - t0), std::memory_order_relaxed);
     if (w[2] & 1u) return fail(TRX_ERR_STACK_OVERFLOW, "a ray overflowed the %d-entry traversal stack (or the step cap)", kLdsStack + kSpillStack);
     trx_hit h;
     std::memcpy(&h.t, &w[0], 4);
