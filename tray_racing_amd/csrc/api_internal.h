@@ -179,7 +179,7 @@ struct FrameLoop {
 // trx_scene_destroy), so that device-wide synchronisations elsewhere in the process wait for it no longer than that; the
 // same thread bumps the heartbeat without which the kernel leaves by itself.
 struct RayService {
-    static constexpr uint32_t kGroups = 8, kSlots = kGroups * trx::kSvcRays;
+    static constexpr uint32_t kGroups = 16, kSlots = kGroups * trx::kSvcRays;
     static constexpr int64_t kIdleStopNs = 50 * 1000 * 1000, kBeatNs = 2 * 1000 * 1000, kGiveUpNs = 5LL * 1000 * 1000 * 1000;
     trx_scene *scene = nullptr;
     uint32_t sem = 0;

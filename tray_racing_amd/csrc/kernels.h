@@ -49,10 +49,11 @@ constexpr uint32_t kMaxSteps = 1u << 22; // per-ray iteration cap: every wave re
 enum TraceMode : int { kModePrimary = 0, kModeAo = 1, kModeRays = 2, kModeFused = 3, kModeService = 4 };
 
 // The ray service (k_trace<kModeService>; api_traverse.cpp holds the host side).  A workgroup is two waves: the WALKER
-// steps up to kSvcRays rays, eight lanes to a ray (the thin walk of an incoherent pass's last rays), and never touches
-// host memory - a load from it takes 1.5-2 us, and a wave's loads return in order, so a poll in flight would hold up
-// every node fetch behind it; the PORTER polls the workgroup's kSvcRays request slots, hands complete requests to the
-// walker through mailboxes in LDS and carries the walker's answers back to the slots' answer words.
+// steps up to kSvcRays rays, eight lanes to a ray (the thin walk of an incoherent pass's last rays), and reads nothing
+// from host memory - a load from it takes 1.5-2 us, and a wave's loads return in order, so a poll in flight would hold up
+// every node fetch behind it; the PORTER polls the workgroup's kSvcRays request slots - through the SCALAR cache: a CU's
+// vector-memory path makes the walker's requests wait for the porter's as well (trace_service.inc) - and hands complete
+// requests to the walker through mailboxes in LDS; the walker stores its answers into the slots' answer words itself.
 //   slot k of the ring = 128 bytes: [0..47] the request, three 16-byte granules {ox oy oz seq}{dx dy dz seq}{tmin tmax 0
 // seq}, each written by ONE 16-byte store of the host (a request is complete when the three carry the same seq, and new
 // when that differs from the slot's last answer); [64..79] the answer {t, prim, overflow, seq}, one 16-byte store of the
@@ -60,7 +61,7 @@ enum TraceMode : int { kModePrimary = 0, kModeAo = 1, kModeRays = 2, kModeFused 
 //   control words (pinned host memory): [0] != 0: leave (set when no caller is inside trx_traverse1); [1] a heartbeat
 // the host bumps every few milliseconds while the service is up - a porter that sees it stand still for kSvcDeadTicks of
 // the 100 MHz wall clock takes the host for dead and leaves as well: every wave of the grid reaches its exit.
-constexpr uint32_t kSvcRays = 8;                 // request slots per workgroup (one ray per eight lanes of the walker)
+constexpr uint32_t kSvcRays = 4;                 // request slots per workgroup (one ray per eight lanes of the walker's lower half: the porter reads a workgroup's requests in ONE look - 4 x 12 words are what its scalar registers hold)
 constexpr uint32_t kSvcSlotWords = 32;           // 128 bytes per slot
 constexpr unsigned long long kSvcDeadTicks = 200000000ull; // 2 s without a heartbeat
 

@@ -634,6 +634,7 @@ __device__ __forceinline__ const TraceParams *refill_params() {
 // requested ahead (vmcnt).  Round 4 shipped that for a while: AO passes +8-10 %, profiles/r04_flat_stack_pop.log.
 // tests/test_kernel_resources.py holds the line (no flat_load_dwordx2 in any trace kernel).
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
 __device__ __forceinline__ uint2 lds_ld(const lds_u32x2 *p) {
     const u32x2 v = *p;
