@@ -991,15 +991,35 @@ def main():
             t1_hits, t1_s, t1_launches = scene.traverse_threads(t1_rays, threads=16, sem=args.sem)
             tb_hits, tb_ms = scene.traverse_batch(t1_rays, sem=args.sem)
             one_hits, one_s, _ = scene.traverse_threads(t1_rays[:2000], threads=1, sem=args.sem)
+            # ... and with the reference's own access pattern (`(0..w*h).into_par_iter()`, rt_cpu.rs:35: rayon hands every worker a
+            # CONTIGUOUS run of pixel indices): thread k walks pixels k m .. (k + 1) m - 1 of the frame's middle rows
+            m_run = 1500
+            idx = np.arange(16 * m_run) + (h // 2) * w
+            fx = (idx % w + 0.5) / w * 2.0 - 1.0
+            fy = 1.0 - (idx // w + 0.5) / h * 2.0
+            dirs = fwd[None, :] + (fx * th * w / h)[:, None] * right[None, :] + (fy * th)[:, None] * up[None, :]
+            dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+            runs = np.zeros(16 * m_run, dtype=T.RAY_DTYPE)
+            runs["origin"] = np.array(eye, dtype=np.float32)
+            runs["direction"] = dirs.astype(np.float32)
+            runs["tmax"] = 3.4028234663852886e38
+            dealt = np.empty_like(runs)
+            for k in range(16):
+                dealt[k::16] = runs[k * m_run:(k + 1) * m_run]   # (the helper gives thread k the rays k, k + 16, ...)
+            run_hits, run_s, _ = scene.traverse_threads(dealt, threads=16, sem=args.sem)
+            runb_hits, _ = scene.traverse_batch(dealt, sem=args.sem)
+            st = scene.service_stats()
             legs["traverse1_threads"] = {
                 "threads": 16, "rays": n_t1, "mrays": round(n_t1 / t1_s / 1e6, 4),
                 # (single-level scenes since round 6: a resident kernel answers the calls - `service_starts` kernel launches for
                 # all of them instead of one per batch of callers)
                 "service_starts": t1_launches, "us_per_call_and_thread": round(t1_s / n_t1 * 16 * 1e6, 2),
-                "equals_traverse_batch": bool((t1_hits == tb_hits).all() and (one_hits == tb_hits[:2000]).all()),
+                "equals_traverse_batch": bool((t1_hits == tb_hits).all() and (one_hits == tb_hits[:2000]).all() and (run_hits == runb_hits).all()),
+                "pixel_runs_mrays": round(len(dealt) / run_s / 1e6, 4), "pixel_runs_us_per_call_and_thread": round(run_s / len(dealt) * 16 * 1e6, 2),
+                "gpu_us_per_call": round(st["gpu_us_per_call"], 2), "trips_per_call": round(st["trips_per_call"], 1),
                 "traverse_batch_kernel_mrays": round(n_t1 / (tb_ms * 1e-3) / 1e6, 1),
                 "one_thread_mrays": round(2000 / one_s / 1e6, 4), "one_thread_us_per_call": round(one_s / 2000 * 1e6, 2),
-                "note": "one blocking trx_traverse1 call per ray from 16 host threads (and from one): Traversable::traverse, literally",
+                "note": "one blocking trx_traverse1 call per ray from 16 host threads (and from one): Traversable::traverse, literally; `mrays`: random pixels, `pixel_runs_mrays`: every thread a contiguous run of pixels (rayon's split of the reference's loop)",
             }
 
         def leg_footprint():
