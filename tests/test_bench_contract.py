@@ -97,7 +97,7 @@ def test_roofline_objects(line):
     # which coherent rays share through the caches, are reported as a rate and priced against nothing
     h = line["roofline_hbm"]
     assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["peak"] == 8000.0
-    assert "requested_over_hbm_peak" not in h and h["frac"] == pytest.approx(h["achieved"] / h["peak"], rel=2e-3) and 0 < h["frac"] < 0.1
+    assert "requested_over_hbm_peak" not in h and h["frac"] == pytest.approx(h["achieved"] / h["peak"], abs=1e-4) and 0 < h["frac"] < 0.1
     assert h["achieved"] == pytest.approx(h["traffic"] / (line["kernel_ms_mean"] * 1e-3) / 1e9, rel=2e-3)
     per_ray = 80 * h["nodes_per_ray"] + 48 * h["tris_per_ray"] + 8       # algorithmic bytes per ray
     assert h["bytes_per_launch"] == pytest.approx(per_ray * 1920 * 1080, rel=1e-3)
@@ -159,8 +159,11 @@ def test_cpu_baseline_and_legs(line):
     assert g["build_seconds"] < 0.5 * p["build_seconds"] and g["build_seconds"] <= 2.0 and g["nodes_per_ray"] <= p["nodes_per_ray"]
     t1 = legs["traverse1_threads"]
     assert t1["threads"] == 16 and t1["equals_traverse_batch"] is True and t1["mrays"] > 0.1
-    if line["protocol_version"] >= 6:   # the resident ray service: a handful of kernel starts, twice round 5's rate
-        assert t1["service_starts"] < 8 and t1["mrays"] > 0.3 and t1["one_thread_mrays"] > 0.02
+    if line["protocol_version"] >= 6:   # the resident ray service: a handful of kernel starts, four times round 5's rate
+        assert t1["service_starts"] < 8 and t1["mrays"] > 0.6 and t1["one_thread_mrays"] > 0.045
+        # ... every thread a contiguous run of pixels, as rayon deals out the reference's loop (rt_cpu.rs:35); on the GPU a call is
+        # its ray's trips, well under a microsecond each since the porter polls through the scalar cache (EXPERIMENTS 6.7)
+        assert t1["pixel_runs_mrays"] > 0.6 and 0.4 < t1["gpu_us_per_call"] / t1["trips_per_call"] < 1.0
     # round 5, second half: the incoherent passes against the measured no-locality fetch rate of the same scene (trx_debug_fetch_rate)
     for leg in (legs["ao_pass_ms"]["fetch_vs_random"], legs["random_rays_ms"]["fetch_vs_random"], hb["ao_pass_fetch_vs_random"]):
         assert leg["random_fetch_gbs"] > 1000 and leg["requested_gbs"] > 0.4 * leg["random_fetch_gbs"]   # north_star's ">= 40 % of the measured roofline"
@@ -191,8 +194,11 @@ def test_the_drivers_protocol_lines_of_the_round():
         assert len(d["kernel_ms_per_step"]) == 20
     assert all(d["config"]["wake_frames"] == 64 and d["value"] > 4800 for d in lines)
     assert cold["config"]["wake_frames"] == 0 and cold["value"] < min(d["value"] for d in lines)
-    # a GPU still at idle clocks: the per-launch series falls through the timed region
-    assert cold["kernel_ms_per_step"][0] > cold["kernel_ms_per_step"][-1] * 1.01
+    # a GPU that has not been woken: the step costs over a per cent more, and the series' first launch is not its fastest
+    # (how the series falls differs from box to box - on some the clocks are up after the scene's build, and what is left is
+    # launch gaps)
+    assert cold["ms_per_step"] > min(d["ms_per_step"] for d in lines) * 1.01
+    assert cold["kernel_ms_per_step"][0] > min(cold["kernel_ms_per_step"]) * 1.01
 
 
 def test_default_arguments_finish_in_minutes():
