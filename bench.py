@@ -1022,6 +1022,47 @@ def main():
                 "note": "one blocking trx_traverse1 call per ray from 16 host threads (and from one): Traversable::traverse, literally; `mrays`: random pixels, `pixel_runs_mrays`: every thread a contiguous run of pixels (rayon's split of the reference's loop)",
             }
 
+        def leg_traverse1_two_level():
+            # (k2) the same literal traverse over a TWO-LEVEL scene (the reference's CwBvhTlasScene, src/rt_cpu/mod.rs:48-60): answered by
+            #      the resident service as well since the thin walk learned its two levels (late round 6; the launch combiner of round 5
+            #      before that) - a reduced san-miguel-class scene, so that the default run stays short
+            v2, c2 = T.gen_scene("san_miguel", 600000, 1)
+            f2 = T.flat_build(v2, c2, use_tlas=True)
+            e2, l2, fov2 = T.scene_camera("san_miguel")
+            w2, h2 = 640, 360
+            sc2 = T.Scene(f2, device=local_rank)
+            try:
+                rng = np.random.default_rng(13)
+                px = rng.integers(0, w2 * h2, 16 * 600)
+                fx = (px % w2 + 0.5) / w2 * 2.0 - 1.0
+                fy = 1.0 - (px // w2 + 0.5) / h2 * 2.0
+                fwd = np.array(l2, dtype=np.float64) - np.array(e2, dtype=np.float64)
+                fwd /= np.linalg.norm(fwd)
+                right = np.cross(fwd, [0.0, 1.0, 0.0])
+                right /= np.linalg.norm(right)
+                up = np.cross(right, fwd)
+                th = np.tan(np.radians(fov2) / 2.0)
+                dirs = fwd[None, :] + (fx * th * w2 / h2)[:, None] * right[None, :] + (fy * th)[:, None] * up[None, :]
+                dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+                r2 = np.zeros(len(px), dtype=T.RAY_DTYPE)
+                r2["origin"] = np.array(e2, dtype=np.float32)
+                r2["direction"] = dirs.astype(np.float32)
+                r2["tmax"] = 3.4028234663852886e38
+                sc2.traverse_threads(r2[:512], threads=16, sem=args.sem)
+                g16, s16, starts = sc2.traverse_threads(r2, threads=16, sem=args.sem)
+                g1, s1, _ = sc2.traverse_threads(r2[:1500], threads=1, sem=args.sem)
+                gb, _ = sc2.traverse_batch(r2, sem=args.sem)
+                st = sc2.service_stats()
+                legs["traverse1_two_level"] = {
+                    "scene": "san_miguel (600 000 triangles, %d TLAS primitives)" % int(f2.instance_offsets.shape[0]), "threads": 16, "rays": int(len(px)),
+                    "mrays": round(len(px) / s16 / 1e6, 4), "us_per_call_and_thread": round(s16 / len(px) * 16 * 1e6, 2),
+                    "one_thread_mrays": round(1500 / s1 / 1e6, 4), "one_thread_us_per_call": round(s1 / 1500 * 1e6, 2),
+                    "service_starts": starts, "gpu_us_per_call": round(st["gpu_us_per_call"], 2), "trips_per_call": round(st["trips_per_call"], 1),
+                    "equals_traverse_batch": bool((g16 == gb).all() and (g1 == gb[:1500]).all()),
+                }
+            finally:
+                sc2.close()
+
         def leg_footprint():
             # (f) compulsory footprint: distinct nodes / triangles one frame touches
             fn, ft = scene.footprint(view, w, h, sem=args.sem)
@@ -1035,7 +1076,8 @@ def main():
                          ("dense_scene", leg_dense_scene), ("ploc_pipeline", leg_ploc_pipeline),
                          ("ploc_pipeline_gpu_stages", leg_ploc_pipeline_gpu_stages), ("preset_build_gpu", leg_medium_build_gpu),
                          ("no_wake", leg_no_wake),
-                         ("traverse1_threads", leg_traverse1_threads), ("footprint", leg_footprint)):
+                         ("traverse1_threads", leg_traverse1_threads), ("traverse1_two_level", leg_traverse1_two_level),
+                         ("footprint", leg_footprint)):
             run_leg(name, fn)
             ctx.pop("tmp", None)
         ctx.clear()

@@ -392,12 +392,15 @@ int trx_trace_rays_inst(trx_scene *scene, const trx_ray *rays, uint64_t n_rays, 
 int trx_trace_occluded(trx_scene *scene, const trx_ray *rays, uint64_t n_rays, uint32_t semantics,
                        uint8_t *out_flags, float *out_ms);
 /* Single-ray Traversable::traverse (traversable/src/lib.rs:13-28).  Thread-safe and meant to be called the way the
- * reference calls it - from every worker of a thread pool at once (src/rt_cpu/rt_cpu.rs:35-57): the callers that are
- * inside this function at the same moment share ONE launch (a per-scene combiner: a caller drops its ray into the open
- * batch - pinned host memory the kernel reads and writes in place - the first one in waits until arrivals pause for 3 us,
- * 4 096 rays have gathered or 50 us have passed, launches, and wakes the others, who read their records by ticket).
- * A caller blocks for one GPU round trip, so the rate is (concurrent callers) / (round trip): use trx_traverse_batch
- * where the rays can be had together.  primitive_id indexes the PERMUTED triangle
+ * reference calls it - from every worker of a thread pool at once (src/rt_cpu/rt_cpu.rs:35-57).  No call launches
+ * anything: the first call starts the scene's RAY SERVICE, a resident kernel that answers out of a ring of 64 slots in
+ * pinned host memory (a caller claims a slot, writes its ray, spins on the slot's answer; single- and two-level scenes,
+ * one service per semantics word in use) and that a watchdog thread stops 50 ms after the last call - until then a
+ * device-wide synchronisation elsewhere in the process (hipDeviceSynchronize, hipFree) waits for it; trx_scene_destroy
+ * stops it at once.  (TRX_TRAVERSE1_COMBINER=1 in the environment sends two-level scenes through round 5's path instead:
+ * the callers inside this function at the same moment share one launch.)  A caller blocks for its ray's own walk plus
+ * 4 us through host memory, so the rate is (concurrent callers) / (16-45 us): use trx_traverse_batch where the rays can
+ * be had together.  primitive_id indexes the PERMUTED triangle
  * list of the hit BLAS (primitive_indices order), exactly like the reference, whose scene structs store their
  * triangles in that order (src/rt_cpu/mod.rs:38-43) and index them with RayHit.primitive_id
  * (src/cwbvh.rs:151-160,177-186); trx_flat.tri_source[blas_tri_start[g] + primitive_id] names the input

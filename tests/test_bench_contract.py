@@ -164,6 +164,10 @@ def test_cpu_baseline_and_legs(line):
         # ... every thread a contiguous run of pixels, as rayon deals out the reference's loop (rt_cpu.rs:35); on the GPU a call is
         # its ray's trips, well under a microsecond each since the porter polls through the scalar cache (EXPERIMENTS 6.7)
         assert t1["pixel_runs_mrays"] > 0.6 and 0.4 < t1["gpu_us_per_call"] / t1["trips_per_call"] < 1.0
+        # ... and over a two-level scene (the reference's CwBvhTlasScene): the service as well, several times round 5's combiner
+        t2 = legs["traverse1_two_level"]
+        assert t2["equals_traverse_batch"] is True and t2["service_starts"] < 8 and t2["mrays"] > 0.25 and t2["one_thread_mrays"] > 0.02
+        assert t2["trips_per_call"] > t1["trips_per_call"]   # (two levels: the longer walk)
     # round 5, second half: the incoherent passes against the measured no-locality fetch rate of the same scene (trx_debug_fetch_rate)
     for leg in (legs["ao_pass_ms"]["fetch_vs_random"], legs["random_rays_ms"]["fetch_vs_random"], hb["ao_pass_fetch_vs_random"]):
         assert leg["random_fetch_gbs"] > 1000 and leg["requested_gbs"] > 0.4 * leg["random_fetch_gbs"]   # north_star's ">= 40 % of the measured roofline"

@@ -481,6 +481,41 @@ def test_the_ray_service_walks_deep_stacks_and_reports_overflow_per_call(trx, or
     sc.close()
 
 
+@pytest.mark.parametrize("kind", ["rebraided", "transformed"])
+def test_the_ray_service_walks_two_level_scenes(trx, orc, kind):
+    """trx_traverse1 over a two-level scene is answered by the resident service as well (late round 6: the thin walk's two
+    levels - instances entered and left, re-braided entry nodes, instance transforms, the instance id in a granule of its
+    own): sixteen threads' RayHits equal trx_traverse_batch's (the full-wave two-level walk) field for field and the
+    oracle's hits bit for bit, under the CPU preset and under the shader's text."""
+    from helpers import aimed_rays, instanced_scene
+    if kind == "rebraided":
+        w, h = 160, 120
+        flat, view, osc, ov = make_scene(trx, orc, "san_miguel", 120000, w, h, tlas=True)
+        assert flat.instance_entry is not None and (np.asarray(flat.instance_entry) != 0).any()   # the TLAS was re-braided
+        sc = trx.Scene(flat)
+        rays = np.concatenate([osc.primary_rays(ov, w, h), random_rays(trx, flat, 6000, 5)])
+    else:
+        flat, _o2w, world, _first, _blas_of = instanced_scene(trx, n_instances=24, tris_per_object=900)
+        sc = trx.Scene(flat)
+        osc = orc.Scene(flat.nodes, flat.tri_verts, flat.instance_offsets, flat.tlas_start, instance_w2o=sc.instance_world_to_object())
+        rays = np.concatenate([aimed_rays(trx, world, 12000, 7), random_rays(trx, flat, 4000, 9)])
+    for sem in (3, 0):
+        want, winst, _ = osc.trace_rays_inst(rays, sem=sem)
+        batch, _ms = sc.traverse_batch(rays, sem=sem)
+        before = sc.service_stats()["rays"]
+        got, secs, _starts = sc.traverse_threads(rays, threads=16, sem=sem)
+        assert sc.service_stats()["rays"] - before >= rays.shape[0]          # every call went through the service
+        hit = want["prim"] != 0xFFFFFFFF
+        assert hit.sum() > rays.shape[0] // 4
+        assert (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all(), sem
+        assert (got["instance_id"][hit] == winst[hit]).all() and (got["instance_id"][~hit] == 0xFFFFFFFF).all(), sem
+        for f in ("primitive_id", "geometry_id", "instance_id"):
+            assert (got[f] == batch[f]).all(), (sem, f)
+        assert (got["t"].view(np.uint32) == batch["t"].view(np.uint32)).all(), sem
+        print("two-level %s, sem %d: %d rays, %.3f Mrays/s from 16 threads" % (kind, sem, rays.shape[0], rays.shape[0] / secs / 1e6))
+    sc.close()
+
+
 def test_the_ray_service_restarts_after_idling_and_serves_more_callers_than_slots(trx, orc):
     """The resident kernel stops itself 50 ms after the last call (a device-wide synchronisation elsewhere waits no longer
     than that) and the next call starts it again - its request is served all the same; 100 threads on its 64 slots wait
@@ -930,10 +965,10 @@ def test_sixteen_threads_call_traverse_for_their_pixels(trx, orc, tmp_path):
 
 @pytest.mark.parametrize("tlas", [0, 1])
 def test_callers_of_mixed_semantics_share_the_single_ray_path(trx, orc, tmp_path, tlas):
-    """Even threads call trx_traverse1 with the CPU preset, odd threads with the shader's text, all at once: single-level
-    scenes run one ray service per semantics word, two-level scenes the launch combiner, whose batches are of one
-    semantics each (callers of another wait for the open batch to close) - every RayHit equals the oracle's under its
-    caller's semantics."""
+    """Even threads call trx_traverse1 with the CPU preset, odd threads with the shader's text, all at once: a scene runs
+    one ray service per semantics word (two-level scenes as well since the thin walk learned its two levels; round 5's launch
+    combiner, whose batches are of one semantics each, stays behind TRX_TRAVERSE1_COMBINER=1) - every RayHit equals the
+    oracle's under its caller's semantics."""
     import subprocess
     from test_abi import build_c_consumer
     exe = build_c_consumer("traverse_threads", tmp_path)

@@ -1,6 +1,6 @@
 """Round 6: rays per second of the single-ray trx_traverse1 through the resident ray service (single-level scenes) under
 1 / 4 / 16 / 64 host threads, against trx_traverse_batch on the same rays; and what the service's idle waves cost a
-concurrent primary frame.  usage: python tools/gpu_service.py [scene] [tris]"""
+concurrent primary frame.  usage: python tools/gpu_service.py [scene] [tris] [tlas]   (TRX_TRAVERSE1_COMBINER=1: two-level scenes through round 5's launch combiner)"""
 import os
 import sys
 import time
@@ -14,7 +14,8 @@ scene_name = sys.argv[1] if len(sys.argv) > 1 else "bistro"
 tris = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 w, h = 1920, 1080
 verts, counts = T.gen_scene(scene_name, tris, 1)
-flat = T.flat_build(verts, counts, preset="medium_build")
+two_level = len(sys.argv) > 3 and sys.argv[3] == "tlas"   # python tools/gpu_service.py san_miguel 0 tlas
+flat = T.flat_build(verts, counts, use_tlas=True) if two_level else T.flat_build(verts, counts, preset="medium_build")
 eye, look, fov = T.scene_camera(scene_name)
 view = T.view_from_camera(eye, look, fov, w, h)
 sc = T.Scene(flat)

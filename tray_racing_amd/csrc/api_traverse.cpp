@@ -118,7 +118,7 @@ void RayService::stop_locked() {
     (void)hipStreamSynchronize(stream);
 #ifdef TRX_SVC_PHASES   // (tuning builds, trace_thin.inc: cycles per step of the walkers' trips)
     for (uint32_t g = 0; g < kGroups; g++) {
-        const volatile uint32_t *w = ring + (size_t)g * trx::kSvcRays * trx::kSvcSlotWords + 20;
+        const volatile uint32_t *w = ring + (size_t)g * trx::kSvcRays * trx::kSvcSlotWords + 24;
         if (w[7] != 0u)
             fprintf(stderr, "SVC_PHASES group %u: %u trips; cycles per trip: (0) %.0f (1) %.0f (2) %.0f (3) %.0f (4) %.0f (5) %.0f back-edge %.0f\n", g, w[7],
                     (double)w[0] / w[7], (double)w[1] / w[7], (double)w[2] / w[7], (double)w[3] / w[7], (double)w[4] / w[7], (double)w[5] / w[7], (double)w[6] / w[7]);
@@ -160,8 +160,10 @@ static void to_rayhit(const trx_scene *s, const trx_hit h, uint32_t inst, trx_ra
 int trx_traverse1(trx_scene *s, const trx_ray *ray, uint32_t sem, trx_rayhit *out) {
     if (!s || !ray || !out) return fail(TRX_ERR_INVALID, "null argument");
     if (sem & ~7u) return fail(TRX_ERR_INVALID, "unknown semantics bits 0x%x", sem);
-    // single-level scenes: the resident ray service (no launch per ray); two-level scenes: the combiner below
-    if (!s->tlas) return traverse1_service(s, ray, sem, out);
+    // the resident ray service (no launch per ray).  (Two-level scenes went through the launch combiner below until the
+    // thin walk learned its two levels, late in round 6; TRX_TRAVERSE1_COMBINER=1 in the environment still sends them there.)
+    static const bool combiner_for_tlas = [] { const char *e = std::getenv("TRX_TRAVERSE1_COMBINER"); return e && e[0] == '1'; }();
+    if (!s->tlas || !combiner_for_tlas) return traverse1_service(s, ray, sem, out);
     HIP_TRY(hipSetDevice(s->device));
     std::call_once(s->comb_once, [s]() { s->comb = new (std::nothrow) RayCombiner(s->device); });
     RayCombiner *c = s->comb;
@@ -451,7 +453,10 @@ static int traverse1_service(trx_scene *s, const trx_ray *ray, uint32_t sem, trx
     (void)registered;
     static const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
     const bool crowded = calling_threads.load(std::memory_order_relaxed) > cores;
-    for (uint32_t spins = 0; ans[3] != seq; spins++) {
+    // (two-level scenes: a second granule {instance, -, -, seq} beside the answer; the two land in either order)
+    const volatile uint32_t *ans2 = slot + 20;
+    const bool two = s->tlas;
+    for (uint32_t spins = 0; ans[3] != seq || (two && ans2[3] != seq); spins++) {
         if (crowded) std::this_thread::yield();
         else cpu_relax();
         if ((spins & 0x3ffu) == 0x3ffu) {
@@ -465,8 +470,9 @@ static int traverse1_service(trx_scene *s, const trx_ray *ray, uint32_t sem, trx
         }
     }
     const __m128i a = _mm_load_si128(reinterpret_cast<const __m128i *>(slot + 16));
-    alignas(16) uint32_t w[4];
+    alignas(16) uint32_t w[4], w2[4] = {0xFFFFFFFFu, 0u, 0u, seq};
     _mm_store_si128(reinterpret_cast<__m128i *>(w), a);
+    if (two) _mm_store_si128(reinterpret_cast<__m128i *>(w2), _mm_load_si128(reinterpret_cast<const __m128i *>(slot + 20)));
     const int64_t t1 = now_ns();
     me.rays.fetch_add(1, std::memory_order_relaxed);
     me.walk_ticks.fetch_add((w[2] >> 1) & 0x7fffu, std::memory_order_relaxed);
@@ -474,11 +480,11 @@ static int traverse1_service(trx_scene *s, const trx_ray *ray, uint32_t sem, trx
     me.call_ns.fetch_add((uint64_t)(t1 - t0), std::memory_order_relaxed);
     me.last_use_ns.store(t1, std::memory_order_relaxed);
     me.busy.store(0u, std::memory_order_release);
-    if (w[3] != seq) return fail(TRX_ERR_NO_DEVICE, "the ray service's answer was torn");
+    if (w[3] != seq || w2[3] != seq) return fail(TRX_ERR_NO_DEVICE, "the ray service's answer was torn");
     if (w[2] & 1u) return fail(TRX_ERR_STACK_OVERFLOW, "a ray overflowed the %d-entry traversal stack (or the step cap)", kLdsStack + kSpillStack);
     trx_hit h;
     std::memcpy(&h.t, &w[0], 4);
     h.prim = w[1];
-    to_rayhit(s, h, 0xFFFFFFFFu, out);
+    to_rayhit(s, h, w2[0], out);
     return TRX_OK;
 }

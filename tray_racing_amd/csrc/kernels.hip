@@ -791,9 +791,9 @@ hipError_t launch_node(const TraceParams &p, int node, int grid, hipStream_t str
 template <int MODE>
 hipError_t launch_mode(const TraceParams &p, bool tlas, int node, bool count, bool pipe, int grid, hipStream_t stream) {
     if constexpr (MODE == kModeService) {
-        // (single-level scenes; the resident kernel is the plain thin walk: no pipelining, no counting)
-        if (tlas || count) return hipErrorInvalidValue;
-        return launch_node<MODE, false, false, false>(p, node, grid, stream);
+        // (the resident kernel is the plain thin walk, single- or two-level: no pipelining, no counting)
+        if (count) return hipErrorInvalidValue;
+        return tlas ? launch_node<MODE, true, false, false>(p, node, grid, stream) : launch_node<MODE, false, false, false>(p, node, grid, stream);
     } else {
         // (the one-launch frame exists for single-level scenes: the two-level walk has no registers to spare for the in-place
         // hand-over - it spills - so trx_trace_frame_dev runs a two-level frame as two launches, api_trace.cpp)
