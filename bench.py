@@ -967,9 +967,9 @@ def main():
 
         def leg_traverse1_threads():
             # (k) Traversable::traverse called the way the reference's CPU loop calls it (src/rt_cpu/rt_cpu.rs:35-57): 16 host
-            #     threads, ONE ray per call, every call blocking for its RayHit.  Concurrent callers share launches (the
-            #     per-scene combiner behind trx_traverse1); a caller still waits one GPU round trip per ray, so this is a latency
-            #     figure - threads / round trip - next to which trx_traverse_batch (the same rays in one call) is the throughput one
+            #     threads, ONE ray per call, every call blocking for its RayHit.  The scene's resident ray service answers (no launch
+            #     per ray); a caller still waits for its ray's own walk, so this is a latency figure - threads / call time - next to
+            #     which trx_traverse_batch (the same rays in one call) is the throughput one
             rng = np.random.default_rng(11)
             n_t1 = 16 * 1500
             px = rng.integers(0, n_rays_total, n_t1)

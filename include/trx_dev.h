@@ -45,11 +45,12 @@ int trx_debug_tri_histogram(trx_scene *scene, const trx_view *view, uint32_t wid
 int trx_debug_tile_profile(trx_scene *scene, const trx_view *view, uint32_t width, uint32_t height,
                            uint32_t semantics, uint32_t *out_cost, uint32_t *out_iters, uint32_t n_tiles);
 
-/* Launches issued and rays served by trx_traverse1's combiner on this scene so far (rays / launches = callers that
- * shared a launch on average).  Either pointer may be NULL. */
+/* Launches issued and rays served by trx_traverse1 on this scene so far: the ray services' kernel starts (a handful per
+ * stretch of calls) plus, under TRX_TRAVERSE1_COMBINER=1, the combiner's launches (rays / launches = callers that shared
+ * a launch on average).  Either pointer may be NULL. */
 int trx_debug_traverse1_stats(trx_scene *scene, uint64_t *out_launches, uint64_t *out_rays);
 
-/* The ray services of the scene (single-level scenes: a resident kernel answers trx_traverse1, include/trx.h) so far: calls
+/* The ray services of the scene (a resident kernel answers trx_traverse1, include/trx.h) so far: calls
  * answered, kernel starts, nanoseconds callers spent between posting a ray and reading its answer, the GPU-side share of
  * that in 100 MHz ticks (admission to answer) and the trips of the walks.  Any pointer may be NULL. */
 int trx_debug_service_stats(trx_scene *scene, uint64_t *out_rays, uint64_t *out_starts, uint64_t *out_call_ns,

@@ -54,6 +54,12 @@ def instanced_case(T, O, rng, case):
             got, gi, _ = sc.trace_rays_inst(rays, sem=sem)
             want, wi, _ = osc.trace_rays_inst(rays, sem=sem)
             bad += [("inst rays", differs(got, want)), ("inst ids", (int((gi != wi).sum()),) if (gi != wi).any() else None)]
+            if rng.integers(2):   # round 6: the same rays one by one through the ray service (two levels, instance transforms)
+                sub = rays[: int(rng.integers(1, 2500))]
+                one, _secs, _starts = sc.traverse_threads(sub, threads=int(rng.integers(1, 13)), sem=sem)
+                hit = want["prim"][: sub.shape[0]] != 0xFFFFFFFF
+                n_b = int((bits(one["t"]) != bits(want["t"][: sub.shape[0]])).sum()) + int((one["instance_id"][hit] != wi[: sub.shape[0]][hit]).sum())
+                bad += [("inst traverse1", (n_b,) if n_b else None)]
         else:
             w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
             lo, hi = world.reshape(-1, 3).min(0), world.reshape(-1, 3).max(0)
@@ -119,9 +125,17 @@ def one_case(T, O, rng, case):
         sc = T.Scene(flat)
         osc = O.Scene.from_flat(flat)
     bad = []
-    kind = int(rng.integers(6))
+    kind = int(rng.integers(7))
     try:
-        if kind == 4:      # round 4: n AO frames in one launch (trx_trace_ao_batch_dev), odd frame stride
+        if kind == 6:      # round 6: the literal single-ray traverse from a few host threads (the resident ray service, both levels)
+            rays = random_rays(T, flat, int(rng.integers(1, 3000)), seed)
+            got, _secs, _starts = sc.traverse_threads(rays, threads=int(rng.integers(1, 13)), sem=sem)
+            batch, _ms = sc.traverse_batch(rays, sem=sem)
+            want = osc.trace_rays(rays, sem=sem)[0]
+            n_t = int((bits(got["t"]) != bits(want["t"])).sum())
+            n_f = sum(int((got[f] != batch[f]).sum()) for f in ("primitive_id", "geometry_id", "instance_id")) + int((bits(got["t"]) != bits(batch["t"])).sum())
+            bad += [("traverse1 t vs oracle", (n_t,) if n_t else None), ("traverse1 vs traverse_batch", (n_f,) if n_f else None)]
+        elif kind == 4:      # round 4: n AO frames in one launch (trx_trace_ao_batch_dev), odd frame stride
             m, frame0, eps = int(rng.integers(2, 9)), int(rng.integers(0, 5000)), float(rng.choice([0.01, 0.0001]))
             stride = w * h + int(rng.integers(0, 7))
             d_p = torch.empty(w * h, dtype=torch.int64, device="cuda")
