@@ -9,9 +9,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tray_racing_amd as T  # noqa: E402
 
 w, h = 1920, 1080
-verts, counts = T.gen_scene("bistro", 0, 1)
+name = sys.argv[1] if len(sys.argv) > 1 else "bistro"
+verts, counts = T.gen_scene(name, 0, 1)
 flat = T.flat_build(verts, counts, preset="medium_build")
-eye, look, fov = T.scene_camera("bistro")
+eye, look, fov = T.scene_camera(name)
 sc = T.Scene(flat)
 rng = np.random.default_rng(11)
 px = rng.integers(0, w * h, 16)
