@@ -340,7 +340,7 @@ class Scene:
         ao = np.empty(width * height, dtype=HIT_DTYPE) if fetch else None
         ms = C.c_float()
         L.check(self._lib.trx_frame_loop(self._h, C.byref(view), width, height, sem, frame0, 1 if animate else 0, ao_eps, frames,
-                                         1 if overlap else 0, _ptr(prim) if fetch else None, _ptr(ao) if fetch else None, C.byref(ms)))
+                                         int(overlap), _ptr(prim) if fetch else None, _ptr(ao) if fetch else None, C.byref(ms)))
         return ms.value, prim, ao
 
     def trace_primary_ao_inst(self, view, width, height, sem=L.SEM_HLSL, frame=0, ao_eps=0.01):
